@@ -1,0 +1,1 @@
+"""tf1_shim: package marker (test infrastructure, see ../__init__.py)."""
