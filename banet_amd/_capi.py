@@ -1,0 +1,114 @@
+"""ctypes binding of libbanet_hip.so (the C ABI declared in include/banet_hip.h).
+
+PyTorch is used only as plumbing here: device memory (`tensor.data_ptr()`), the current
+HIP stream and the caching allocator for workspaces.  There is NO fallback: if the shared
+library is missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbanet_hip.so")
+
+LEGACY_LM, LEGACY_FIXED, BUNDLE_CAMERA, BUNDLE = 0, 1, 2, 3
+
+_FP = ctypes.c_void_p
+
+
+class BanetError(RuntimeError):
+    pass
+
+
+class Level(ctypes.Structure):
+    """mirror of banet_level_t"""
+    _fields_ = [("B", ctypes.c_int32), ("N", ctypes.c_int32), ("C", ctypes.c_int32), ("K", ctypes.c_int32),
+                ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("variant", ctypes.c_int32),
+                ("dense", ctypes.c_int32), ("tgt_has_grad", ctypes.c_int32), ("normalize_rays", ctypes.c_int32),
+                ("scale", ctypes.c_float), ("reserved_", ctypes.c_int32),
+                ("src", _FP), ("tgt", _FP), ("depth", _FP), ("basis", _FP), ("rays", _FP),
+                ("fx", _FP), ("fy", _FP), ("ox", _FP), ("oy", _FP), ("intr", _FP)]
+
+
+class Mlp(ctypes.Structure):
+    """mirror of banet_mlp_t"""
+    _fields_ = [("w", _FP * 5), ("b", _FP * 5)]
+
+
+class State(ctypes.Structure):
+    """mirror of banet_state_t"""
+    _fields_ = [("R", _FP), ("T", _FP), ("Wc", _FP), ("iters", _FP), ("ratio", _FP), ("lambda_out", _FP),
+                ("delta", _FP)]
+
+
+EXPORTS = {
+    "banet_version": (ctypes.c_int, []),
+    "banet_error_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "banet_equation_construction_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 4),
+    "banet_equation_construction_f32": (ctypes.c_int, [_FP] * 5 + [ctypes.c_int] * 4 + [_FP, ctypes.c_size_t, _FP]),
+    "banet_equation_construction_grad_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 4),
+    "banet_equation_construction_grad_f32": (ctypes.c_int, [_FP] * 8 + [ctypes.c_int] * 4 + [_FP, ctypes.c_size_t, _FP]),
+    "banet_ba_assemble_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Level)]),
+    "banet_ba_assemble_f32": (ctypes.c_int, [ctypes.POINTER(Level)] + [_FP] * 7 + [_FP, ctypes.c_size_t, _FP]),
+    "banet_ba_solve_update_f32": (ctypes.c_int, [ctypes.POINTER(Level), ctypes.POINTER(Mlp), ctypes.c_float] + [_FP] * 4 +
+                                  [ctypes.POINTER(State), _FP]),
+    "banet_lm_level_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Level)]),
+    "banet_lm_level_f32": (ctypes.c_int, [ctypes.POINTER(Level), ctypes.POINTER(Mlp), ctypes.c_float, ctypes.c_int,
+                                          ctypes.c_int, ctypes.POINTER(State), _FP, ctypes.c_size_t, _FP]),
+    "banet_profile_begin": (ctypes.c_int, [ctypes.c_int]),
+    "banet_profile_end": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),
+                                         ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libbanet_hip.so (once).  Raises BanetError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BanetError("%s not found: build it with banet_amd/csrc/build.sh (or __graft_entry__.build())"
+                             % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise BanetError("libbanet_hip: %s (%d)" % (lib().banet_error_string(rc).decode(), rc))
+
+
+def ptr(t):
+    """device pointer of a contiguous float32/int32 CUDA(HIP) tensor (None -> NULL)"""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise BanetError("banet_amd runs on the GPU only: got a %s tensor" % t.device)
+    if not t.is_contiguous():
+        raise BanetError("tensor must be contiguous")
+    if t.dtype not in (torch.float32, torch.int32):
+        raise BanetError("tensor must be float32/int32, got %s" % t.dtype)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def workspace(nbytes, device):
+    """256-byte aligned scratch from the caching allocator"""
+    n = max(int(nbytes), 256)
+    buf = torch.empty(n + 256, dtype=torch.uint8, device=device)
+    off = (-buf.data_ptr()) % 256
+    return buf[off:off + n]
+
+
+def f32c(t):
+    return t.contiguous().to(torch.float32)

@@ -1,0 +1,288 @@
+"""Host-side mirror of /root/reference/bundlenet.py for PyTorch-ROCm callers.
+
+Same module functions, same `BundleNet` method names, argument order and tensor layouts
+(NHWC feature maps, `[B,N,.]` per-point tensors, `fx..` as `[B,N]`, `intrisic [B,4,1]`), so an
+encoder/decoder CNN written against the reference can feed this layer unchanged.  The
+iteration bodies (`CameraIteration`, `BundleIteration`) do NOT build a graph of small ops:
+each is one fused assembly launch + one solve/update launch in libbanet_hip.so.
+
+Differences from the reference, on purpose:
+  * `VMatrix` applies the B=1 semantics to every item (the reference's stack/reshape is
+    only correct for B=1);
+  * a zero rotation update yields identity instead of 0/0 = NaN;
+  * NaN projections are masked out in both variants.
+"""
+import math
+
+import torch
+
+from . import ops
+
+__all__ = ["rotation2quaternion", "AngleaAxisRotation", "VMatrix", "CameraJacobianMatrix", "DepthJacobianMatrix",
+           "equation_construction", "equation_construction_grad", "resampler", "BundleNet"]
+
+equation_construction = ops.equation_construction            # bundlenet.py:77
+equation_construction_grad = ops.equation_construction_grad  # bundlenet.py:78
+
+
+def rotation2quaternion(R, name=None):
+    """bundlenet.py:6-15"""
+    diag = 1.0 + R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2]
+    q0 = torch.sqrt(diag) / 2.0
+    q1 = (R[:, 2, 1] - R[:, 1, 2]) / (4.0 * q0)
+    q2 = (R[:, 0, 2] - R[:, 2, 0]) / (4.0 * q0)
+    q3 = (R[:, 1, 0] - R[:, 0, 1]) / (4.0 * q0)
+    q = torch.stack([q0, q1, q2, q3], dim=1)
+    return q / torch.sqrt(torch.clamp((q * q).sum(dim=1, keepdim=True), min=1e-12))
+
+
+def AngleaAxisRotation(wx, wy, wz, name=None):
+    """bundlenet.py:17-37; wx,wy,wz [B,1] -> [B,3,3]"""
+    ones = torch.ones_like(wx)
+    theta = torch.clamp(torch.sqrt(wx * wx + wy * wy + wz * wz), min=1e-6)
+    wx, wy, wz = wx / theta, wy / theta, wz / theta
+    c, s = torch.cos(theta), torch.sin(theta)
+    m = torch.stack([c + wx * wx * (ones - c), wz * s + wx * wy * (ones - c), -wy * s + wx * wz * (ones - c),
+                     wx * wy * (ones - c) - wz * s, c + wy * wy * (ones - c), wx * s + wy * wz * (ones - c),
+                     wy * s + wx * wz * (ones - c), -wx * s + wy * wz * (ones - c), c + wz * wz * (ones - c)], dim=-1)
+    return m.reshape(-1, 3, 3).transpose(1, 2)
+
+
+def VMatrix(wx, wy, wz, name=None):
+    """bundlenet.py:39-46, per item."""
+    wx, wy, wz = wx.reshape(-1), wy.reshape(-1), wz.reshape(-1)
+    theta = torch.sqrt(wx * wx + wy * wy + wz * wz)
+    c, s = torch.cos(theta), torch.sin(theta)
+    z = torch.zeros_like(wx)
+    K = torch.stack([z, -wz, wy, wz, z, -wx, -wy, wx, z], dim=-1).reshape(-1, 3, 3)
+    a = ((1 - c) / (theta * theta))[:, None, None]
+    b = ((theta - s) / (theta * theta * theta))[:, None, None]
+    eye = torch.eye(3, dtype=wx.dtype, device=wx.device)[None]
+    return eye + a * K + b * torch.matmul(K, K)
+
+
+def CameraJacobianMatrix(x, y, Z, fx, fy, name=None):
+    """bundlenet.py:49-61 -> [B,N,2,6] (note the leading minus)."""
+    xy = x * y
+    xx = -1.0 - x * x
+    x_z = x / Z
+    yy = 1.0 + y * y
+    y_z = y / Z
+    iz = 1.0 / Z
+    zeros = torch.zeros_like(xy)
+    dx = fx.unsqueeze(-1) * torch.stack([xy, xx, y, -iz, zeros, x_z], dim=2)
+    dy = fy.unsqueeze(-1) * torch.stack([yy, -xy, -x, zeros, -iz, y_z], dim=2)
+    return -torch.stack([dx, dy], dim=2)
+
+
+def DepthJacobianMatrix(rx, ry, rz, x, y, Z, fx, fy, name=None):
+    """bundlenet.py:63-74; rx.. [B,1,N] -> [B,N,2]"""
+    rx, ry, rz = rx.squeeze(1), ry.squeeze(1), rz.squeeze(1)
+    dx = fx * ((rx - rz * x) / Z)
+    dy = fy * ((ry - rz * y) / Z)
+    return torch.stack([dx, dy], dim=2)
+
+
+def resampler(data, warp):
+    """tf.contrib.resampler.resampler restated for torch tensors: bilinear, zero padding.
+    data [B,H,W,C], warp [B,N,2] (x,y) -> [B,N,C].  Used by the per-level preparation
+    (bundlenet.py:290,320,343-344,385) -- not part of the per-iteration hot path."""
+    B, H, W, C = data.shape
+    x, y = warp[..., 0], warp[..., 1]
+    ok = (x > -1.0) & (y > -1.0) & (x < W) & (y < H)
+    xs = torch.where(ok, x, torch.zeros_like(x))
+    ys = torch.where(ok, y, torch.zeros_like(y))
+    fx_, fy_ = torch.floor(xs), torch.floor(ys)
+    cx, cy = fx_ + 1, fy_ + 1
+    dx, dy = cx - xs, cy - ys
+    flat = data.reshape(B, H * W, C)
+
+    def tap(xi, yi):
+        xi, yi = xi.long(), yi.long()
+        inside = (xi >= 0) & (yi >= 0) & (xi <= W - 1) & (yi <= H - 1)
+        idx = (yi.clamp(0, H - 1) * W + xi.clamp(0, W - 1)).unsqueeze(-1).expand(-1, -1, C)
+        v = torch.gather(flat, 1, idx)
+        return torch.where(inside.unsqueeze(-1), v, torch.zeros_like(v))
+
+    out = (dx * dy).unsqueeze(-1) * tap(fx_, fy_) + ((1 - dx) * (1 - dy)).unsqueeze(-1) * tap(cx, cy) \
+        + (dx * (1 - dy)).unsqueeze(-1) * tap(fx_, cy) + ((1 - dx) * dy).unsqueeze(-1) * tap(cx, fy_)
+    return torch.where(ok.unsqueeze(-1), out, torch.zeros_like(out))
+
+
+def he_normal_lambda_weights(C, seed, device="cpu"):
+    """lambda_<level>_<i> weights as bundlenet.py:105-106 creates them (he_normal, zero bias)."""
+    g = torch.Generator().manual_seed(seed)
+    dims = [C, 2 * C, 4 * C, 2 * C, C, 1]
+    out = []
+    for i in range(5):
+        std = math.sqrt(2.0 / dims[i]) / 0.87962566103423978
+        w = torch.clamp(torch.randn(dims[i], dims[i + 1], generator=g), -2, 2) * std
+        out.append((w.to(device), torch.zeros(dims[i + 1], device=device)))
+    return out
+
+
+class BundleNet:
+    """bundlenet.py:86-463.  `lambda_weights[level]` holds that level's five conv1d layers
+    as (filters [Cin,Cout], biases [Cout]) pairs -- the reference's TF variables
+    `lambda_<level>_<i>_filters/_biases`."""
+
+    def __init__(self, is_training=True, reuse_variables=None, lambda_weights=None):
+        self.is_training = is_training
+        self.reuse_variables = reuse_variables
+        self.lambda_weights = dict(lambda_weights or {})
+        self._mlp_cache = {}
+
+    # -- small helpers kept for API parity --------------------------------------------
+    def grad_fixed(self, input, name=None):
+        """bundlenet.py:92-100"""
+        H, W = input.shape[1], input.shape[2]
+        p = torch.nn.functional.pad(input.permute(0, 3, 1, 2), (1, 1, 1, 1), mode="reflect").permute(0, 2, 3, 1)
+        gx = 0.5 * (p[:, 1:H + 1, 2:W + 2, :] - p[:, 1:H + 1, 0:W, :])
+        gy = 0.5 * (p[:, 2:H + 2, 1:W + 1, :] - p[:, 0:H, 1:W + 1, :])
+        return torch.cat([gx, gy], dim=-1)
+
+    def conv1d(self, x, num_out_layers, name, activation=torch.nn.functional.elu):
+        """bundlenet.py:102-110 (kernel width 1).  x [B,L,Cin]; weights looked up by name
+        `lambda_<level>_<i>` in self.lambda_weights."""
+        _, level, i = name.split("_")
+        w, b = self.lambda_weights[level][int(i) - 1]
+        assert w.shape[-1] == num_out_layers
+        return activation(torch.matmul(x, w.to(x.device)) + b.to(x.device))
+
+    def computeCoordinates(self, points2d, fx, fy, ox, oy):
+        """bundlenet.py:112-120 -> p [B,3,N] (unit rays)"""
+        x = ((points2d[:, :, 0] - ox) / fx).unsqueeze(1)
+        y = ((points2d[:, :, 1] - oy) / fy).unsqueeze(1)
+        p = torch.cat([x, y, torch.ones_like(x)], dim=1)
+        return p / torch.sqrt(torch.clamp((p * p).sum(dim=1, keepdim=True), min=1e-12))
+
+    def _mlp(self, level, device):
+        key = (str(level), str(device))
+        if key not in self._mlp_cache:
+            if str(level) not in self.lambda_weights:
+                raise KeyError("no lambda weights for level %r (set BundleNet.lambda_weights[level])" % (level,))
+            self._mlp_cache[key] = ops.MlpWeights(self.lambda_weights[str(level)], device)
+        return self._mlp_cache[key]
+
+    # -- the two iteration bodies -------------------------------------------------------
+    def CameraIteration(self, conv1, conv2, fx, fy, ox, oy, p, D, R, T, l2_regularizer_base=None, level=None):
+        """bundlenet.py:122-191: one pose-only GN/LM step -> (updatedR, updatedT)."""
+        B, H, W, C3 = conv2.shape
+        C = conv1.shape[2]
+        lv = ops.LevelProblem("bundle_camera", conv1, conv2, D, H, W, C, rays=p, fx=fx, fy=fy, ox=ox, oy=oy,
+                              dense=False, tgt_has_grad=True)
+        st = ops.LmState(R, T, None, P=6)
+        AtA, Atb, absres, nvalid = ops.ba_assemble(lv, st.R, st.T)
+        ops.ba_solve_update(lv, self._mlp(level, conv1.device), 1.0, AtA, Atb, absres, nvalid, st)
+        self.last = dict(AtA=AtA, Atb=Atb, lam=st.lambda_out, delta=st.delta)
+        return st.R, st.T
+
+    def BundleIteration(self, conv1, conv2, fx, fy, ox, oy, p, D, B, R, T, W, l2_regularizer_base=None, level=None):
+        """bundlenet.py:193-278: pose + depth-basis step -> (updatedR, updatedT, updatedW)."""
+        nb, H, Wd, C3 = conv2.shape
+        C = conv1.shape[2]
+        K = B.shape[-1]
+        lv = ops.LevelProblem("bundle", conv1, conv2, D, H, Wd, C, basis=B, rays=p, fx=fx, fy=fy, ox=ox, oy=oy,
+                              dense=False, tgt_has_grad=True)
+        st = ops.LmState(R, T, W.reshape(nb, K, 1), P=6 + K)
+        AtA, Atb, absres, nvalid = ops.ba_assemble(lv, st.R, st.T, st.Wc)
+        l2 = 1.0 if l2_regularizer_base is None else float(l2_regularizer_base)
+        ops.ba_solve_update(lv, self._mlp(level, conv1.device), l2, AtA, Atb, absres, nvalid, st)
+        self.last = dict(AtA=AtA, Atb=Atb, lam=st.lambda_out, delta=st.delta)
+        return st.R, st.T, st.Wc
+
+    # -- level drivers ------------------------------------------------------------------
+    @staticmethod
+    def _crop(points):
+        x = 320 * (points[..., 0:1] - 4) / 312
+        y = 256 * (points[..., 1:2] - 4) / 232
+        return torch.cat([x, y], dim=-1)
+
+    def _crop_intrinsics(self, intrisic, npixels):
+        self.fx = 40.0 * intrisic[:, 0].repeat(1, npixels) / 39.0
+        self.fy = 32.0 * intrisic[:, 1].repeat(1, npixels) / 29.0
+        self.ox = (40.0 * intrisic[:, 2].repeat(1, npixels) / 39.0) - (160.0 / 39.0)
+        self.oy = (32.0 * intrisic[:, 3].repeat(1, npixels) / 29.0) - (128.0 / 29.0)
+
+    @staticmethod
+    def _swap_halves(x):
+        n = x.shape[0]
+        return torch.cat([x[n // 2:n], x[0:n // 2]], dim=0)
+
+    def CameraResize(self, intrisic, layers, points, _depths, reuse_variables=False):
+        """bundlenet.py:280-329: 4 levels (scale 8,4,2,1) x 1 CameraIteration."""
+        self.reuse_variables = reuse_variables
+        _points = self._crop(points)
+        d = resampler(_depths.detach(), _points / 2)
+        nbatch, npixels = layers[-1].shape[0], points.shape[1]
+        self._crop_intrinsics(intrisic, npixels)
+        p = self.computeCoordinates(_points, self.fx, self.fy, self.ox, self.oy)
+        R = torch.eye(3, device=points.device).repeat(nbatch, 1, 1)
+        T = torch.zeros(nbatch, 3, 1, device=points.device)
+        rotations, translations = [], []
+        for level in range(0, 4):
+            scale = 2 ** (3 - level)
+            layer1 = resampler(layers[level], _points / scale)
+            layer2 = self._swap_halves(layers[level])
+            layer2 = torch.cat([layer2, self.grad_fixed(layer2)], dim=-1)
+            R, T = self.CameraIteration(layer1, layer2, self.fx / scale, self.fy / scale, self.ox / scale,
+                                        self.oy / scale, p, d, R, T, 1.0, str(level))
+            rotations.append(R)
+            translations.append(T)
+        return rotations, translations
+
+    def BundleResize(self, intrisic, layers, points, basis, init_depth, init_rotation=None, init_translation=None,
+                     reuse_variables=False):
+        """bundlenet.py:332-399: levels 2,3 (scale 2,1) x 1 BundleIteration."""
+        self.reuse_variables = reuse_variables
+        _points = self._crop(points)
+        depths = init_depth.detach()
+        d = resampler(depths, _points / 2)
+        b = resampler(basis, _points / 2)
+        nbatch, npixels, nbasis = layers[-1].shape[0], points.shape[1], basis.shape[-1]
+        self._crop_intrinsics(intrisic, npixels)
+        p = self.computeCoordinates(_points, self.fx, self.fy, self.ox, self.oy)
+        dev = points.device
+        R = torch.eye(3, device=dev).repeat(nbatch, 1, 1) if init_rotation is None else init_rotation
+        T = torch.zeros(nbatch, 3, 1, device=dev) if init_translation is None else init_translation
+        W = torch.zeros(nbatch, nbasis, 1, device=dev)
+        out_R, out_T, out_D = [], [], []
+        Hh, Wh = init_depth.shape[1], init_depth.shape[2]
+        for level in range(2, 4):
+            scale = 2 ** (3 - level)
+            layer1 = resampler(layers[level], _points / scale)
+            layer2 = self._swap_halves(layers[level])
+            layer2 = torch.cat([layer2, self.grad_fixed(layer2)], dim=-1)
+            R, T, W = self.BundleIteration(layer1, layer2, self.fx / scale, self.fy / scale, self.ox / scale,
+                                           self.oy / scale, p, d, b, R, T, W, 1000.0, str(level))
+            out_R.append(R)
+            out_T.append(T)
+            out_D.append(init_depth + torch.matmul(basis.reshape(nbatch, -1, nbasis), W).reshape(nbatch, Hh, Wh, 1))
+        return out_R, out_T, out_D
+
+    # -- losses (bundlenet.py:401-463) ---------------------------------------------------
+    def lossR(self, predQ, gtQ):
+        return torch.mean(1.0 - (predQ * gtQ).sum(dim=1))            # tf.losses.cosine_distance
+
+    def lossT(self, predT, gtT):
+        return torch.mean(torch.abs(predT - gtT))                     # the second definition wins (:411)
+
+    def lossF(self, intrisic, depth, mask, predR, predT, gtR, gtT):
+        nbatch, height, width = depth.shape[0], depth.shape[1], depth.shape[2]
+        npixels = height * width
+        dev = depth.device
+        mask = mask.reshape(nbatch, npixels)
+        self._crop_intrinsics(intrisic, npixels)
+        ys, xs = torch.meshgrid(torch.arange(height, device=dev), torch.arange(width, device=dev), indexing="ij")
+        pts = torch.stack([xs.reshape(-1).float(), ys.reshape(-1).float()], dim=-1)[None].repeat(nbatch, 1, 1)
+        p = self.computeCoordinates(pts, self.fx, self.fy, self.ox, self.oy)
+
+        def flow(R, T):
+            X = torch.matmul(R, p) * depth.reshape(nbatch, 1, npixels) + T.reshape(nbatch, 3, 1)
+            return self.fx * X[:, 0] / X[:, 2] + self.ox, self.fy * X[:, 1] / X[:, 2] + self.oy
+
+        fxp, fyp = flow(predR, predT)
+        fxg, fyg = flow(gtR, gtT)
+        valid, total = mask.sum(), float(npixels * nbatch)
+        return (total / valid) * (torch.mean(torch.abs(fxp - fxg) * mask) / width +
+                                  torch.mean(torch.abs(fyp - fyg) * mask) / width)

@@ -1,0 +1,215 @@
+// C-ABI entry points of libbanet_hip.so (see include/banet_hip.h).  Argument checking,
+// workspace carving and kernel enqueue only -- no allocation, no synchronisation.
+#include "kernels.hpp"
+
+namespace banet {
+
+static bool aligned256(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 255u) == 0; }
+
+static int check_level(const banet_level_t* lv) {
+  if (!lv || !lv->src || !lv->tgt || !lv->depth) return BANET_ERR_INVALID_ARG;
+  if (lv->variant < BANET_LEGACY_LM || lv->variant > BANET_BUNDLE) return BANET_ERR_INVALID_ARG;
+  if (lv->K > 0 && !lv->basis) return BANET_ERR_INVALID_ARG;
+  if ((lv->variant == BANET_BUNDLE) != (lv->K > 0)) return BANET_ERR_INVALID_ARG;
+  if (lv->dense) {
+    if (!lv->intr || !(lv->scale > 0.f)) return BANET_ERR_INVALID_ARG;
+  } else {
+    if (!lv->rays || !lv->fx || !lv->fy || !lv->ox || !lv->oy) return BANET_ERR_INVALID_ARG;
+  }
+  return BANET_OK;
+}
+
+struct LevelWs {  // carve of the level workspace
+  float* partials;
+  float* AtA;
+  float* Atb;
+  float* absres;
+  float* nvalid;
+  LmCtl* ctl;
+  size_t total;
+};
+
+static LevelWs carve_level(const banet_level_t* lv, const AsmPlan& pl, void* ws) {
+  LevelWs w;
+  char* p = static_cast<char*>(ws);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* r = p ? p + off : nullptr;
+    off += align_up(bytes, 256);
+    return r;
+  };
+  w.partials = reinterpret_cast<float*>(take(pl.partial_bytes));
+  w.AtA = reinterpret_cast<float*>(take((size_t)lv->B * pl.P * pl.P * sizeof(float)));
+  w.Atb = reinterpret_cast<float*>(take((size_t)lv->B * pl.P * sizeof(float)));
+  w.absres = reinterpret_cast<float*>(take((size_t)lv->B * lv->C * sizeof(float)));
+  w.nvalid = reinterpret_cast<float*>(take((size_t)lv->B * sizeof(float)));
+  w.ctl = reinterpret_cast<LmCtl*>(take((size_t)lv->B * sizeof(LmCtl)));
+  w.total = off;
+  return w;
+}
+
+static SolveArgs make_solve_args(const banet_level_t* lv, const banet_mlp_t* mlp, float l2_base, const float* AtA,
+                                 const float* Atb, const float* absres, const float* nvalid, const banet_state_t* st) {
+  SolveArgs a;
+  a.B = lv->B;
+  a.N = lv->N;
+  a.C = lv->C;
+  a.K = lv->K;
+  a.P = 6 + lv->K;
+  a.variant = lv->variant;
+  a.l2_base = l2_base;
+  a.max_iters = 0;
+  a.use_mlp = lv->variant != BANET_LEGACY_FIXED;
+  if (mlp) a.mlp = *mlp;
+  else
+    for (int i = 0; i < 5; ++i) a.mlp.w[i] = a.mlp.b[i] = nullptr;
+  a.AtA = AtA;
+  a.Atb = Atb;
+  a.absres = absres;
+  a.nvalid = nvalid;
+  a.st = *st;
+  a.ctl = nullptr;
+  return a;
+}
+
+static int check_state(const banet_level_t* lv, const banet_mlp_t* mlp, const banet_state_t* st) {
+  if (!st || !st->R || !st->T || !st->iters || !st->ratio || !st->lambda_out || !st->delta) return BANET_ERR_INVALID_ARG;
+  if (lv->K > 0 && !st->Wc) return BANET_ERR_INVALID_ARG;
+  if (lv->variant != BANET_LEGACY_FIXED) {
+    if (!mlp) return BANET_ERR_INVALID_ARG;
+    for (int i = 0; i < 5; ++i)
+      if (!mlp->w[i] || !mlp->b[i]) return BANET_ERR_INVALID_ARG;
+  }
+  return BANET_OK;
+}
+
+}  // namespace banet
+
+using namespace banet;
+
+extern "C" {
+
+int banet_version(void) { return BANET_VERSION; }
+
+const char* banet_error_string(int code) {
+  switch (code) {
+    case BANET_OK: return "ok";
+    case BANET_ERR_INVALID_ARG: return "invalid argument";
+    case BANET_ERR_WORKSPACE: return "workspace too small or misaligned";
+    case BANET_ERR_UNSUPPORTED: return "shape not supported by the compiled kernel set";
+    case BANET_ERR_LAUNCH: return "kernel launch failed";
+    default: return "unknown error";
+  }
+}
+
+size_t banet_equation_construction_workspace_bytes(int B, int N, int C, int P) {
+  EqPlan pl;
+  if (plan_eq(B, N, C, P, &pl) != BANET_OK) return 0;
+  return pl.partial_bytes;
+}
+
+int banet_equation_construction_f32(const float* J, const float* G, const float* d, float* AtA, float* Atb, int B,
+                                    int N, int C, int P, void* ws, size_t ws_bytes, banet_stream_t stream) {
+  if (!J || !G || !d || !AtA || !Atb) return BANET_ERR_INVALID_ARG;
+  EqPlan pl;
+  const int rc = plan_eq(B, N, C, P, &pl);
+  if (rc != BANET_OK) return rc;
+  if (!ws || ws_bytes < pl.partial_bytes || !aligned256(ws)) return BANET_ERR_WORKSPACE;
+  return launch_eq(J, G, d, AtA, Atb, B, N, C, P, pl, static_cast<float*>(ws), static_cast<hipStream_t>(stream));
+}
+
+size_t banet_equation_construction_grad_workspace_bytes(int, int, int, int) { return 0; }
+
+int banet_equation_construction_grad_f32(const float* J, const float* G, const float* d, const float* g0,
+                                         const float* g1, float* gJ, float* gG, float* gd, int B, int N, int C, int P,
+                                         void* /*ws*/, size_t /*ws_bytes*/, banet_stream_t stream) {
+  if (!J || !G || !d || !g0 || !g1 || !gJ || !gG || !gd) return BANET_ERR_INVALID_ARG;
+  return launch_eq_grad(J, G, d, g0, g1, gJ, gG, gd, B, N, C, P, static_cast<hipStream_t>(stream));
+}
+
+size_t banet_ba_assemble_workspace_bytes(const banet_level_t* lv) {
+  AsmPlan pl;
+  if (plan_assemble(lv, &pl) != BANET_OK) return 0;
+  return pl.partial_bytes;
+}
+
+int banet_ba_assemble_f32(const banet_level_t* lv, const float* R, const float* T, const float* Wc, float* AtA,
+                          float* Atb, float* absres, float* nvalid, void* ws, size_t ws_bytes, banet_stream_t stream) {
+  int rc = check_level(lv);
+  if (rc != BANET_OK) return rc;
+  if (!R || !T || !AtA || !Atb || !absres || !nvalid || (lv->K > 0 && !Wc)) return BANET_ERR_INVALID_ARG;
+  AsmPlan pl;
+  rc = plan_assemble(lv, &pl);
+  if (rc != BANET_OK) return rc;
+  if (!ws || ws_bytes < pl.partial_bytes || !aligned256(ws)) return BANET_ERR_WORKSPACE;
+  return launch_assemble(lv, pl, R, T, Wc, nullptr, 0, static_cast<float*>(ws), AtA, Atb, absres, nvalid,
+                         static_cast<hipStream_t>(stream));
+}
+
+int banet_ba_solve_update_f32(const banet_level_t* lv, const banet_mlp_t* mlp, float l2_base, const float* AtA,
+                              const float* Atb, const float* absres, const float* nvalid, banet_state_t* st,
+                              banet_stream_t stream) {
+  if (!lv || !AtA || !Atb || !absres || !nvalid) return BANET_ERR_INVALID_ARG;
+  if (lv->variant < BANET_LEGACY_LM || lv->variant > BANET_BUNDLE || lv->B <= 0 || lv->N <= 0 || lv->C <= 0 || lv->K < 0)
+    return BANET_ERR_INVALID_ARG;
+  const int rc = check_state(lv, mlp, st);
+  if (rc != BANET_OK) return rc;
+  SolveArgs a = make_solve_args(lv, mlp, l2_base, AtA, Atb, absres, nvalid, st);
+  return launch_solve(a, static_cast<hipStream_t>(stream));
+}
+
+size_t banet_lm_level_workspace_bytes(const banet_level_t* lv) {
+  AsmPlan pl;
+  if (plan_assemble(lv, &pl) != BANET_OK) return 0;
+  return carve_level(lv, pl, nullptr).total;
+}
+
+int banet_lm_level_f32(const banet_level_t* lv, const banet_mlp_t* mlp, float l2_base, int max_iters,
+                       int early_termination, banet_state_t* st, void* ws, size_t ws_bytes, banet_stream_t stream) {
+  int rc = check_level(lv);
+  if (rc != BANET_OK) return rc;
+  rc = check_state(lv, mlp, st);
+  if (rc != BANET_OK) return rc;
+  if (max_iters < 0) return BANET_ERR_INVALID_ARG;
+  AsmPlan pl;
+  rc = plan_assemble(lv, &pl);
+  if (rc != BANET_OK) return rc;
+  if (!ws || !aligned256(ws)) return BANET_ERR_WORKSPACE;
+  LevelWs w = carve_level(lv, pl, ws);
+  if (ws_bytes < w.total) return BANET_ERR_WORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  SolveArgs a = make_solve_args(lv, mlp, l2_base, w.AtA, w.Atb, w.absres, w.nvalid, st);
+  a.max_iters = max_iters;
+  const bool lm = early_termination && lv->variant == BANET_LEGACY_LM;
+  if (lm) {
+    // device-side loop control: max_iters + 1 evaluation rounds; the last one only runs the
+    // pending accept/reject test (legacy/ba.py:304-345), see solve.hip
+    launch_ctl_init(w.ctl, st->iters, lv->B, s);
+    a.ctl = w.ctl;
+    const int stride = (int)(sizeof(LmCtl) / sizeof(int32_t));
+    for (int it = 0; it <= max_iters; ++it) {
+      rc = launch_assemble(lv, pl, st->R, st->T, st->Wc, &w.ctl->active, stride, w.partials, w.AtA, w.Atb, w.absres,
+                           w.nvalid, s);
+      if (rc != BANET_OK) return rc;
+      rc = launch_solve(a, s);
+      if (rc != BANET_OK) return rc;
+    }
+  } else {
+    launch_zero_iters(st->iters, lv->B, s);
+    for (int it = 0; it < max_iters; ++it) {
+      rc = launch_assemble(lv, pl, st->R, st->T, st->Wc, nullptr, 0, w.partials, w.AtA, w.Atb, w.absres, w.nvalid, s);
+      if (rc != BANET_OK) return rc;
+      rc = launch_solve(a, s);
+      if (rc != BANET_OK) return rc;
+    }
+  }
+  return BANET_OK;
+}
+
+int banet_profile_begin(int max_launches) { return profile_begin(max_launches); }
+
+int banet_profile_end(int max_tags, int32_t* tag_points, int32_t* tag_launches, double* tag_ms, int32_t* ntags) {
+  return profile_end(max_tags, tag_points, tag_launches, tag_ms, ntags);
+}
+
+}  // extern "C"

@@ -1,0 +1,68 @@
+"""Dense multi-level window solver: every pixel of every pyramid level is a BA point
+(SURVEY.md 8(d) "dense mode"; the reference samples N=1024-4096 points instead).
+
+Per level the layer's inputs are the CNN's outputs in their native layouts -- source and
+target feature maps NHWC `[B,H_l,W_l,C]`, depth `[B,H_l,W_l]`, basis `[B,H_l,W_l,K]` -- and
+the whole coarse->fine LM schedule is enqueued on the current stream without a host sync.
+Iteration bodies: `bundle` = bundlenet.py:193-278 (pose + depth basis), `bundle_camera` =
+bundlenet.py:122-191, `legacy_lm` / `legacy_fixed` = legacy/ba.py:226-345 / :148-214.
+"""
+import torch
+
+from . import ops
+
+
+class DenseLevel:
+    def __init__(self, scale, src, tgt, depth, basis=None):
+        self.scale = float(scale)
+        self.src, self.tgt, self.depth, self.basis = src, tgt, depth, basis
+        self.B, self.H, self.W, self.C = tgt.shape
+
+
+class DenseBA:
+    def __init__(self, intr, levels, lambda_weights, variant="bundle", l2_base=1000.0):
+        """intr [B,4] full-resolution (fx,fy,ox,oy); levels: list of DenseLevel coarse->fine;
+        lambda_weights: list (one per level) of 5 (filters, biases) pairs."""
+        self.variant = variant
+        self.l2_base = float(l2_base) if variant == "bundle" else 1.0
+        self.intr = intr.contiguous().float()
+        dev = self.intr.device
+        legacy = variant.startswith("legacy")
+        self.problems, self.mlps = [], []
+        for lv, lw in zip(levels, lambda_weights):
+            B, H, W, C = lv.B, lv.H, lv.W, lv.C
+            basis = lv.basis.reshape(B, H * W, -1) if (variant == "bundle") else None
+            self.problems.append(ops.LevelProblem(variant, lv.src, lv.tgt, lv.depth.reshape(B, H * W), H, W, C,
+                                                  basis=basis, intr=self.intr, scale=lv.scale, dense=True,
+                                                  tgt_has_grad=False, normalize_rays=not legacy))
+            self.mlps.append(None if variant == "legacy_fixed" else ops.MlpWeights(lw, dev))
+        self.K = self.problems[0].K
+        nb = max(ops.lm_level_workspace_bytes(p) for p in self.problems)
+        if nb == 0:
+            raise ops.capi.BanetError("DenseBA: unsupported level shape")
+        self.ws = ops.capi.workspace(nb, dev)
+        self.B = self.problems[0].B
+
+    def new_state(self, R=None, T=None, Wc=None):
+        dev = self.intr.device
+        B, K = self.B, self.K
+        R = torch.eye(3, device=dev).repeat(B, 1, 1) if R is None else R
+        T = torch.zeros(B, 3, 1, device=dev) if T is None else T
+        if K > 0 and Wc is None:
+            Wc = torch.zeros(B, K, 1, device=dev)
+        return ops.LmState(R, T, Wc if K > 0 else None, P=6 + K)
+
+    def solve(self, iters_per_level, state=None, early_termination=False):
+        """Enqueue the full schedule; returns the state (R,T,Wc updated in place) and the list
+        of per-level iteration-count tensors."""
+        st = state if state is not None else self.new_state()
+        counts = []
+        for prob, mlp, its in zip(self.problems, self.mlps, iters_per_level):
+            ops.lm_level(prob, mlp, self.l2_base, its, early_termination, st, ws=self.ws)
+            counts.append(st.iters.clone())
+        return st, counts
+
+    def algorithmic_bytes_per_iteration(self, level_index):
+        """4*N_l*(C*F + K + 1) per window-iteration (F = 2 frames)."""
+        p = self.problems[level_index]
+        return 4 * p.N * (p.C * 2 + p.K + 1)

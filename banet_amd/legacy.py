@@ -1,0 +1,116 @@
+"""Host-side mirror of /root/reference/legacy/ba.py (`Tracker`) for PyTorch-ROCm callers.
+
+`trackTF` keeps the reference's signature and semantics (3 levels, scale 4/2/1, pose carried
+across levels, early-terminated LM with accept/reject) but the whole per-level loop is
+enqueued on the device by `banet_lm_level_f32` -- no per-iteration host round trip, and the
+CheckUpdate pass of iteration k doubles as the assembly pass of iteration k+1.
+The feature CNN of the reference (`feat.py`) is out of scope: `layers` are given.
+"""
+import torch
+
+from . import ops
+
+# module-level switches, as legacy/ba.py:5-9
+early_termination = True
+angle_change = 0.002 * (3.14 / 180.0)   # compiled into solve.hip (kAngleChange)
+translation_change = 0.0002
+residual_ratio = 1.0
+qr = True
+
+
+def interpolate2d2(imgs, p):
+    """legacy/utils_python.py:177-232: clamped bilinear, no mask.  imgs [B,H,W,C], p [B,N,2]."""
+    B, H, W, C = imgs.shape
+    x, y = p[..., 0], p[..., 1]
+    x0f, y0f = torch.floor(x), torch.floor(y)
+    dx, dy = x - x0f, y - y0f
+    x0, y0 = x0f.long(), y0f.long()
+    x1, y1 = x0 + 1, y0 + 1
+    x0, x1 = x0.clamp(0, W - 1), x1.clamp(0, W - 1)
+    y0, y1 = y0.clamp(0, H - 1), y1.clamp(0, H - 1)
+    flat = imgs.reshape(B, H * W, C)
+
+    def g(yy, xx):
+        return torch.gather(flat, 1, (yy * W + xx).unsqueeze(-1).expand(-1, -1, C))
+
+    w00, w01 = ((1 - dx) * (1 - dy)).unsqueeze(-1), (dx * (1 - dy)).unsqueeze(-1)
+    w10, w11 = ((1 - dx) * dy).unsqueeze(-1), (dx * dy).unsqueeze(-1)
+    return ((g(y0, x0) * w00 + g(y0, x1) * w01) + g(y1, x0) * w10) + g(y1, x1) * w11
+
+
+class Tracker:
+    """legacy/ba.py:15-482 without the TF session / CNN: the BA part only."""
+
+    def __init__(self, lambda_weights=None, iters=(3, 5, 7)):
+        self.lambda_weights = dict(lambda_weights or {})
+        self.iters = list(iters)
+        self._mlp_cache = {}
+
+    def _mlp(self, level, device):
+        key = (str(level), str(device))
+        if key not in self._mlp_cache:
+            self._mlp_cache[key] = ops.MlpWeights(self.lambda_weights[str(level)], device)
+        return self._mlp_cache[key]
+
+    def grad_fixed(self, input, name=None):
+        """legacy/ba.py:17-25"""
+        H, W = input.shape[1], input.shape[2]
+        p = torch.nn.functional.pad(input.permute(0, 3, 1, 2), (1, 1, 1, 1), mode="reflect").permute(0, 2, 3, 1)
+        gx = 0.5 * (p[:, 1:H + 1, 2:W + 2, :] - p[:, 1:H + 1, 0:W, :])
+        gy = 0.5 * (p[:, 2:H + 2, 1:W + 1, :] - p[:, 0:H, 1:W + 1, :])
+        return torch.cat([gx, gy], dim=-1)
+
+    def computeCoordinates(self, points2d, fx, fy, ox, oy):
+        """legacy/ba.py:27-34 (rays NOT normalised)"""
+        x = ((points2d[:, :, 0] - ox) / fx).unsqueeze(1)
+        y = ((points2d[:, :, 1] - oy) / fy).unsqueeze(1)
+        return torch.cat([x, y, torch.ones_like(x)], dim=1)
+
+    def _level(self, variant, conv1, conv2, fx, fy, ox, oy, p, D):
+        B, H, W, C3 = conv2.shape
+        return ops.LevelProblem(variant, conv1, conv2, D, H, W, conv1.shape[2], rays=p, fx=fx, fy=fy, ox=ox, oy=oy,
+                                dense=False, tgt_has_grad=True)
+
+    def CameraIteration(self, conv1, conv2, fx, fy, ox, oy, p, D, R, T):
+        """legacy/ba.py:148-214 -> (updatedR, updatedT, ratio)"""
+        lv = self._level("legacy_fixed", conv1, conv2, fx, fy, ox, oy, p, D)
+        st = ops.LmState(R, T, None, 6)
+        ops.lm_level(lv, None, 1.0, 1, False, st)
+        return st.R, st.T, st.ratio
+
+    def CameraIteration2(self, conv1, conv2, fx, fy, ox, oy, p, D, R, T, level):
+        """legacy/ba.py:226-345 -> (R, T, update_w, update_t, ratio): one LM step including
+        its accept/reject test (two evaluation rounds on the device)."""
+        lv = self._level("legacy_lm", conv1, conv2, fx, fy, ox, oy, p, D)
+        st = ops.LmState(R, T, None, 6)
+        ops.lm_level(lv, self._mlp(level, conv1.device), 1.0, 1, True, st)
+        accepted = ((st.R - ops.capi.f32c(R).reshape(-1, 3, 3)).abs().amax(dim=(1, 2)) > 0) | \
+                   ((st.T - ops.capi.f32c(T).reshape(-1, 3, 1)).abs().amax(dim=(1, 2)) > 0)
+        uw = torch.where(accepted, st.delta[:, 0:3].norm(dim=1), torch.zeros_like(st.ratio))
+        ut = torch.where(accepted, st.delta[:, 3:6].norm(dim=1), torch.zeros_like(st.ratio))
+        return st.R, st.T, uw, ut, st.ratio
+
+    def trackTF(self, intrisic, layers, points, d, initR, initT, level_iters):
+        """legacy/ba.py:85-145.  layers: 3 maps coarse->fine, each [2B,H_l,W_l,C] with the
+        source frames first and the target frames second (the reference has B=1).
+        Returns (R, T, ratio) and leaves the per-level iteration counts in self.level_iters_run."""
+        npixels = points.shape[1]
+        nb = layers[-1].shape[0] // 2
+        fx0 = intrisic[:, 0].repeat(1, npixels)
+        fy0 = intrisic[:, 1].repeat(1, npixels)
+        ox0 = intrisic[:, 2].repeat(1, npixels)
+        oy0 = intrisic[:, 3].repeat(1, npixels)
+        p = self.computeCoordinates(points, fx0, fy0, ox0, oy0)
+        st = ops.LmState(initR, initT, None, 6)
+        self.level_iters_run = []
+        for level in range(1, 4):
+            scale = 2 ** (3 - level)
+            layer1 = interpolate2d2(layers[level - 1][0:nb], points / scale)
+            layer2 = layers[level - 1][nb:2 * nb]
+            layer2 = torch.cat([layer2, self.grad_fixed(layer2)], dim=-1)
+            variant = "legacy_lm" if early_termination else "legacy_fixed"
+            lv = self._level(variant, layer1, layer2, fx0 / scale, fy0 / scale, ox0 / scale, oy0 / scale, p, d)
+            mlp = self._mlp(level, points.device) if early_termination else None
+            ops.lm_level(lv, mlp, 1.0, level_iters[level - 1], early_termination, st)
+            self.level_iters_run.append(st.iters.clone())
+        return st.R, st.T, st.ratio

@@ -1,0 +1,204 @@
+"""Operator layer: the reference's custom ops (`util.equation_construction`,
+`util.equation_construction_grad`, bundlenet.py:76-82) and the fused entry points, each a
+thin call into libbanet_hip.so through its C ABI.  GPU only -- no CPU / eager fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _capi as capi
+
+_VARIANT_OF = {"legacy_lm": capi.LEGACY_LM, "legacy_fixed": capi.LEGACY_FIXED,
+               "bundle_camera": capi.BUNDLE_CAMERA, "bundle": capi.BUNDLE}
+
+
+# --------------------------------------------------------------------------------------
+# EquationConstruction (+Grad)                      utils.cu:150-171 / :420-428
+# --------------------------------------------------------------------------------------
+def _eq_shapes(jacobian, gradient, difference):
+    B, N, two, P = jacobian.shape
+    Bg, Ng, C, two2 = gradient.shape
+    if two != 2 or two2 != 2 or (Bg, Ng) != (B, N) or tuple(difference.shape) != (B, N, C, 1):
+        raise capi.BanetError("equation_construction: expected J[B,N,2,P], G[B,N,C,2], d[B,N,C,1]; got %s %s %s"
+                              % (tuple(jacobian.shape), tuple(gradient.shape), tuple(difference.shape)))
+    return B, N, C, P
+
+
+def equation_construction_forward(jacobian, gradient, difference):
+    J, G, d = capi.f32c(jacobian), capi.f32c(gradient), capi.f32c(difference)
+    B, N, C, P = _eq_shapes(J, G, d)
+    L = capi.lib()
+    left = torch.empty((B, P, P), dtype=torch.float32, device=J.device)
+    right = torch.empty((B, P, 1), dtype=torch.float32, device=J.device)
+    nb = L.banet_equation_construction_workspace_bytes(B, N, C, P)
+    if nb == 0:
+        raise capi.BanetError("equation_construction: unsupported shape B=%d N=%d C=%d P=%d" % (B, N, C, P))
+    ws = capi.workspace(nb, J.device)
+    capi.check(L.banet_equation_construction_f32(capi.ptr(J), capi.ptr(G), capi.ptr(d), capi.ptr(left), capi.ptr(right),
+                                                 B, N, C, P, ctypes.c_void_p(ws.data_ptr()),
+                                                 ws.numel(), capi.stream()))
+    return left, right
+
+
+def equation_construction_grad(jacobian, gradient, difference, left_grad, right_grad):
+    """`util.equation_construction_grad` (bundlenet.py:78,81)."""
+    J, G, d = capi.f32c(jacobian), capi.f32c(gradient), capi.f32c(difference)
+    g0, g1 = capi.f32c(left_grad), capi.f32c(right_grad)
+    B, N, C, P = _eq_shapes(J, G, d)
+    L = capi.lib()
+    gJ, gG, gd = torch.empty_like(J), torch.empty_like(G), torch.empty_like(d)
+    capi.check(L.banet_equation_construction_grad_f32(capi.ptr(J), capi.ptr(G), capi.ptr(d), capi.ptr(g0), capi.ptr(g1),
+                                                      capi.ptr(gJ), capi.ptr(gG), capi.ptr(gd), B, N, C, P, None, 0,
+                                                      capi.stream()))
+    return gJ, gG, gd
+
+
+class _EquationConstruction(torch.autograd.Function):
+    """forward = EquationConstruction, backward = EquationConstructionGrad: the pairing the
+    reference registers with @ops.RegisterGradient (bundlenet.py:79-82)."""
+
+    @staticmethod
+    def forward(ctx, jacobian, gradient, difference):
+        ctx.save_for_backward(jacobian, gradient, difference)
+        return equation_construction_forward(jacobian, gradient, difference)
+
+    @staticmethod
+    def backward(ctx, left_grad, right_grad):
+        J, G, d = ctx.saved_tensors
+        return equation_construction_grad(J, G, d, left_grad, right_grad)
+
+
+def equation_construction(jacobian, gradient, difference):
+    """`util.equation_construction(jacobian=, gradient=, difference=)` -> (AtA [B,P,P], Atb [B,P,1])."""
+    return _EquationConstruction.apply(jacobian, gradient, difference)
+
+
+# --------------------------------------------------------------------------------------
+# fused path
+# --------------------------------------------------------------------------------------
+class MlpWeights:
+    """Device copies of the five k=1 conv layers lambda_<level>_<i>_{filters,biases}
+    (bundlenet.py:102-110,168-172): filters [Cin,Cout] row-major, biases [Cout]."""
+
+    def __init__(self, layers, device):
+        assert len(layers) == 5
+        self.w = [torch.as_tensor(w, dtype=torch.float32).reshape(w.shape[-2], w.shape[-1]).contiguous().to(device)
+                  for w, _ in layers]
+        self.b = [torch.as_tensor(b, dtype=torch.float32).contiguous().to(device) for _, b in layers]
+        self.c = capi.Mlp()
+        for i in range(5):
+            self.c.w[i] = self.w[i].data_ptr()
+            self.c.b[i] = self.b[i].data_ptr()
+
+
+class LmState:
+    """Per-window LM state (banet_state_t): R [B,3,3], T [B,3,1], Wc [B,K,1] + diagnostics."""
+
+    def __init__(self, R, T, Wc=None, P=6):
+        dev = R.device
+        B = R.shape[0]
+        self.R = capi.f32c(R).clone().reshape(B, 3, 3)
+        self.T = capi.f32c(T).clone().reshape(B, 3, 1)
+        self.Wc = capi.f32c(Wc).clone() if Wc is not None else None
+        self.iters = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.ratio = torch.zeros(B, dtype=torch.float32, device=dev)
+        self.lambda_out = torch.zeros(B, dtype=torch.float32, device=dev)
+        self.delta = torch.zeros(B, P, dtype=torch.float32, device=dev)
+        self.c = capi.State()
+        self.c.R = self.R.data_ptr()
+        self.c.T = self.T.data_ptr()
+        self.c.Wc = self.Wc.data_ptr() if self.Wc is not None else None
+        self.c.iters = self.iters.data_ptr()
+        self.c.ratio = self.ratio.data_ptr()
+        self.c.lambda_out = self.lambda_out.data_ptr()
+        self.c.delta = self.delta.data_ptr()
+
+
+class LevelProblem:
+    """One banet_level_t plus the tensors it points at (kept alive here)."""
+
+    def __init__(self, variant, src, tgt, depth, H, W, C, basis=None, rays=None, fx=None, fy=None, ox=None, oy=None,
+                 intr=None, scale=1.0, dense=False, tgt_has_grad=True, normalize_rays=False):
+        v = _VARIANT_OF[variant] if isinstance(variant, str) else int(variant)
+        keep = [capi.f32c(x) if x is not None else None for x in (src, tgt, depth, basis, rays, fx, fy, ox, oy, intr)]
+        src, tgt, depth, basis, rays, fx, fy, ox, oy, intr = keep
+        self.keep = keep
+        B = tgt.shape[0]
+        N = depth.numel() // B
+        K = 0 if basis is None else basis.shape[-1]
+        lv = capi.Level()
+        lv.B, lv.N, lv.C, lv.K, lv.H, lv.W = B, N, C, K, H, W
+        lv.variant, lv.dense, lv.tgt_has_grad = v, int(dense), int(tgt_has_grad)
+        lv.normalize_rays, lv.scale = int(normalize_rays), float(scale)
+        for name, t in (("src", src), ("tgt", tgt), ("depth", depth), ("basis", basis), ("rays", rays), ("fx", fx),
+                        ("fy", fy), ("ox", ox), ("oy", oy), ("intr", intr)):
+            setattr(lv, name, None if t is None else t.data_ptr())
+            if t is not None and not t.is_cuda:
+                raise capi.BanetError("banet_amd runs on the GPU only (%s is on %s)" % (name, t.device))
+        expect_tgt = B * H * W * C * (3 if tgt_has_grad else 1)
+        if tgt.numel() != expect_tgt or src.numel() != B * N * C:
+            raise capi.BanetError("level tensors have inconsistent sizes")
+        self.c = lv
+        self.B, self.N, self.C, self.K, self.P = B, N, C, K, 6 + K
+        self.device = tgt.device
+
+
+def ba_assemble(level, R, T, Wc=None):
+    """banet_ba_assemble_f32 -> (AtA [B,P,P], Atb [B,P], absres [B,C], nvalid [B])."""
+    L = capi.lib()
+    dev = level.device
+    B, P, C = level.B, level.P, level.C
+    AtA = torch.empty((B, P, P), dtype=torch.float32, device=dev)
+    Atb = torch.empty((B, P), dtype=torch.float32, device=dev)
+    absres = torch.empty((B, C), dtype=torch.float32, device=dev)
+    nvalid = torch.empty((B,), dtype=torch.float32, device=dev)
+    nb = L.banet_ba_assemble_workspace_bytes(ctypes.byref(level.c))
+    if nb == 0:
+        raise capi.BanetError("ba_assemble: unsupported level shape")
+    ws = capi.workspace(nb, dev)
+    R, T = capi.f32c(R), capi.f32c(T)
+    Wc = capi.f32c(Wc) if Wc is not None else None
+    capi.check(L.banet_ba_assemble_f32(ctypes.byref(level.c), capi.ptr(R), capi.ptr(T), capi.ptr(Wc), capi.ptr(AtA),
+                                       capi.ptr(Atb), capi.ptr(absres), capi.ptr(nvalid),
+                                       ctypes.c_void_p(ws.data_ptr()), ws.numel(), capi.stream()))
+    return AtA, Atb, absres, nvalid
+
+
+def ba_solve_update(level, mlp, l2_base, AtA, Atb, absres, nvalid, state):
+    """banet_ba_solve_update_f32: lambda, damping, solve, SE(3)/W update (in place on `state`)."""
+    L = capi.lib()
+    capi.check(L.banet_ba_solve_update_f32(ctypes.byref(level.c), ctypes.byref(mlp.c) if mlp is not None else None,
+                                           float(l2_base), capi.ptr(AtA), capi.ptr(Atb), capi.ptr(absres),
+                                           capi.ptr(nvalid), ctypes.byref(state.c), capi.stream()))
+
+
+def lm_level(level, mlp, l2_base, max_iters, early_termination, state, ws=None):
+    """banet_lm_level_f32: the whole LM loop of one pyramid level, enqueued without host sync."""
+    L = capi.lib()
+    nb = L.banet_lm_level_workspace_bytes(ctypes.byref(level.c))
+    if nb == 0:
+        raise capi.BanetError("lm_level: unsupported level shape")
+    if ws is None or ws.numel() < nb:
+        ws = capi.workspace(nb, level.device)
+    capi.check(L.banet_lm_level_f32(ctypes.byref(level.c), ctypes.byref(mlp.c) if mlp is not None else None,
+                                    float(l2_base), int(max_iters), int(bool(early_termination)),
+                                    ctypes.byref(state.c), ctypes.c_void_p(ws.data_ptr()), ws.numel(), capi.stream()))
+    return ws
+
+
+def lm_level_workspace_bytes(level):
+    return capi.lib().banet_lm_level_workspace_bytes(ctypes.byref(level.c))
+
+
+def profile_begin(max_launches):
+    capi.check(capi.lib().banet_profile_begin(int(max_launches)))
+
+
+def profile_end(max_tags=16):
+    """-> {points_per_window: (launches, total_ms)} for the assembly kernel since profile_begin"""
+    pts = (ctypes.c_int32 * max_tags)()
+    cnt = (ctypes.c_int32 * max_tags)()
+    ms = (ctypes.c_double * max_tags)()
+    nt = ctypes.c_int32(0)
+    capi.check(capi.lib().banet_profile_end(max_tags, pts, cnt, ms, ctypes.byref(nt)))
+    return {int(pts[i]): (int(cnt[i]), float(ms[i])) for i in range(nt.value)}

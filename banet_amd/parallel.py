@@ -1,0 +1,52 @@
+"""One process per GPU; independent windows are sharded across ranks.
+
+Every window is an independent LM problem, so the data path has NO collective: each rank
+solves its contiguous shard of the batch.  The only exchange is one all-gather per solve of
+the small per-window result record [R(9) | T(3) | W(K) | iters(L)] -- the "cross-window pose
+reduction" a sequence-level consumer needs (cf. legacy/seq_example.py:170-173).  On MI355X
+that is RCCL over xGMI (`backend="nccl"`); the CPU tests run the same code over gloo.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total, rank, world):
+    """contiguous shard [lo, hi) of `total` windows for `rank` (sizes differ by at most 1)"""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def pack_results(R, T, Wc, iters_per_level):
+    """-> [B_local, 12 + K + L] float32 record"""
+    B = R.shape[0]
+    parts = [R.reshape(B, 9), T.reshape(B, 3)]
+    if Wc is not None:
+        parts.append(Wc.reshape(B, -1))
+    parts.append(torch.stack([c.to(torch.float32) for c in iters_per_level], dim=1))
+    return torch.cat(parts, dim=1).contiguous()
+
+
+def unpack_results(rec, K, L):
+    B = rec.shape[0]
+    R = rec[:, 0:9].reshape(B, 3, 3)
+    T = rec[:, 9:12].reshape(B, 3, 1)
+    Wc = rec[:, 12:12 + K].reshape(B, K, 1) if K > 0 else None
+    iters = rec[:, 12 + K:12 + K + L].to(torch.int32)
+    return R, T, Wc, iters
+
+
+def gather_results(local_rec, total, group=None):
+    """all-gather the per-window records of all ranks into one [total, F] tensor, ordered by
+    window index (shards are contiguous).  One fused buffer, one collective."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local_rec
+    world = dist.get_world_size(group)
+    F = local_rec.shape[1]
+    sizes = [shard_range(total, r, world) for r in range(world)]
+    maxb = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros(maxb, F, dtype=local_rec.dtype, device=local_rec.device)
+    pad[:local_rec.shape[0]] = local_rec
+    out = torch.empty(world * maxb, F, dtype=local_rec.dtype, device=local_rec.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    return torch.cat([out[r * maxb:r * maxb + (hi - lo)] for r, (lo, hi) in enumerate(sizes)], dim=0)

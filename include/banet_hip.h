@@ -1,0 +1,176 @@
+/* banet_hip.h -- C ABI of libbanet_hip.so: the MI355X (gfx950) bundle-adjustment hot path.
+ *
+ * This is the drop-in boundary for the one native component of frobelbest/BANet, the
+ * TensorFlow custom-op library `utils.so` (reference: utils.cu, loaded by
+ * bundlenet.py:76-82 and legacy/ba.py:11-13), plus fused entry points that replace the
+ * TF-graph portion of the same path (bundlenet.py:122-278, legacy/ba.py:148-345).
+ *
+ * Conventions (all entry points):
+ *   - plain C, no C++/torch types; every pointer is a DEVICE pointer owned by the caller;
+ *   - row-major contiguous float32 tensors with the reference's axis order;
+ *   - asynchronous: work is enqueued on the caller's hipStream_t; nothing synchronises,
+ *     allocates or frees; scratch comes from the caller-supplied workspace `ws`
+ *     (size from the matching *_workspace_bytes query; 256-byte aligned);
+ *   - stateless and re-entrant: no globals (the reference keeps per-GPU static scratch
+ *     sized by the first call, utils.cu:214-216,259-264 -- not reproduced);
+ *   - return value: BANET_OK or a negative BANET_ERR_* code; never throws.
+ *   - deterministic: reductions use fixed-order partials, no float atomics.
+ */
+#ifndef BANET_HIP_H_
+#define BANET_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef BANET_STREAM_T
+#define BANET_STREAM_T
+typedef void* banet_stream_t; /* a hipStream_t (NULL = default stream) */
+#endif
+
+#define BANET_VERSION 100 /* 0.1.0 */
+
+enum {
+  BANET_OK = 0,
+  BANET_ERR_INVALID_ARG = -1, /* null pointer, non-positive size, bad enum        */
+  BANET_ERR_WORKSPACE = -2,   /* ws too small or misaligned                       */
+  BANET_ERR_UNSUPPORTED = -3, /* shape outside the compiled kernel set (see docs) */
+  BANET_ERR_LAUNCH = -4       /* hipGetLastError() != hipSuccess after enqueue    */
+};
+
+int banet_version(void);
+const char* banet_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------
+ * (1) EquationConstruction  -- replaces the TF op registered at utils.cu:150-171 and its
+ *     kernel utils.cu:219-417 (5 cuBLAS sgemmBatched + 2 column reductions).
+ *       jacobian   J [B,N,2,P]     gradient G [B,N,C,2]     difference d [B,N,C,1]
+ *       left  AtA [B,P,P] = sum_n J_n^T (G_n^T G_n) J_n
+ *       right Atb [B,P,1] = sum_n J_n^T  G_n^T d_n
+ *     Never materialises the per-pixel PxP products (utils.cu:356-365 does: 22 GB/item at
+ *     640x480, P=134).  Supported: 1 <= P <= 272, any C >= 1, any N >= 1.
+ * ------------------------------------------------------------------------------------- */
+size_t banet_equation_construction_workspace_bytes(int B, int N, int C, int P);
+int banet_equation_construction_f32(const float* jacobian, const float* gradient,
+                                    const float* difference, float* left, float* right,
+                                    int B, int N, int C, int P, void* ws, size_t ws_bytes,
+                                    banet_stream_t stream);
+
+/* (2) EquationConstructionGrad -- replaces utils.cu:420-428 (op) / :465-694 (kernel),
+ *     bound as the op's gradient at bundlenet.py:79-82.
+ *       left_grad g0 [B,P,P], right_grad g1 [B,P,1]
+ *       A_n = G_n J_n ; dA_n = 2 A_n g0 + d_n g1^T   (alpha = 2.0 as utils.cu:651)
+ *       jacobian_grad = G^T dA [B,N,2,P]; gradient_grad = dA J^T [B,N,C,2];
+ *       difference_grad = A g1 [B,N,C,1]                                                 */
+size_t banet_equation_construction_grad_workspace_bytes(int B, int N, int C, int P);
+int banet_equation_construction_grad_f32(const float* jacobian, const float* gradient,
+                                         const float* difference, const float* left_grad,
+                                         const float* right_grad, float* jacobian_grad,
+                                         float* gradient_grad, float* difference_grad, int B,
+                                         int N, int C, int P, void* ws, size_t ws_bytes,
+                                         banet_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Fused path.  One "level problem" = B independent windows at one pyramid level.
+ * ------------------------------------------------------------------------------------- */
+enum { /* banet_level_t.variant: which reference iteration is restated */
+  BANET_LEGACY_LM = 0,     /* legacy/ba.py:226-345 CameraIteration2 (MLP, exponent 1+y,
+                              N/sum(mask) scaling, QR, V, accept/reject)                  */
+  BANET_LEGACY_FIXED = 1,  /* legacy/ba.py:148-214 CameraIteration (lambda=|avg|^2, no V)  */
+  BANET_BUNDLE_CAMERA = 2, /* bundlenet.py:122-191 CameraIteration (pose only)            */
+  BANET_BUNDLE = 3         /* bundlenet.py:193-278 BundleIteration (pose + depth basis)   */
+};
+
+typedef struct banet_level {
+  int32_t B;            /* windows                                                        */
+  int32_t N;            /* points per window                                              */
+  int32_t C;            /* feature channels (C <= 256)                                    */
+  int32_t K;            /* depth-basis coefficients; 0 for the pose-only variants; <= 128 */
+  int32_t H, W;         /* target map height / width at this level                        */
+  int32_t variant;      /* BANET_LEGACY_LM ... BANET_BUNDLE                               */
+  int32_t dense;        /* 1: the N = H*W points are this level's own pixel grid          */
+  int32_t tgt_has_grad; /* 1: target map is the reference's [f|gx|gy] 3C layout
+                              (legacy/ba.py:116-118); 0: C channels, gradient computed in
+                              the kernel from the map (same arithmetic as grad_fixed)      */
+  int32_t normalize_rays; /* dense only: 1 = bundlenet.py:119, 0 = legacy/ba.py:33-34     */
+  float scale;          /* dense only: level scale s (points, intrinsics = full-res / s)  */
+  int32_t reserved_;
+  const float* src;     /* dense: source map [B,H,W,C];  sparse: conv1 [B,N,C]            */
+  const float* tgt;     /* target map [B,H,W,C] or [B,H,W,3C]                             */
+  const float* depth;   /* D  [B,N]   (legacy: z-depth; bundle: range along the ray)      */
+  const float* basis;   /* Bs [B,N,K] or NULL when K == 0                                 */
+  const float* rays;    /* sparse: p [B,3,N] (bundlenet.py:115-119); dense: NULL          */
+  const float* fx;      /* sparse: per-point level intrinsics [B,N] each                  */
+  const float* fy;
+  const float* ox;
+  const float* oy;
+  const float* intr;    /* dense: full-resolution (fx,fy,ox,oy) per window [B,4]          */
+} banet_level_t;
+
+/* Five k=1 conv layers of the lambda predictor (bundlenet.py:168-172): filters [Cin,Cout]
+ * row-major (the reference's [1,Cin,Cout] variable), biases [Cout]; C->2C->4C->2C->C->1. */
+typedef struct banet_mlp {
+  const float* w[5];
+  const float* b[5];
+} banet_mlp_t;
+
+/* Per-window LM state carried across iterations and levels (device memory, caller-owned).
+ *   R [B,9]  T [B,3]  Wc [B,K]      current estimate (input and output)
+ *   iters [B] int32                 iterations executed at the current level
+ *   ratio [B]                       legacy "keep ratio" (legacy/ba.py:214 / :344)
+ *   lambda_out [B]                  last lambda (diagnostic)
+ *   delta [B,P]                     last solved update (diagnostic / parity tests)       */
+typedef struct banet_state {
+  float* R;
+  float* T;
+  float* Wc;
+  int32_t* iters;
+  float* ratio;
+  float* lambda_out;
+  float* delta;
+} banet_state_t;
+
+/* (3) one fused assembly pass: warp -> sample -> residual/gradient -> Jacobians -> normal
+ *     equations, for all B windows at the pose (R,T,Wc) -- replaces the TF graph of
+ *     bundlenet.py:206-263 / legacy/ba.py:238-283 plus the EquationConstruction op.
+ *       AtA [B,P,P], Atb [B,P]  (P = 6 + K), absres [B,C] = sum_n |d_nc|, nvalid [B]    */
+size_t banet_ba_assemble_workspace_bytes(const banet_level_t* lv);
+int banet_ba_assemble_f32(const banet_level_t* lv, const float* R, const float* T,
+                          const float* Wc, float* AtA, float* Atb, float* absres,
+                          float* nvalid, void* ws, size_t ws_bytes, banet_stream_t stream);
+
+/* (4) lambda prediction + damping + solve + SE(3)/W update for all B windows
+ *     (bundlenet.py:165-190,241-276; legacy/ba.py:187-213,266-302).  Consumes the outputs
+ *     of (3); updates `st` in place.  l2_base: bundlenet.py:252-253 (pass 1.0 for none). */
+int banet_ba_solve_update_f32(const banet_level_t* lv, const banet_mlp_t* mlp, float l2_base,
+                              const float* AtA, const float* Atb, const float* absres,
+                              const float* nvalid, banet_state_t* st, banet_stream_t stream);
+
+/* (5) the LM loop at one level, entirely enqueued (no host sync): max_iters iterations of
+ *     (3)+(4).  For BANET_LEGACY_LM with early_termination != 0 the accept/reject test and
+ *     the update-norm thresholds of legacy/ba.py:132-140,343-345 are evaluated on the
+ *     device per window (the CheckUpdate pass of iteration k is the assembly pass of
+ *     iteration k+1); st->iters receives the reference's iteration count.               */
+size_t banet_lm_level_workspace_bytes(const banet_level_t* lv);
+int banet_lm_level_f32(const banet_level_t* lv, const banet_mlp_t* mlp, float l2_base,
+                       int max_iters, int early_termination, banet_state_t* st, void* ws,
+                       size_t ws_bytes, banet_stream_t stream);
+
+/* (6) optional kernel timing, used by bench.py for the roofline figure.  Between
+ *     banet_profile_begin and banet_profile_end every launch of the fused assembly kernel
+ *     (from banet_ba_assemble_f32 / banet_lm_level_f32) is bracketed by two hipEvents recorded
+ *     on its stream.  banet_profile_end synchronises those events and returns, per distinct
+ *     level size (tag = points per window N), the number of launches and the summed kernel
+ *     time in milliseconds.  Process-global and NOT thread-safe: a measurement aid, not part
+ *     of the data path; events are created in _begin, never inside the timed region.       */
+int banet_profile_begin(int max_launches);
+int banet_profile_end(int max_tags, int32_t* tag_points, int32_t* tag_launches, double* tag_ms,
+                      int32_t* ntags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BANET_HIP_H_ */

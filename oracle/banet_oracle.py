@@ -272,6 +272,23 @@ def equation_construction_tf_twin(J, G, d):
     return AtA, Atb
 
 
+def equation_construction_gemm(J, G, d):
+    """Same quantity as `equation_construction`, arranged the way a sane CPU port would do it
+    (and the way the HIP kernel does): per-pixel 2x2 M = G^T G and g = G^T d, then one
+    [2N x P]^T [2N x P] GEMM per window instead of N materialised PxP products.  Used for the
+    timed CPU baseline (bench.py) where the literal form needs N*P*P*4 bytes (22 GB at
+    640x480, P=134)."""
+    gx, gy, dd = G[..., 0], G[..., 1], d[..., 0]
+    m11, m12, m22 = (gx * gx).sum(-1), (gx * gy).sum(-1), (gy * gy).sum(-1)       # [B,N]
+    g1, g2 = (gx * dd).sum(-1), (gy * dd).sum(-1)
+    Jx, Jy = J[:, :, 0, :], J[:, :, 1, :]                                            # [B,N,P]
+    Zx = m11[..., None] * Jx + m12[..., None] * Jy
+    Zy = m12[..., None] * Jx + m22[..., None] * Jy
+    AtA = np.matmul(np.swapaxes(Zx, 1, 2), Jx) + np.matmul(np.swapaxes(Zy, 1, 2), Jy)
+    Atb = (np.matmul(np.swapaxes(Jx, 1, 2), g1[..., None]) + np.matmul(np.swapaxes(Jy, 1, 2), g2[..., None]))
+    return AtA, Atb
+
+
 def equation_construction_grad(J, G, d, g0, g1):
     """utils.cu:613-690:  A=GJ; dA = 2*A*g0 + d*g1^T; dJ=G^T dA; dG=dA J^T; dd=A g1.
     g0 [B,P,P] (dL/dAtA), g1 [B,P,1] (dL/dAtb).  Note the alpha=2.0 (utils.cu:651): exact
@@ -527,8 +544,10 @@ def bundle_camera_iteration(conv1, conv2, fx, fy, ox, oy, p, D, R, T, mlp, l2_ba
     return Rn, Tn, dict(AtA=AtA0, Atb=Atb, lam=lam, avg=avg, motion=motion)
 
 
-def bundle_iteration(conv1, conv2, fx, fy, ox, oy, p, D, Bs, R, T, W, mlp, l2_base=None):
-    """BundleNet.BundleIteration, bundlenet.py:193-278.  Bs [B,N,K], W [B,K,1]."""
+def bundle_iteration(conv1, conv2, fx, fy, ox, oy, p, D, Bs, R, T, W, mlp, l2_base=None, eq=None):
+    """BundleNet.BundleIteration, bundlenet.py:193-278.  Bs [B,N,K], W [B,K,1].
+    eq: normal-equation routine (default: the literal utils.cu GEMM chain)."""
+    eq = eq or equation_construction
     dt = conv1.dtype.type
     Dn = D + np.matmul(Bs, W)
     w = warp(R, T, p, Dn, fx, fy, ox, oy)
@@ -542,7 +561,7 @@ def bundle_iteration(conv1, conv2, fx, fy, ox, oy, p, D, Bs, R, T, W, mlp, l2_ba
     jd = depth_jacobian(w["rx"], w["ry"], w["rz"], w["x"], w["y"], w["Z"], fx, fy)
     Jd = np.matmul(jd[..., None], Bs[:, :, None, :])
     J = np.concatenate([Jc, Jd], axis=-1)
-    AtA0, Atb = equation_construction(J, grad, diff)
+    AtA0, Atb = eq(J, grad, diff)
     AtA = damp(AtA0, lam, undamped_last=True)
     sol = solve_lu(AtA, Atb)
     Rn, Tn = _se3_update(sol[:, 0:6], R, T)

@@ -1,0 +1,103 @@
+"""Dense-mode drivers on top of banet_oracle  --  TEST INFRASTRUCTURE ONLY.
+
+"Dense mode"  feeds the reference's iteration bodies with every pixel of a
+pyramid level as a BA point: points = the level's own grid, conv1 = the source map itself
+(bilinear sampling at integer coordinates is the identity), conv2 = [f|gx|gy] of the target
+map.  These helpers build exactly those reference-layout inputs and call the restated
+reference iterations, so the HIP dense path is checked against the same arithmetic.
+"""
+import numpy as np
+
+from . import banet_oracle as orc
+
+
+def level_inputs(intr, lv, normalize, dtype=np.float32):
+    """intr [B,4] full-res; lv: dict(scale,H,W,src[B,H,W,C],tgt[B,H,W,C],D0[B,H,W],basis[B,H,W,K])."""
+    B = lv["src"].shape[0]
+    H, W, s = lv["H"], lv["W"], dtype(lv["scale"])
+    N = H * W
+    vv, uu = np.meshgrid(np.arange(H, dtype=dtype), np.arange(W, dtype=dtype), indexing="ij")
+    pts_full = np.stack([uu.reshape(-1) * s, vv.reshape(-1) * s], -1)[None].repeat(B, 0).astype(dtype)
+    intr = intr.astype(dtype)
+    fx0 = np.repeat(intr[:, 0:1], N, 1)
+    fy0 = np.repeat(intr[:, 1:2], N, 1)
+    ox0 = np.repeat(intr[:, 2:3], N, 1)
+    oy0 = np.repeat(intr[:, 3:4], N, 1)
+    p = orc.compute_coordinates(pts_full, fx0, fy0, ox0, oy0, normalize)
+    out = dict(conv1=lv["src"].reshape(B, N, -1).astype(dtype), conv2=orc.target_map(lv["tgt"].astype(dtype)),
+               fx=fx0 / s, fy=fy0 / s, ox=ox0 / s, oy=oy0 / s, p=p, D=lv["D0"].reshape(B, N, 1).astype(dtype))
+    if lv.get("basis") is not None and lv["basis"].shape[-1] > 0:
+        out["Bs"] = lv["basis"].reshape(B, N, -1).astype(dtype)
+    return out
+
+
+def batch_scene(scenes):
+    """stack per-window scenes (oracle/synth.make_pair_scene dicts) into batched levels"""
+    nl = len(scenes[0]["levels"])
+    levels = []
+    for i in range(nl):
+        l0 = scenes[0]["levels"][i]
+        levels.append(dict(scale=l0["scale"], H=l0["H"], W=l0["W"],
+                           src=np.stack([s["levels"][i]["src"] for s in scenes]),
+                           tgt=np.stack([s["levels"][i]["tgt"] for s in scenes]),
+                           D0=np.stack([s["levels"][i]["D0"] for s in scenes]),
+                           basis=np.stack([s["levels"][i]["basis"] for s in scenes])))
+    intr = np.stack([s["intr"] for s in scenes])
+    return intr, levels
+
+
+def solve_bundle(intr, levels, mlps, iters, l2_base=1000.0, dtype=np.float32, pose_only=False):
+    """Fixed-count dense BA with the bundlenet iteration bodies.  Returns final (R,T,W) and
+    the list of per-iteration records (level, delta, lam, AtA, Atb)."""
+    B = levels[0]["src"].shape[0]
+    K = 0 if pose_only else levels[0]["basis"].shape[-1]
+    R = np.tile(np.eye(3, dtype=dtype)[None], (B, 1, 1))
+    T = np.zeros((B, 3, 1), dtype)
+    W = np.zeros((B, K, 1), dtype)
+    hist = []
+    for li, (lv, n_it) in enumerate(zip(levels, iters)):
+        a = level_inputs(intr, lv, True, dtype)
+        for _ in range(n_it):
+            if pose_only:
+                R, T, dbg = orc.bundle_camera_iteration(a["conv1"], a["conv2"], a["fx"], a["fy"], a["ox"], a["oy"],
+                                                        a["p"], a["D"], R, T, mlps[li], 1.0)
+                hist.append(dict(level=li, delta=dbg["motion"][:, :, 0], lam=dbg["lam"], AtA=dbg["AtA"], Atb=dbg["Atb"],
+                                 avg=dbg["avg"]))
+            else:
+                R, T, W, dbg = orc.bundle_iteration(a["conv1"], a["conv2"], a["fx"], a["fy"], a["ox"], a["oy"], a["p"],
+                                                    a["D"], a["Bs"], R, T, W, mlps[li], l2_base)
+                hist.append(dict(level=li, delta=dbg["solution"][:, :, 0], lam=dbg["lam"], AtA=dbg["AtA"],
+                                 Atb=dbg["Atb"], avg=dbg["avg"], mask=dbg["mask"]))
+    return R, T, W, hist
+
+
+def solve_legacy(intr, levels, mlps, iters, early_termination=True, dtype=np.float32):
+    """Dense legacy tracker (legacy/ba.py CameraIteration2 / CameraIteration), one window at a
+    time (the reference's accept/reject is scalar).  Returns R [B,3,3], T [B,3,1], ratio [B],
+    counts [levels][B]."""
+    B = levels[0]["src"].shape[0]
+    Rs, Ts, ratios, counts = [], [], [], [[0] * B for _ in levels]
+    for b in range(B):
+        R = np.eye(3, dtype=dtype)[None]
+        T = np.zeros((1, 3, 1), dtype)
+        ratio = dtype(1.0)
+        for li, (lv, n_it) in enumerate(zip(levels, iters)):
+            one = {k: (v[b:b + 1] if isinstance(v, np.ndarray) else v) for k, v in lv.items()}
+            a = level_inputs(intr[b:b + 1], one, False, dtype)
+            it = 0
+            if early_termination:
+                uw = ut = dtype(1.0)
+                while it < n_it and orc.ANGLE_CHANGE < uw and orc.TRANSLATION_CHANGE < ut:
+                    R, T, uw, ut, ratio, _ = orc.legacy_camera_iteration2(a["conv1"], a["conv2"], a["fx"], a["fy"],
+                                                                          a["ox"], a["oy"], a["p"], a["D"], R, T, mlps[li])
+                    it += 1
+            else:
+                for _ in range(n_it):
+                    R, T, ratio = orc.legacy_camera_iteration(a["conv1"], a["conv2"], a["fx"], a["fy"], a["ox"],
+                                                              a["oy"], a["p"], a["D"], R, T)
+                    it += 1
+            counts[li][b] = it
+        Rs.append(R[0])
+        Ts.append(T[0])
+        ratios.append(float(np.squeeze(ratio)))
+    return np.stack(Rs), np.stack(Ts), np.array(ratios), counts

@@ -1,0 +1,102 @@
+"""CPU-side checks of the C-ABI boundary: the shared library loads, exports every symbol that
+include/banet_hip.h declares, mirrors the struct layouts, and validates arguments without
+touching a GPU.  (No compute calls here -- those are the -m gpu tests.)"""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+HEADER = os.path.join(ROOT, "include", "banet_hip.h")
+
+
+@pytest.fixture(scope="module")
+def capi():
+    sys.path.insert(0, ROOT)
+    from banet_amd import _capi
+    if not os.path.exists(_capi.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _capi
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(banet_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(capi):
+    L = capi.lib()
+    names = declared_functions()
+    assert len(names) >= 11
+    for n in names:
+        assert hasattr(L, n), "libbanet_hip.so does not export %s" % n
+        assert n in capi.EXPORTS, "ctypes binding lacks %s" % n
+
+
+def test_version_and_error_strings(capi):
+    L = capi.lib()
+    assert L.banet_version() == 100
+    assert L.banet_error_string(0) == b"ok"
+    assert b"workspace" in L.banet_error_string(-2)
+
+
+def test_struct_layouts_match_the_header(capi, tmp_path):
+    """compile a tiny C program against the header and compare sizeof/offsetof with ctypes"""
+    prog = tmp_path / "layout.c"
+    prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "banet_hip.h"\n'
+                    'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(banet_level_t), '
+                    'offsetof(banet_level_t, scale), offsetof(banet_level_t, src), offsetof(banet_level_t, intr), '
+                    'sizeof(banet_mlp_t), sizeof(banet_state_t), offsetof(banet_state_t, iters), '
+                    'offsetof(banet_level_t, variant));return 0;}\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    want = [ctypes.sizeof(capi.Level), capi.Level.scale.offset, capi.Level.src.offset, capi.Level.intr.offset,
+            ctypes.sizeof(capi.Mlp), ctypes.sizeof(capi.State), capi.State.iters.offset, capi.Level.variant.offset]
+    assert got == want
+
+
+def test_argument_validation_without_gpu(capi):
+    L = capi.lib()
+    assert L.banet_equation_construction_workspace_bytes(1, 4096, 128, 6) > 0
+    assert L.banet_equation_construction_workspace_bytes(1, 4096, 128, 134) > 0
+    assert L.banet_equation_construction_workspace_bytes(1, 4096, 128, 273) == 0      # > 17 blocks: unsupported
+    assert L.banet_equation_construction_workspace_bytes(0, 4096, 128, 6) == 0
+    assert L.banet_equation_construction_f32(None, None, None, None, None, 1, 8, 4, 6, None, 0, None) == -1
+    assert L.banet_equation_construction_grad_f32(None, None, None, None, None, None, None, None, 1, 8, 4, 6, None, 0,
+                                                  None) == -1
+    lv = capi.Level()
+    lv.B, lv.N, lv.C, lv.K, lv.H, lv.W = 2, 160 * 120, 128, 32, 120, 160
+    lv.variant, lv.dense, lv.scale = capi.BUNDLE, 1, 1.0
+    nb = L.banet_lm_level_workspace_bytes(ctypes.byref(lv))
+    assert nb > 0 and nb % 256 == 0
+    assert L.banet_ba_assemble_workspace_bytes(ctypes.byref(lv)) <= nb
+    lv.K = 129                                                                           # beyond the compiled set
+    assert L.banet_lm_level_workspace_bytes(ctypes.byref(lv)) == 0
+    lv.K = 32
+    assert L.banet_ba_assemble_f32(ctypes.byref(lv), None, None, None, None, None, None, None, None, 0, None) == -1
+
+
+def test_gpu_only_no_fallback(capi):
+    """the product path must fail loudly on CPU tensors instead of silently computing elsewhere"""
+    import torch
+    from banet_amd import ops
+    J = torch.zeros(1, 8, 2, 6)
+    G = torch.zeros(1, 8, 4, 2)
+    d = torch.zeros(1, 8, 4, 1)
+    with pytest.raises(capi.BanetError):
+        ops.equation_construction(J, G, d)
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "banet_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "oracle/" not in txt.replace(
+                    "oracle/synth.py", ""), f

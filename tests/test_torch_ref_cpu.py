@@ -1,0 +1,52 @@
+"""The float64 torch twin used for the full-size GPU checks agrees with the numpy oracle."""
+import numpy as np
+import torch
+
+import torch_ref
+from oracle import banet_oracle as orc, dense as odense, synth
+
+
+def _scene(K, C=6, H=20, W=28, big_motion=False):
+    t = [0.5, -0.3, 0.2] if big_motion else [0.06, -0.04, 0.03]
+    w = [0.08, -0.06, 0.05] if big_motion else [0.01, -0.008, 0.006]
+    sc = synth.make_pair_scene(H, W, C, K, [1], 3, normalize_rays=True, w_gt=w, t_gt=t)
+    return sc, odense.batch_scene([sc])
+
+
+def test_bundle_normal_equations_match_oracle():
+    for big in (False, True):
+        sc, (intr, levels) = _scene(5, big_motion=big)
+        lv = levels[0]
+        a = odense.level_inputs(intr, lv, True, np.float64)
+        R = synth.rodrigues(np.array([0.004, 0.002, -0.003]))[None]
+        T = (np.asarray(sc["T_gt"]) * 0.8).reshape(1, 3, 1)
+        Wc = np.full((1, 5, 1), 0.01)
+        mlp = orc.he_normal_mlp_weights(6, 1)
+        _, _, _, dbg = orc.bundle_iteration(a["conv1"], a["conv2"], a["fx"], a["fy"], a["ox"], a["oy"], a["p"], a["D"],
+                                            a["Bs"], R, T, Wc, mlp, 1000.0)
+        tt = lambda x: torch.from_numpy(np.ascontiguousarray(x))  # noqa: E731
+        AtA, Atb, absres, nvalid = torch_ref.dense_assemble(tt(intr), 1.0, tt(lv["src"]), tt(lv["tgt"]), tt(lv["D0"]),
+                                                            tt(lv["basis"]), tt(R), tt(T), tt(Wc), True, True)
+        assert 0 < nvalid.item() <= 20 * 28 and nvalid.item() == dbg["mask"].sum()
+        if big:
+            assert nvalid.item() < 20 * 28                    # some pixels really leave the image
+        np.testing.assert_allclose(AtA.numpy(), dbg["AtA"], rtol=1e-9, atol=1e-9 * np.abs(dbg["AtA"]).max())
+        np.testing.assert_allclose(Atb.numpy()[..., None], dbg["Atb"], rtol=1e-9, atol=1e-9 * np.abs(dbg["Atb"]).max())
+        np.testing.assert_allclose(absres.numpy() / (20 * 28), dbg["avg"][:, 0], rtol=1e-10)
+
+
+def test_legacy_normal_equations_match_oracle():
+    sc = synth.make_pair_scene(20, 28, 6, 0, [1], 3, normalize_rays=False, w_gt=[0.01, -0.008, 0.006],
+                               t_gt=[0.06, -0.04, 0.03])
+    intr, levels = odense.batch_scene([sc])
+    lv = levels[0]
+    a = odense.level_inputs(intr, lv, False, np.float64)
+    R, T = np.eye(3)[None], np.zeros((1, 3, 1))
+    mlp = orc.he_normal_mlp_weights(6, 1)
+    *_, dbg = orc.legacy_camera_iteration2(a["conv1"], a["conv2"], a["fx"], a["fy"], a["ox"], a["oy"], a["p"], a["D"],
+                                           R, T, mlp)
+    tt = lambda x: torch.from_numpy(np.ascontiguousarray(x))  # noqa: E731
+    AtA, Atb, absres, nvalid = torch_ref.dense_assemble(tt(intr), 1.0, tt(lv["src"]), tt(lv["tgt"]), tt(lv["D0"]), None,
+                                                        tt(R), tt(T), None, False, False)
+    np.testing.assert_allclose(AtA.numpy(), dbg["AtA"], rtol=1e-9, atol=1e-9 * np.abs(dbg["AtA"]).max())
+    np.testing.assert_allclose(Atb.numpy()[..., None], dbg["Atb"], rtol=1e-9, atol=1e-9 * np.abs(dbg["Atb"]).max())
