@@ -604,6 +604,7 @@ __global__ __launch_bounds__(kBlock, (NB == 0 ? 4 : 3)) void ba_assemble_kernel(
   float* sAbs = sEpi + 128;       // [4][256]
   float* sH = sEpi + 128 + 1024;  // [4][8][KPAD]
   {
+    __syncthreads();  // also orders the sHacc zero-fill when this workgroup had no tile
     // fold the 16 pixel slots of each (wave, quantity): fixed order
     float hsum = 0.f;
     if (tid < 4 * 28) {
@@ -611,7 +612,6 @@ __global__ __launch_bounds__(kBlock, (NB == 0 ? 4 : 3)) void ba_assemble_kernel(
 #pragma unroll
       for (int i = 0; i < 16; ++i) hsum += hp[i];
     }
-    if (NB > 0) __syncthreads();  // sEpi overlays sB: every wave must be done with the last tile (it is) and with sHacc reads
     if (tid < 4 * 28) sRed[(tid / 28) * 32 + (tid % 28)] = hsum;
 #pragma unroll
     for (int ch = 0; ch < CH; ++ch)
