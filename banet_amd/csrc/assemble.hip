@@ -175,6 +175,7 @@ __global__ __launch_bounds__(kBlock, (NB == 0 ? 4 : 3)) void ba_assemble_kernel(
   const int N = lv.N, C = lv.C, K = lv.K, H = lv.H, W = lv.W;
   const int Ct = GRAD ? 3 * C : C;
   const bool dense = lv.dense != 0;
+  const int dbg = lv.reserved_;  // profiling ablation bits (tools/prof_assemble.py); 0 in production
 
   const float* __restrict__ tgt_b = lv.tgt + (size_t)b * H * W * Ct;
   const float* __restrict__ src_b = lv.src + (size_t)b * N * C;
@@ -241,7 +242,8 @@ __global__ __launch_bounds__(kBlock, (NB == 0 ? 4 : 3)) void ba_assemble_kernel(
 
     // ---- P0: basis tile -> LDS -------------------------------------------------------
     if constexpr (NB > 0) {
-      if ((K & 3) == 0) {
+      if (dbg & 8) {
+      } else if ((K & 3) == 0) {
         constexpr int QPR = KPAD / 4;  // float4 per LDS row
         for (int idx = tid; idx < kTilePix * QPR; idx += kBlock) {
           const int n = idx / QPR, q = idx - n * QPR;
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(kBlock, (NB == 0 ? 4 : 3)) void ba_assemble_kernel(
       const int base = 16 * w;
       // binary-counter merge tree over 8 pixel pairs (see common.hpp::bfly_slot)
       Q5 p2{0.f, 0.f, 0.f, 0.f, 0.f}, p3 = p2, p4 = p2, q = p2;
-      for (int pp = 0; pp < 8; ++pp) {
+      for (int pp = 0; pp < ((dbg & 4) ? 0 : 8); ++pp) {
         const Q5 qa = pixel_q5(base + 2 * pp);
         const Q5 qb = pixel_q5(base + 2 * pp + 1);
         const Q5 m1 = q5_merge(qa, qb, 32);
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(kBlock, (NB == 0 ? 4 : 3)) void ba_assemble_kernel(
       q = q5_finish(q);
       if constexpr (!GRAD) {
         // patch the pixels whose stencil touches the image rim (rare): slow generic path
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < ((dbg & 1) ? 0 : 16); ++i) {
           const int n = base + i;
           const int flags = rfl(__float_as_int(sGeo[n * kGeoStride + 6]));
           if (flags & 4) {  // wave-uniform
@@ -553,7 +555,7 @@ __global__ __launch_bounds__(kBlock, (NB == 0 ? 4 : 3)) void ba_assemble_kernel(
       // ---- P4: H_cd += u_n b_n^T, Atb_d += r_n b_n ;  lane = coefficient(s) ----------
       {
         const int kb = lane * KV;
-        if (kb < KPAD) {
+        if (kb < KPAD && !(dbg & 2)) {
 #pragma unroll 4
           for (int i = 0; i < 16; ++i) {
             const int n = 16 * w + i;
@@ -574,7 +576,7 @@ __global__ __launch_bounds__(kBlock, (NB == 0 ? 4 : 3)) void ba_assemble_kernel(
         }
       }
       // ---- P5: H_dd += sum_n s_n b_n b_n^T on the matrix cores -----------------------
-      if (mf_on) {
+      if (mf_on && !(dbg & 16)) {
         const int col = lane & 15, kq = lane >> 4;
 #pragma unroll 2
         for (int kk = 0; kk < kTilePix / 4; ++kk) {

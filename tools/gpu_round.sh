@@ -20,21 +20,25 @@ if [[ $MODE == bench || $MODE == all ]]; then
   tail -5 $OUT/bench.log
 fi
 if [[ $MODE == prof || $MODE == all ]]; then
-  rm -rf $OUT/prof
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o r01 -- python $OLDPWD/bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline > $OLDPWD/$OUT/prof_run.log 2>&1)
+  rm -rf /tmp/prof && mkdir -p /tmp/prof $OUT/prof
+  REPO=$PWD
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r01 -- python $REPO/bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline > $REPO/$OUT/prof_run.log 2>&1)
   echo "prof exit $?" >> $OUT/prof_run.log
-  find $OUT/prof -name "*kernel_stats*" | head -3
-  f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 "$f"
-  # the trace itself is large; keep only the stats
-  find $OUT/prof -name "*kernel_trace.csv" -size +20M -delete
+  tail -3 $OUT/prof_run.log
+  find /tmp/prof -type f | head -20
+  for f in $(find /tmp/prof -name "*stats*.csv"); do cp "$f" $OUT/prof/; done
+  f=$(find /tmp/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -14 "$f"
 fi
 if [[ $MODE == pmc || $MODE == all ]]; then
-  rm -rf $OUT/pmc
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OLDPWD/$OUT/pmc -o fetch -- python $OLDPWD/bench.py --gpus 1 --steps 1 --warmup 0 --no-cpu-baseline > $OLDPWD/$OUT/pmc_run.log 2>&1)
-  echo "pmc fetch exit $?" >> $OUT/pmc_run.log
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OLDPWD/$OUT/pmc -o write -- python $OLDPWD/bench.py --gpus 1 --steps 1 --warmup 0 --no-cpu-baseline >> $OLDPWD/$OUT/pmc_run.log 2>&1)
-  echo "pmc write exit $?" >> $OUT/pmc_run.log
-  python tools/summarize_pmc.py $OUT/pmc > $OUT/pmc_summary.txt 2>&1
-  tail -20 $OUT/pmc_summary.txt
+  rm -rf /tmp/pmc && mkdir -p /tmp/pmc
+  REPO=$PWD
+  for CNT in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d /tmp/pmc -o $CNT -- python $REPO/bench.py --gpus 1 --steps 1 --warmup 0 --no-cpu-baseline > $REPO/$OUT/pmc_run_$CNT.log 2>&1)
+    echo "pmc $CNT exit $?" >> $OUT/pmc_run_$CNT.log
+    tail -2 $OUT/pmc_run_$CNT.log
+  done
+  find /tmp/pmc -type f | head
+  python tools/summarize_pmc.py /tmp/pmc > $OUT/pmc_summary.txt 2>&1
+  tail -30 $OUT/pmc_summary.txt
 fi
 exit 0

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Ablation timing of the fused assembly kernel at L0 (640x480, C=K=128): which phase costs what.
+Uses the reserved_ field of banet_level_t as debug bits (see assemble.hip `dbg`)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from banet_amd import dense as bdense, ops, synth as bsynth  # noqa: E402
+from banet_amd.bundlenet import he_normal_lambda_weights  # noqa: E402
+
+B = int(os.environ.get("PB", "4"))
+H, W, C, K = 480, 640, 128, int(os.environ.get("PK", "128"))
+only = os.environ.get("PONLY")
+dev = torch.device("cuda:0")
+intr, levels, gt = bsynth.make_dense_windows(B, H, W, C, K, [1], 5, dev, trans_mag=0.06)
+variant = "bundle" if K > 0 else "bundle_camera"
+ba = bdense.DenseBA(intr, levels, [he_normal_lambda_weights(C, 1)], variant, 1000.0)
+p = ba.problems[0]
+R = torch.eye(3, device=dev).repeat(B, 1, 1)
+T = (gt["T"] * 0.7).reshape(B, 3, 1).to(dev)
+Wc = torch.zeros(B, max(K, 1), 1, device=dev)[:, :K]
+byts = ba.algorithmic_bytes_per_iteration(0) * B
+cases = [(0, "full"), (1, "no rim patch"), (2, "no H_cd"), (16, "no MFMA"), (18, "no H_cd, no MFMA"), (4, "no gather"),
+         (4 | 2 | 16, "no gather/H_cd/MFMA"), (4 | 2 | 16 | 8, "geometry + sync only")]
+for bits, name in cases:
+    if only is not None and int(only) != bits:
+        continue
+    p.c.reserved_ = bits
+    for _ in range(2):
+        ops.ba_assemble(p, R, T, Wc if K else None)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 5
+    e0.record()
+    for _ in range(n):
+        ops.ba_assemble(p, R, T, Wc if K else None)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    print("%-28s bits=%2d  %8.1f us/launch  %7.1f us/window  %7.1f GB/s" % (name, bits, ms * 1e3, ms * 1e3 / B, byts / ms / 1e6))
