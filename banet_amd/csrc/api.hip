@@ -38,7 +38,7 @@ static LevelWs carve_level(const banet_level_t* lv, const AsmPlan& pl, void* ws)
     off += align_up(bytes, 256);
     return r;
   };
-  w.partials = reinterpret_cast<float*>(take(pl.partial_bytes));
+  w.partials = reinterpret_cast<float*>(take(pl.ws_bytes));
   w.AtA = reinterpret_cast<float*>(take((size_t)lv->B * pl.P * pl.P * sizeof(float)));
   w.Atb = reinterpret_cast<float*>(take((size_t)lv->B * pl.P * sizeof(float)));
   w.absres = reinterpret_cast<float*>(take((size_t)lv->B * lv->C * sizeof(float)));
@@ -130,7 +130,7 @@ int banet_equation_construction_grad_f32(const float* J, const float* G, const f
 size_t banet_ba_assemble_workspace_bytes(const banet_level_t* lv) {
   AsmPlan pl;
   if (plan_assemble(lv, &pl) != BANET_OK) return 0;
-  return pl.partial_bytes;
+  return align_up(pl.ws_bytes, 256);
 }
 
 int banet_ba_assemble_f32(const banet_level_t* lv, const float* R, const float* T, const float* Wc, float* AtA,
@@ -141,8 +141,8 @@ int banet_ba_assemble_f32(const banet_level_t* lv, const float* R, const float* 
   AsmPlan pl;
   rc = plan_assemble(lv, &pl);
   if (rc != BANET_OK) return rc;
-  if (!ws || ws_bytes < pl.partial_bytes || !aligned256(ws)) return BANET_ERR_WORKSPACE;
-  return launch_assemble(lv, pl, R, T, Wc, nullptr, 0, static_cast<float*>(ws), AtA, Atb, absres, nvalid,
+  if (!ws || ws_bytes < pl.ws_bytes || !aligned256(ws)) return BANET_ERR_WORKSPACE;
+  return launch_assemble(lv, pl, R, T, Wc, nullptr, 0, ws, AtA, Atb, absres, nvalid,
                          static_cast<hipStream_t>(stream));
 }
 

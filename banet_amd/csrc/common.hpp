@@ -29,14 +29,51 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// One level of the transposing butterfly: lanes with bit `s` clear keep `a`, lanes with the
-// bit set keep `b`; each adds the partner's copy of what it keeps.  After merging with
-// s = 32,16,8,4 a lane holds one of 16 values summed over the 16 lanes sharing its bits 5..2.
+// ---- cross-lane primitives (wave64, gfx950) ------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {  // CTRL: LLVM dpp_ctrl encoding
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+constexpr int kDppRor8 = 0x128;        // lane i <- lane i^8   (rotate by 8 inside a 16-lane row)
+constexpr int kDppHalfMirror = 0x141;  // lane i <- lane i^7   (mirror inside each 8-lane half row)
+constexpr int kDppXor2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int kDppXor1 = 0xB1;         // quad_perm [1,0,3,2]
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// sum over the 16 lanes of a DPP row; every lane of the row gets the total (fixed order)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<kDppRor8>(v);
+  v += dpp_mov<kDppHalfMirror>(v);
+  v += dpp_mov<kDppXor2>(v);
+  v += dpp_mov<kDppXor1>(v);
+  return v;
+}
+
+// One level of the transposing butterfly: lanes with bit `s` clear keep `a`, lanes with the bit
+// set keep `b`; each adds its partner's copy of what it keeps.  Partner = a lane that differs in
+// bit `s` and agrees in all higher bits (lower bits may differ: s=4 pairs i with i^7).  After the
+// levels s = 32,16,8,4(,2,1) a lane holds one value summed over all lanes that share its higher
+// bits.  s=32/16 use the gfx950 half/row swaps, s<=8 DPP -- no LDS crossbar (ds_bpermute) traffic.
 __device__ __forceinline__ float bfly_merge(float a, float b, int s) {
+  // NOTE: the __builtin_amdgcn_permlane{16,32}_swap builtins are miscompiled by hipcc 7.2 when
+  // both results are consumed as floats (r[0] + r[1] becomes r[0] + r[0]; tools/probe/bfly.hip),
+  // hence inline asm.  The leading s_nop 1 covers the VALU-write -> permlane-read hazard
+  // (2 wait states) that the compiler cannot see inside an asm statement.
+  if (s == 32) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;  // lanes <32: a_lo + a_hi ; lanes >=32: b_lo + b_hi
+  }
+  if (s == 16) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;  // even rows: a_r + a_{r+1} ; odd rows: b_{r-1} + b_r
+  }
   const bool hi = (lane_id() & s) != 0;
   const float keep = hi ? b : a;
   const float send = hi ? a : b;
-  return keep + __shfl_xor(send, s, 64);
+  if (s == 8) return keep + dpp_mov<kDppRor8>(send);
+  if (s == 4) return keep + dpp_mov<kDppHalfMirror>(send);
+  if (s == 2) return keep + dpp_mov<kDppXor2>(send);
+  return keep + dpp_mov<kDppXor1>(send);
 }
 
 // pixel slot (0..15) whose channel-sums end up on this lane after the 4-level merge tree
@@ -60,14 +97,16 @@ __device__ __forceinline__ Q5 q5_merge(const Q5& a, const Q5& b, int s) {
 }
 
 __device__ __forceinline__ Q5 q5_finish(Q5 q) {  // remaining lane bits 1,0
-#pragma unroll
-  for (int s = 2; s >= 1; s >>= 1) {
-    q.m11 += __shfl_xor(q.m11, s, 64);
-    q.m12 += __shfl_xor(q.m12, s, 64);
-    q.m22 += __shfl_xor(q.m22, s, 64);
-    q.g1 += __shfl_xor(q.g1, s, 64);
-    q.g2 += __shfl_xor(q.g2, s, 64);
-  }
+  q.m11 += dpp_mov<kDppXor2>(q.m11);
+  q.m12 += dpp_mov<kDppXor2>(q.m12);
+  q.m22 += dpp_mov<kDppXor2>(q.m22);
+  q.g1 += dpp_mov<kDppXor2>(q.g1);
+  q.g2 += dpp_mov<kDppXor2>(q.g2);
+  q.m11 += dpp_mov<kDppXor1>(q.m11);
+  q.m12 += dpp_mov<kDppXor1>(q.m12);
+  q.m22 += dpp_mov<kDppXor1>(q.m22);
+  q.g1 += dpp_mov<kDppXor1>(q.g1);
+  q.g2 += dpp_mov<kDppXor1>(q.g2);
   return q;
 }
 

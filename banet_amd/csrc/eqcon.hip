@@ -14,7 +14,36 @@
 
 namespace banet {
 
-constexpr int kEqPix = 32;  // pixels per tile (64 Jacobian rows = 16 MFMA k-steps)
+constexpr int kEqPix = 32;
+
+// fixed-order sum of the per-workgroup partials [P*P + P] (cf. utils.cu:181-198)
+__global__ __launch_bounds__(256) void eq_reduce_kernel(const float* __restrict__ partials, int G, int pstride, int P,
+                                                        float* __restrict__ AtA, float* __restrict__ Atb) {
+  const int b = blockIdx.y;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= P * P + P) return;
+  const float* p = partials + (size_t)b * G * pstride + e;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int i = 0;
+  for (; i + 3 < G; i += 4) {
+    s0 += p[(size_t)(i + 0) * pstride];
+    s1 += p[(size_t)(i + 1) * pstride];
+    s2 += p[(size_t)(i + 2) * pstride];
+    s3 += p[(size_t)(i + 3) * pstride];
+  }
+  for (; i < G; ++i) s0 += p[(size_t)i * pstride];
+  const float v = (s0 + s1) + (s2 + s3);
+  if (e < P * P)
+    AtA[(size_t)b * P * P + e] = v;
+  else
+    Atb[(size_t)b * P + (e - P * P)] = v;
+}
+
+void launch_reduce(const float* partials, int B, int G, int pstride, int P, float* AtA, float* Atb, hipStream_t s) {
+  const int total = P * P + P;
+  hipLaunchKernelGGL(eq_reduce_kernel, dim3((total + 255) / 256, B), dim3(256), 0, s, partials, G, pstride, P, AtA, Atb);
+}
+  // pixels per tile (64 Jacobian rows = 16 MFMA k-steps)
 
 struct EqArgs {
   const float* J;
@@ -94,14 +123,12 @@ __global__ __launch_bounds__(kBlock) void eq_construction_kernel(const EqArgs a)
       auto L1 = [&](int o) { return q5_merge(pixel_q5(base + o), pixel_q5(base + o + 1), 32); };
       auto L2 = [&](int o) { return q5_merge(L1(o), L1(o + 2), 16); };
       Q5 q = q5_merge(L2(0), L2(4), 8);
-#pragma unroll
-      for (int s = 4; s >= 1; s >>= 1) {
-        q.m11 += __shfl_xor(q.m11, s, 64);
-        q.m12 += __shfl_xor(q.m12, s, 64);
-        q.m22 += __shfl_xor(q.m22, s, 64);
-        q.g1 += __shfl_xor(q.g1, s, 64);
-        q.g2 += __shfl_xor(q.g2, s, 64);
-      }
+      q.m11 += dpp_mov<kDppHalfMirror>(q.m11);  // remaining lane bits 2,1,0 (i^7, i^2, i^1 cover all 8)
+      q.m12 += dpp_mov<kDppHalfMirror>(q.m12);
+      q.m22 += dpp_mov<kDppHalfMirror>(q.m22);
+      q.g1 += dpp_mov<kDppHalfMirror>(q.g1);
+      q.g2 += dpp_mov<kDppHalfMirror>(q.g2);
+      q = q5_finish(q);
       if ((lane & 7) == 0) {
         const int n = base + (((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2));
         sM[n * 4 + 0] = q.m11;
@@ -337,7 +364,7 @@ int launch_eq(const float* J, const float* G, const float* d, float* AtA, float*
     case 17: launch_eq_nb<17>(a, s); break;
     default: return BANET_ERR_UNSUPPORTED;
   }
-  launch_reduce(partials, nullptr, 0, B, pl.Gr, pl.pstride, P, -1, AtA, Atb, nullptr, nullptr, s);
+  launch_reduce(partials, B, pl.Gr, pl.pstride, P, AtA, Atb, s);
   return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;
 }
 

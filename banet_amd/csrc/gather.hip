@@ -1,0 +1,660 @@
+// ba_gather_kernel -- the HBM-bound half of one BA assembly pass on gfx950.
+//
+// Per pixel n of window b (citations under /root/reference):
+//   D = D0 + Bs.W                         bundlenet.py:208
+//   X = (R p) D + T ; x,y,Z ; px,py       bundlenet.py:209-224 / legacy/ba.py:239-251
+//   sample [f|gx|gy] at (px,py), mask     utils_python.py:61-117 / bundlenet.py:154-157
+//   d = m (F2w - F1) ; G = m [gx,gy]      legacy/ba.py:258-264 (bundlenet: opposite sign)
+//   M = G^T G (2x2), g = G^T d            utils.cu:331-340,382-391 (GEMM-F1, F4)
+//   Jc (2x6), jd (2)                      legacy/ba.py:36-48 ; bundlenet.py:49-74
+//   H_cc += Jc^T M Jc ; Atb_c += Jc^T g   utils.cu:344-380,393-414 restricted to the pose block
+//   record (u = Jc^T M jd, s = jd^T M jd, r = jd^T g) for the depth-basis blocks (syrk.hip)
+//
+// Design: NO workgroup barriers and no LDS in the main loop -- every wave is an independent
+// stream, so occupancy (4 waves/SIMD) hides the dependent chain basis-row -> depth -> projection
+// -> texel address -> 13 row loads.  A wave owns 64-pixel batches (8x8 patches):
+//   1. depth: the 64 basis rows are read as coalesced 512-B rows (64 loads in flight), each lane
+//      keeps its partial dot with W, and a 6-level transposing butterfly (one shuffle per value)
+//      leaves D_j on lane j;
+//   2. geometry with lane = pixel (all 64 lanes busy);
+//   3. gather with lane = channel pair: pixel j's scalars come from v_readlane (SGPRs), its
+//      texel rows are coalesced 512-B loads with scalar bases; two pixels per trip = 26 loads in
+//      flight per wave; the five channel sums per pixel go through the same butterfly so that
+//      pixel j's sums land on lane j;
+//   4. 6x6 algebra with lane = pixel; H_cc in LDS accumulators (ds_add_f32, one owner per address).
+#include "kernels.hpp"
+
+#ifndef BANET_GATHER_WAVES
+#define BANET_GATHER_WAVES 3
+#endif
+
+namespace banet {
+
+struct GatherArgs {
+  banet_level_t lv;
+  const float* R;
+  const float* T;
+  const float* Wc;
+  const int32_t* active;
+  int active_stride;
+  float* rec;       // [B][N][8]  u0..u5, s, r   (bundle only)
+  float* partials;  // [B][G][kGHdr + C]
+  int G, tiles, tiles_x, tiles_y, groups;
+};
+
+template <int VEC>
+struct Vec {
+  float v[VEC];
+};
+
+// Branch-free row load: lanes beyond the row length read element 0 (always valid) and are
+// zeroed by a select afterwards.  No exec-mask branch => the compiler can keep every row load
+// of a pixel pair in flight together (an `if (ok) load` splits them into wait-separated blocks).
+template <int VEC>
+__device__ __forceinline__ Vec<VEC> ldv(const float* __restrict__ row, int c, bool ok) {
+  Vec<VEC> r;
+  const float* p = row + (ok ? c : 0);
+  if constexpr (VEC == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    r.v[0] = ok ? t.x : 0.f;
+    r.v[1] = ok ? t.y : 0.f;
+  } else {
+    const float t = *p;
+    r.v[0] = ok ? t : 0.f;
+  }
+  return r;
+}
+
+// dense tile order: vertical strips 8 tiles wide, row-major inside a strip, so that tiles that
+// are processed at the same time share target rows in L1/L2.
+__device__ __forceinline__ void tile_coords(int t, int tiles_x, int tiles_y, int& tx, int& ty) {
+  const int full = tiles_x >> 3;
+  const int per_strip = tiles_y << 3;
+  if (t < full * per_strip) {
+    const int s = t / per_strip;
+    const int r = t - s * per_strip;
+    ty = r >> 3;
+    tx = (s << 3) + (r & 7);
+  } else {
+    const int r = t - full * per_strip;
+    const int wl = tiles_x - (full << 3);
+    ty = r / wl;
+    tx = (full << 3) + (r - ty * wl);
+  }
+}
+
+__device__ __forceinline__ float rdl(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ int rdl(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+
+// binary-counter carry chain of the transposing butterfly: leaf t (0..63) in, result out after
+// leaf 63; level L merges with lane distance 32>>L, so leaf t ends on lane bitrev6(t).
+__device__ __forceinline__ float merge(float a, float b, int s) { return bfly_merge(a, b, s); }
+__device__ __forceinline__ Q5 merge(const Q5& a, const Q5& b, int s) { return q5_merge(a, b, s); }
+
+template <typename TT>
+__device__ __forceinline__ void carry_push(TT (&pend)[6], TT v, int t, TT& out) {
+  bool done = false;
+#pragma unroll
+  for (int L = 0; L < 6; ++L) {
+    if (!done) {
+      if (((t >> L) & 1) == 0) {
+        pend[L] = v;
+        done = true;
+      } else {
+        v = merge(pend[L], v, 32 >> L);
+      }
+    }
+  }
+  if (!done) out = v;
+}
+
+__device__ __forceinline__ int brev6(int t) { return (int)(__brev((unsigned)t) >> 26); }
+
+#ifdef BANET_TIMING  // development aid: per-segment cycle counts of the gather loop (tools/prof_assemble.py)
+__device__ __forceinline__ unsigned long long tick() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define BANET_TICK(var) const unsigned long long var = tick()
+#define BANET_TACC(acc, a, b) acc += (float)((b) - (a))
+#else
+#define BANET_TICK(var)
+#define BANET_TACC(acc, a, b)
+#endif
+
+// Pixel id n (= the lane that owns the pixel) -> position inside the 8x8 patch.  The butterfly
+// visits pixel ids in the order brev6(0), brev6(1), ...; mapping id n to the Z-order (Morton)
+// position of brev6(n) makes consecutive visits spatial neighbours (they share 8 of their 12
+// target texel rows while those are still in L1/L2).
+__device__ __forceinline__ void patch_pos(int n, int& px, int& py) {
+  const int z = brev6(n);  // visit order of this pixel id
+  px = (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4);
+  py = ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4);
+}
+
+// Slow generic path for pixels whose gradient stencil touches the image rim: clamped taps
+// (utils_python.py:96-99) and reflect-padded central differences (bundlenet.py:97-99).
+template <int VEC, int CH>
+__device__ __noinline__ Q5 border_pixel_q5(int x0, int y0, float w00, float w01, float w10, float w11,
+                                           const float* __restrict__ srow, const float* __restrict__ tgt_b, int C,
+                                           int H, int W, int lane, float (&absd)[CH][VEC]) {
+  Q5 q{0.f, 0.f, 0.f, 0.f, 0.f};
+  const float wt[4] = {w00, w01, w10, w11};
+  const int xs[2] = {min(max(x0, 0), W - 1), min(max(x0 + 1, 0), W - 1)};
+  const int ys[2] = {min(max(y0, 0), H - 1), min(max(y0 + 1, 0), H - 1)};
+#pragma unroll
+  for (int ch = 0; ch < CH; ++ch) {
+    const int c = (ch * 64 + lane) * VEC;
+    const bool ok = c < C;
+    const Vec<VEC> f1 = ldv<VEC>(srow, c, ok);
+    Vec<VEC> f, gx, gy;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) f.v[e] = gx.v[e] = gy.v[e] = 0.f;
+#pragma unroll
+    for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+      for (int ix = 0; ix < 2; ++ix) {
+        const int xc = xs[ix], yc = ys[iy];
+        const Vec<VEC> cc = ldv<VEC>(tgt_b + (size_t)(yc * W + xc) * C, c, ok);
+        const Vec<VEC> xl = ldv<VEC>(tgt_b + (size_t)(yc * W + refl_m(xc)) * C, c, ok);
+        const Vec<VEC> xr = ldv<VEC>(tgt_b + (size_t)(yc * W + refl_p(xc, W)) * C, c, ok);
+        const Vec<VEC> yu = ldv<VEC>(tgt_b + (size_t)(refl_m(yc) * W + xc) * C, c, ok);
+        const Vec<VEC> yd = ldv<VEC>(tgt_b + (size_t)(refl_p(yc, H) * W + xc) * C, c, ok);
+        const float wq = wt[iy * 2 + ix];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          f.v[e] += cc.v[e] * wq;
+          gx.v[e] += (0.5f * (xr.v[e] - xl.v[e])) * wq;
+          gy.v[e] += (0.5f * (yd.v[e] - yu.v[e])) * wq;
+        }
+      }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float d = f.v[e] - f1.v[e];
+      q.m11 = fmaf(gx.v[e], gx.v[e], q.m11);
+      q.m12 = fmaf(gx.v[e], gy.v[e], q.m12);
+      q.m22 = fmaf(gy.v[e], gy.v[e], q.m22);
+      q.g1 = fmaf(gx.v[e], d, q.g1);
+      q.g2 = fmaf(gy.v[e], d, q.g2);
+      absd[ch][e] += fabsf(d);
+    }
+  }
+  return q;
+}
+
+// VEC/CH: channels per lane / channel chunks (C <= 64*VEC*CH); GRAD: target is the 3C [f|gx|gy]
+// map; KVEC/KCH: basis coefficients per lane / chunks (K <= 64*KVEC*KCH), KCH = 0: no basis.
+template <int VEC, int CH, bool GRAD, int KVEC, int KCH>
+__global__ __launch_bounds__(kBlock, BANET_GATHER_WAVES) void ba_gather_kernel(const GatherArgs a) {
+  __shared__ float sH[kNumWaves][28][64];   // per-wave, per-lane accumulators of H_cc / Atb_c / nvalid
+  __shared__ float sAbs[kNumWaves][256];
+  const banet_level_t& lv = a.lv;
+  const int b = blockIdx.y, g = blockIdx.x;
+  if (a.active != nullptr && a.active[(size_t)b * a.active_stride] == 0) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = wave_id();
+  const int N = lv.N, C = lv.C, K = lv.K, H = lv.H, W = lv.W;
+  const int Ct = GRAD ? 3 * C : C;
+  const bool dense = lv.dense != 0;
+  const int dbg = lv.reserved_;  // profiling ablation bits (tools/prof_assemble.py); 0 in production
+  const float* __restrict__ tgt_b = lv.tgt + (size_t)b * H * W * Ct;
+  const float* __restrict__ src_b = lv.src + (size_t)b * N * C;
+  const float* __restrict__ dep_b = lv.depth + (size_t)b * N;
+  const float* __restrict__ bas_b = KCH ? lv.basis + (size_t)b * N * K : nullptr;
+  float* __restrict__ rec_b = KCH ? a.rec + (size_t)b * N * 8 : nullptr;
+
+#pragma unroll
+  for (int i = 0; i < 28; ++i) sH[w][i][lane] = 0.f;
+#ifdef BANET_TIMING
+  float tim0 = 0.f, tim1 = 0.f, tim2 = 0.f, tim3 = 0.f;
+#endif
+  float absd[CH][VEC];
+#pragma unroll
+  for (int i = 0; i < CH; ++i)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) absd[i][e] = 0.f;
+
+  // this lane's share of the coefficient vector W
+  float wreg[KCH ? KCH : 1][KVEC];
+  if constexpr (KCH > 0) {
+#pragma unroll
+    for (int kc = 0; kc < KCH; ++kc)
+#pragma unroll
+      for (int e = 0; e < KVEC; ++e) {
+        const int k = (kc * 64 + lane) * KVEC + e;
+        wreg[kc][e] = (k < K) ? a.Wc[(size_t)b * K + k] : 0.f;
+      }
+  }
+
+  // schedule: groups of 4 consecutive tiles (one per wave); groups are dealt to workgroups in 8
+  // XCD bands when the grid allows it, so that a band's tiles share L2
+  int s_begin, s_end, s_step;
+  if ((a.G & 7) == 0) {
+    const int x = g & 7, s = g >> 3, per = a.G >> 3;
+    s_begin = (int)(((long long)a.groups * x) >> 3) + s;
+    s_end = (int)(((long long)a.groups * (x + 1)) >> 3);
+    s_step = per;
+  } else {
+    s_begin = g;
+    s_end = a.groups;
+    s_step = a.G;
+  }
+
+  for (int sg = s_begin; sg < s_end; sg += s_step) {
+    const int t = sg * 4 + w;
+    if (t >= a.tiles) continue;  // wave-uniform
+    int tx = 0, ty = 0;
+    if (dense) tile_coords(t, a.tiles_x, a.tiles_y, tx, ty);
+    auto point_of = [&](int n, bool& valid) -> int {  // n uniform or per lane
+      if (dense) {
+        int qx, qy;
+        patch_pos(n, qx, qy);
+        const int py = (ty << 3) + qy, px = (tx << 3) + qx;
+        valid = (py < H) && (px < W);
+        return valid ? py * W + px : 0;
+      }
+      const int pt = t * kTilePix + n;
+      valid = pt < N;
+      return valid ? pt : 0;
+    };
+    bool valid;
+    const int pt = point_of(lane, valid);
+    BANET_TICK(tb0);
+
+    // ---- 1. depth: D_j = D0_j + b_j . W ---------------------------------------------
+    float D = valid ? dep_b[pt] : 0.f;
+    if constexpr (KCH > 0) {
+      float pend[6], dsum = 0.f;
+      for (int q8 = 0; q8 < ((dbg & 4) ? 0 : 8); ++q8) {
+        float part[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          bool vj;
+          const int ptj = point_of(brev6(q8 * 8 + i), vj);
+          const float* row = bas_b + (size_t)ptj * K;
+          float acc = 0.f;
+#pragma unroll
+          for (int kc = 0; kc < KCH; ++kc) {
+            const int k = (kc * 64 + lane) * KVEC;
+            const Vec<KVEC> bv = ldv<KVEC>(row, k, k < K);
+#pragma unroll
+            for (int e = 0; e < KVEC; ++e) acc = fmaf(bv.v[e], wreg[kc][e], acc);
+          }
+          part[i] = acc;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) carry_push(pend, part[i], q8 * 8 + i, dsum);
+      }
+      D += dsum;
+    }
+
+#ifdef BANET_TIMING
+    asm volatile("" ::"v"(D));
+#endif
+    BANET_TICK(tb1);
+    BANET_TACC(tim2, tb0, tb1);
+    // ---- 2. geometry, lane = pixel ----------------------------------------------------
+    float gw00 = 0.f, gw01 = 0.f, gw10 = 0.f, gw11 = 0.f, jd0 = 0.f, jd1 = 0.f;
+    float jc[12];
+    int gx0 = 1, gy0 = 1, gflags = 0, sx0 = 1, sy0 = 1;
+    float smk = 0.f;
+    {
+      float p0 = 0.f, p1 = 0.f, p2 = 1.f, fx = 1.f, fy = 1.f, ox = 0.f, oy = 0.f;
+      if (valid) {
+        if (dense) {
+          const float fx0 = lv.intr[b * 4 + 0], fy0 = lv.intr[b * 4 + 1], ox0 = lv.intr[b * 4 + 2],
+                      oy0 = lv.intr[b * 4 + 3];
+          const int py = pt / W, px = pt - py * W;
+          p0 = ((float)px * lv.scale - ox0) / fx0;
+          p1 = ((float)py * lv.scale - oy0) / fy0;
+          p2 = 1.f;
+          if (lv.normalize_rays) {
+            const float ss = p0 * p0 + p1 * p1 + p2 * p2;
+            const float inv = 1.f / sqrtf(fmaxf(ss, 1e-12f));
+            p0 *= inv;
+            p1 *= inv;
+            p2 *= inv;
+          }
+          fx = fx0 / lv.scale;
+          fy = fy0 / lv.scale;
+          ox = ox0 / lv.scale;
+          oy = oy0 / lv.scale;
+        } else {
+          const size_t o = (size_t)b * 3 * N;
+          p0 = lv.rays[o + pt];
+          p1 = lv.rays[o + N + pt];
+          p2 = lv.rays[o + 2 * (size_t)N + pt];
+          const size_t q = (size_t)b * N + pt;
+          fx = lv.fx[q];
+          fy = lv.fy[q];
+          ox = lv.ox[q];
+          oy = lv.oy[q];
+        }
+      }
+      const float* Rm = a.R + b * 9;
+      const float* Tv = a.T + b * 3;
+      const float rx = Rm[0] * p0 + Rm[1] * p1 + Rm[2] * p2;
+      const float ry = Rm[3] * p0 + Rm[4] * p1 + Rm[5] * p2;
+      const float rz = Rm[6] * p0 + Rm[7] * p1 + Rm[8] * p2;
+      const float X = rx * D + Tv[0], Y = ry * D + Tv[1], Z = rz * D + Tv[2];
+      const float x = X / Z, y = Y / Z;
+      const float pxl = fx * x + ox, pyl = fy * y + oy;
+      const bool m = valid && (pxl >= 0.f) && (pxl <= (float)(W - 1)) && (pyl >= 0.f) && (pyl <= (float)(H - 1));
+#pragma unroll
+      for (int i = 0; i < 12; ++i) jc[i] = 0.f;
+      int x0 = 0, y0 = 0;
+      if (m) {
+        const float xf = floorf(pxl), yf = floorf(pyl);
+        const float dx = pxl - xf, dy = pyl - yf;
+        x0 = (int)xf;
+        y0 = (int)yf;
+        gw00 = (1.f - dx) * (1.f - dy);
+        gw01 = dx * (1.f - dy);
+        gw10 = (1.f - dx) * dy;
+        gw11 = dx * dy;
+        const float iz = 1.f / Z;
+        jc[0] = fx * (x * y);
+        jc[1] = fx * (-1.f - x * x);
+        jc[2] = fx * y;
+        jc[3] = fx * (-iz);
+        jc[4] = 0.f;
+        jc[5] = fx * (x / Z);
+        jc[6] = fy * (1.f + y * y);
+        jc[7] = fy * (-(x * y));
+        jc[8] = fy * (-x);
+        jc[9] = 0.f;
+        jc[10] = fy * (-iz);
+        jc[11] = fy * (y / Z);
+        jd0 = fx * ((rx - rz * x) / Z);
+        jd1 = fy * ((ry - rz * y) / Z);
+      }
+      // fast path: 3C map (taps clamped one by one) or interior stencil; rim pixels of the
+      // on-the-fly gradient go to the slow path and look masked to the main loop
+      const bool interior = (x0 >= 1) && (x0 + 2 <= W - 1) && (y0 >= 1) && (y0 + 2 <= H - 1);
+      const bool fast = m && (GRAD || interior);
+      gflags = (m ? 1 : 0) | (fast ? 2 : 0) | ((m && !fast) ? 4 : 0);
+      gx0 = x0;
+      gy0 = y0;
+      sx0 = fast ? x0 : 1;
+      sy0 = fast ? y0 : 1;
+      smk = fast ? 1.f : 0.f;
+    }
+
+    // ---- 3. gather: pixel j's scalars from lane j, rows as coalesced 512-B loads -----------
+    auto pixel_q5 = [&](int j) __attribute__((always_inline)) -> Q5 {
+      Q5 q{0.f, 0.f, 0.f, 0.f, 0.f};
+      const int x0 = (dbg & 1) ? 1 : rdl(sx0, j), y0 = (dbg & 1) ? 1 : rdl(sy0, j);  // safe interior texel when not on the fast path
+      const float mk = rdl(smk, j);
+      const float w00 = mk * rdl(gw00, j), w01 = mk * rdl(gw01, j), w10 = mk * rdl(gw10, j), w11 = mk * rdl(gw11, j);
+      const int ptj = rdl(pt, j);
+      const float* __restrict__ srow = src_b + (size_t)ptj * C;
+#pragma unroll
+      for (int ch = 0; ch < CH; ++ch) {
+        const int c = (ch * 64 + lane) * VEC;
+        const bool ok = c < C;
+        const Vec<VEC> f1 = ldv<VEC>(srow, c, ok);
+        Vec<VEC> f, gx, gy;
+        if constexpr (GRAD) {
+          const int x0c = min(max(x0, 0), W - 1), x1c = min(max(x0 + 1, 0), W - 1);
+          const int y0c = min(max(y0, 0), H - 1), y1c = min(max(y0 + 1, 0), H - 1);
+          const float* r00 = tgt_b + (size_t)(y0c * W + x0c) * Ct;
+          const float* r01 = tgt_b + (size_t)(y0c * W + x1c) * Ct;
+          const float* r10 = tgt_b + (size_t)(y1c * W + x0c) * Ct;
+          const float* r11 = tgt_b + (size_t)(y1c * W + x1c) * Ct;
+          const Vec<VEC> a00 = ldv<VEC>(r00, c, ok), a01 = ldv<VEC>(r01, c, ok), a10 = ldv<VEC>(r10, c, ok), a11 = ldv<VEC>(r11, c, ok);
+          const Vec<VEC> b00 = ldv<VEC>(r00 + C, c, ok), b01 = ldv<VEC>(r01 + C, c, ok), b10 = ldv<VEC>(r10 + C, c, ok), b11 = ldv<VEC>(r11 + C, c, ok);
+          const Vec<VEC> c00 = ldv<VEC>(r00 + 2 * C, c, ok), c01 = ldv<VEC>(r01 + 2 * C, c, ok), c10 = ldv<VEC>(r10 + 2 * C, c, ok), c11 = ldv<VEC>(r11 + 2 * C, c, ok);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            f.v[e] = ((a00.v[e] * w00 + a01.v[e] * w01) + a10.v[e] * w10) + a11.v[e] * w11;
+            gx.v[e] = ((b00.v[e] * w00 + b01.v[e] * w01) + b10.v[e] * w10) + b11.v[e] * w11;
+            gy.v[e] = ((c00.v[e] * w00 + c01.v[e] * w01) + c10.v[e] * w10) + c11.v[e] * w11;
+          }
+        } else {
+          // the 4 taps and their +-1 neighbours are 12 distinct texels (interior stencil)
+          const float* ra = tgt_b + (size_t)(y0 * W + x0) * C;      // row y0, col x0
+          const float* rb = ra + (size_t)W * C;                     // row y0+1
+          const float* rm = ra - (size_t)W * C;                     // row y0-1
+          const float* rp = rb + (size_t)W * C;                     // row y0+2
+          const Vec<VEC> a0 = ldv<VEC>(ra - C, c, ok), a1 = ldv<VEC>(ra, c, ok), a2 = ldv<VEC>(ra + C, c, ok), a3 = ldv<VEC>(ra + 2 * C, c, ok);
+          const Vec<VEC> b0 = ldv<VEC>(rb - C, c, ok), b1 = ldv<VEC>(rb, c, ok), b2 = ldv<VEC>(rb + C, c, ok), b3 = ldv<VEC>(rb + 2 * C, c, ok);
+          const Vec<VEC> m1 = ldv<VEC>(rm, c, ok), m2 = ldv<VEC>(rm + C, c, ok);
+          const Vec<VEC> p1 = ldv<VEC>(rp, c, ok), p2 = ldv<VEC>(rp + C, c, ok);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            f.v[e] = ((a1.v[e] * w00 + a2.v[e] * w01) + b1.v[e] * w10) + b2.v[e] * w11;
+            const float gx00 = 0.5f * (a2.v[e] - a0.v[e]), gx01 = 0.5f * (a3.v[e] - a1.v[e]);
+            const float gx10 = 0.5f * (b2.v[e] - b0.v[e]), gx11 = 0.5f * (b3.v[e] - b1.v[e]);
+            gx.v[e] = ((gx00 * w00 + gx01 * w01) + gx10 * w10) + gx11 * w11;
+            const float gy00 = 0.5f * (b1.v[e] - m1.v[e]), gy01 = 0.5f * (b2.v[e] - m2.v[e]);
+            const float gy10 = 0.5f * (p1.v[e] - a1.v[e]), gy11 = 0.5f * (p2.v[e] - a2.v[e]);
+            gy.v[e] = ((gy00 * w00 + gy01 * w01) + gy10 * w10) + gy11 * w11;
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float d = mk * (f.v[e] - f1.v[e]);
+          q.m11 = fmaf(gx.v[e], gx.v[e], q.m11);
+          q.m12 = fmaf(gx.v[e], gy.v[e], q.m12);
+          q.m22 = fmaf(gy.v[e], gy.v[e], q.m22);
+          q.g1 = fmaf(gx.v[e], d, q.g1);
+          q.g2 = fmaf(gy.v[e], d, q.g2);
+          absd[ch][e] += fabsf(d);
+        }
+      }
+      return q;
+    };
+
+    Q5 q{0.f, 0.f, 0.f, 0.f, 0.f};
+    {
+      Q5 pend[6];
+      for (int tt = 0; tt < ((dbg & 8) ? 0 : 64); tt += 2) {
+        const int j0 = brev6(tt);          // leaf tt+1 is pixel j0 + 32
+        BANET_TICK(t0);
+        const Q5 qa = pixel_q5(j0);
+        const Q5 qb = pixel_q5(j0 + 32);
+#ifdef BANET_TIMING
+        asm volatile("" ::"v"(qa.m11), "v"(qb.m11), "v"(qa.g2), "v"(qb.g2));
+#endif
+        BANET_TICK(t1);
+        BANET_TACC(tim0, t0, t1);
+        Q5 m1 = q5_merge(qa, qb, 32);      // level 0
+        // levels 1..5 of the carry chain on leaf-pair index tt/2
+        const int tp = tt >> 1;
+        bool done = false;
+#pragma unroll
+        for (int L = 1; L < 6; ++L) {
+          if (!done) {
+            if (((tp >> (L - 1)) & 1) == 0) {
+              pend[L] = m1;
+              done = true;
+            } else {
+              m1 = q5_merge(pend[L], m1, 32 >> L);
+            }
+          }
+        }
+        if (!done) q = m1;
+#ifdef BANET_TIMING
+        asm volatile("" ::"v"(m1.m11), "v"(m1.g2));
+#endif
+        BANET_TICK(t2);
+        BANET_TACC(tim1, t1, t2);
+      }
+    }
+    if constexpr (!GRAD) {
+      // patch the pixels whose stencil touches the image rim (rare)
+      unsigned long long slow = __ballot((gflags & 4) != 0);
+      while (slow) {  // wave-uniform
+        const int j = __builtin_ctzll(slow);
+        slow &= slow - 1;
+        Q5 e = border_pixel_q5<VEC, CH>(rdl(gx0, j), rdl(gy0, j), rdl(gw00, j), rdl(gw01, j), rdl(gw10, j),
+                                        rdl(gw11, j), src_b + (size_t)rdl(pt, j) * C, tgt_b, C, H, W, lane, absd);
+        e.m11 = wave_sum(e.m11);
+        e.m12 = wave_sum(e.m12);
+        e.m22 = wave_sum(e.m22);
+        e.g1 = wave_sum(e.g1);
+        e.g2 = wave_sum(e.g2);
+        if (lane == j) {
+          q.m11 += e.m11;
+          q.m12 += e.m12;
+          q.m22 += e.m22;
+          q.g1 += e.g1;
+          q.g2 += e.g2;
+        }
+      }
+    }
+
+    // ---- 4. per-pixel 6x6 algebra, lane = pixel ---------------------------------------
+    {
+      float mj[12];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        mj[i] = q.m11 * jc[i] + q.m12 * jc[6 + i];
+        mj[6 + i] = q.m12 * jc[i] + q.m22 * jc[6 + i];
+      }
+      int o = 0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) {
+          atomicAdd(&sH[w][o][lane], jc[i] * mj[j] + jc[6 + i] * mj[6 + j]);
+          ++o;
+        }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) atomicAdd(&sH[w][21 + i][lane], jc[i] * q.g1 + jc[6 + i] * q.g2);
+      atomicAdd(&sH[w][27][lane], (float)(gflags & 1));
+      if constexpr (KCH > 0) {
+        if (valid) {
+          const float md0 = q.m11 * jd0 + q.m12 * jd1, md1 = q.m12 * jd0 + q.m22 * jd1;
+          float4 ua, ub;
+          ua.x = jc[0] * md0 + jc[6] * md1;
+          ua.y = jc[1] * md0 + jc[7] * md1;
+          ua.z = jc[2] * md0 + jc[8] * md1;
+          ua.w = jc[3] * md0 + jc[9] * md1;
+          ub.x = jc[4] * md0 + jc[10] * md1;
+          ub.y = jc[5] * md0 + jc[11] * md1;
+          ub.z = jd0 * md0 + jd1 * md1;    // s_n
+          ub.w = jd0 * q.g1 + jd1 * q.g2;  // r_n
+          float4* rp = reinterpret_cast<float4*>(rec_b + (size_t)pt * 8);
+          rp[0] = ua;
+          rp[1] = ub;
+        }
+      }
+    }
+    BANET_TICK(tb9);
+    BANET_TACC(tim3, tb0, tb9);
+  }  // tiles
+#ifdef BANET_TIMING
+  if (tid == 0) {
+    float* dp = a.partials + ((size_t)b * a.G + g) * (kGHdr + C);
+    dp[28] = tim0;  // cycles: two pixels' loads + channel math
+    dp[29] = tim1;  // cycles: butterfly merges
+    dp[30] = tim2;  // cycles: depth dot
+    dp[31] = tim3;  // cycles: whole batch
+  }
+#endif
+
+  // ---- epilogue: one small partial per workgroup -------------------------------------------
+#pragma unroll
+  for (int ch = 0; ch < CH; ++ch)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int c = (ch * 64 + lane) * VEC + e;
+      if (c < C) sAbs[w][c] = absd[ch][e];
+    }
+  __syncthreads();
+  float* __restrict__ part = a.partials + ((size_t)b * a.G + g) * (kGHdr + C);
+  if (tid < 4 * 28) {
+    const int ww = tid / 28, i = tid - ww * 28;
+    float s = 0.f;
+    for (int l = 0; l < 64; ++l) s += sH[ww][i][l];
+    sH[ww][i][0] = s;
+  }
+  __syncthreads();
+  if (tid < 28) part[tid] = (sH[0][tid][0] + sH[1][tid][0]) + (sH[2][tid][0] + sH[3][tid][0]);
+  for (int c = tid; c < C; c += kBlock) part[kGHdr + c] = (sAbs[0][c] + sAbs[1][c]) + (sAbs[2][c] + sAbs[3][c]);
+}
+
+// --------------------------------------------------------------------------------------
+// host side
+// --------------------------------------------------------------------------------------
+int plan_gather(const banet_level_t* lv, GatherPlan* pl) {
+  if (!lv || lv->B <= 0 || lv->N <= 0 || lv->C <= 0 || lv->K < 0 || lv->H < 4 || lv->W < 4) return BANET_ERR_INVALID_ARG;
+  if (lv->C > 256 || lv->K > 256) return BANET_ERR_UNSUPPORTED;
+  if (lv->dense && lv->N != lv->H * lv->W) return BANET_ERR_INVALID_ARG;
+  if (lv->dense) {
+    pl->tiles_x = (lv->W + 7) / 8;
+    pl->tiles_y = (lv->H + 7) / 8;
+    pl->tiles = pl->tiles_x * pl->tiles_y;
+  } else {
+    pl->tiles_x = pl->tiles_y = 0;
+    pl->tiles = (lv->N + kTilePix - 1) / kTilePix;
+  }
+  pl->groups = (pl->tiles + 3) / 4;
+  // ~4 resident workgroups per CU on 256 CUs, split across the windows; >= 2 groups each
+  int target = (1024 + lv->B - 1) / lv->B;
+  int G = pl->groups / 2;
+  if (G > target) G = target;
+  if (G < 1) G = 1;
+  if (G >= 8) G &= ~7;
+  pl->G = G;
+  pl->pstride = kGHdr + lv->C;
+  pl->partial_bytes = align_up((size_t)lv->B * G * pl->pstride * sizeof(float), 256);
+  pl->rec_bytes = lv->K > 0 ? align_up((size_t)lv->B * lv->N * 8 * sizeof(float), 256) : 0;
+  return BANET_OK;
+}
+
+template <int VEC, int CH, bool GRAD>
+static int launch_k(const GatherArgs& a, int K, hipStream_t s) {
+  dim3 grid(a.G, a.lv.B), block(kBlock);
+  const bool keven = (K & 1) == 0;
+  if (K == 0)
+    hipLaunchKernelGGL((ba_gather_kernel<VEC, CH, GRAD, 1, 0>), grid, block, 0, s, a);
+  else if (keven && K <= 128)
+    hipLaunchKernelGGL((ba_gather_kernel<VEC, CH, GRAD, 2, 1>), grid, block, 0, s, a);
+  else if (keven && K <= 256)
+    hipLaunchKernelGGL((ba_gather_kernel<VEC, CH, GRAD, 2, 2>), grid, block, 0, s, a);
+  else if (K <= 64)
+    hipLaunchKernelGGL((ba_gather_kernel<VEC, CH, GRAD, 1, 1>), grid, block, 0, s, a);
+  else if (K <= 128)
+    hipLaunchKernelGGL((ba_gather_kernel<VEC, CH, GRAD, 1, 2>), grid, block, 0, s, a);
+  else
+    return BANET_ERR_UNSUPPORTED;
+  return BANET_OK;
+}
+
+template <bool GRAD>
+static int launch_c(const GatherArgs& a, int C, int K, hipStream_t s) {
+  const bool even = (C & 1) == 0;
+  if (even && C <= 128) return launch_k<2, 1, GRAD>(a, K, s);
+  if (even && C <= 256) return launch_k<2, 2, GRAD>(a, K, s);
+  if (C <= 64) return launch_k<1, 1, GRAD>(a, K, s);
+  if (C <= 128) return launch_k<1, 2, GRAD>(a, K, s);
+  return BANET_ERR_UNSUPPORTED;
+}
+
+int launch_gather(const banet_level_t* lv, const GatherPlan& pl, const float* R, const float* T, const float* Wc,
+                  const int32_t* active, int active_stride, float* rec, float* partials, hipStream_t s) {
+  GatherArgs a;
+  a.lv = *lv;
+  a.R = R;
+  a.T = T;
+  a.Wc = Wc;
+  a.active = active;
+  a.active_stride = active_stride;
+  a.rec = rec;
+  a.partials = partials;
+  a.G = pl.G;
+  a.tiles = pl.tiles;
+  a.tiles_x = pl.tiles_x;
+  a.tiles_y = pl.tiles_y;
+  a.groups = pl.groups;
+  const int rc = lv->tgt_has_grad ? launch_c<true>(a, lv->C, lv->K, s) : launch_c<false>(a, lv->C, lv->K, s);
+  if (rc != BANET_OK) return rc;
+  return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;
+}
+
+}  // namespace banet

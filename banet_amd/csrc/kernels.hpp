@@ -4,23 +4,47 @@
 
 namespace banet {
 
-// ---- assemble.hip --------------------------------------------------------------------
-struct AsmPlan {
-  int G, tiles, tiles_x, tiles_y, P, pstride, nb;
+constexpr int kGHdr = 32;       // gather partial header: 21 H_cc + 6 Atb_c + nvalid (+pad), then C x sum|d|
+constexpr int kUStrideS = 8;    // per-pixel record: u0..u5, s, r
+
+// ---- gather.hip ------------------------------------------------------------------------
+struct GatherPlan {
+  int G, tiles, tiles_x, tiles_y, groups, pstride;
+  size_t partial_bytes, rec_bytes;
+};
+int plan_gather(const banet_level_t* lv, GatherPlan* pl);
+int launch_gather(const banet_level_t* lv, const GatherPlan& pl, const float* R, const float* T, const float* Wc,
+                  const int32_t* active, int active_stride, float* rec, float* partials, hipStream_t s);
+
+// ---- syrk.hip --------------------------------------------------------------------------
+struct SyrkPlan {
+  int Gs, tiles, pstride, nb;
   size_t partial_bytes;
+};
+int plan_syrk(int B, int N, int K, SyrkPlan* pl);
+int launch_syrk(const float* basis, const float* rec, int B, int N, int K, const SyrkPlan& pl, const int32_t* active,
+                int active_stride, float* partials, hipStream_t s);
+void launch_reduce2(const float* gpart, int Gg, int gstride, const float* spart, int Gs, int sstride,
+                    const int32_t* active, int active_stride, int B, int K, int C, float* AtA, float* Atb, float* absres,
+                    float* nvalid, hipStream_t s);
+
+// ---- assemble.hip: one assembly pass = gather + syrk + reduce ------------------------------
+struct AsmPlan {
+  GatherPlan g;
+  SyrkPlan s;
+  int P;
+  size_t ws_bytes;      // gather partials + records + syrk partials
+  size_t off_rec, off_spart;
 };
 int plan_assemble(const banet_level_t* lv, AsmPlan* pl);
 int launch_assemble(const banet_level_t* lv, const AsmPlan& pl, const float* R, const float* T, const float* Wc,
-                    const int32_t* active, int active_stride, float* partials, float* AtA, float* Atb, float* absres,
+                    const int32_t* active, int active_stride, void* ws, float* AtA, float* Atb, float* absres,
                     float* nvalid, hipStream_t s);
-void launch_reduce(const float* partials, const int32_t* active, int active_stride, int B, int G, int pstride, int P,
-                   int C, float* AtA, float* Atb, float* absres, float* nvalid, hipStream_t s);
-
-// optional launch timing (banet_profile_begin/_end)
 int profile_begin(int max_launches);
 int profile_end(int max_tags, int32_t* tag_points, int32_t* tag_launches, double* tag_ms, int32_t* ntags);
 
-// ---- eqcon.hip -----------------------------------------------------------------------
+// ---- eqcon.hip -------------------------------------------------------------------------
+void launch_reduce(const float* partials, int B, int G, int pstride, int P, float* AtA, float* Atb, hipStream_t s);
 struct EqPlan {
   int Gr, tiles, pstride, nb;
   size_t partial_bytes;
@@ -31,7 +55,7 @@ int launch_eq(const float* J, const float* G, const float* d, float* AtA, float*
 int launch_eq_grad(const float* J, const float* G, const float* d, const float* g0, const float* g1, float* gJ,
                    float* gG, float* gd, int B, int N, int C, int P, hipStream_t s);
 
-// ---- solve.hip -----------------------------------------------------------------------
+// ---- solve.hip -------------------------------------------------------------------------
 struct LmCtl {  // per-window loop state of the legacy early-termination LM (device memory)
   int32_t active;
   int32_t pending;

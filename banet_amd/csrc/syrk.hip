@@ -1,0 +1,333 @@
+// ba_syrk_kernel -- the depth-basis blocks of the normal equations on gfx950:
+//   H_dd = sum_n s_n b_n b_n^T   (K x K, fp32 MFMA v_mfma_f32_16x16x4_f32, upper 16x16 blocks)
+//   H_cd = sum_n u_n b_n^T       (6 x K, VALU rank-1 updates)
+//   Atb_d = sum_n r_n b_n        (K)
+// from the basis [N,K] (streamed once, 64-pixel tiles = 32 KB contiguous at K=128) and the
+// per-pixel records (u,s,r) written by ba_gather_kernel.  This is the part of
+// EquationConstruction (utils.cu:331-414) that involves J's depth columns jd (x) b_n
+// (bundlenet.py:260-261), never materialised here.
+// Pipeline: registers <- tile t+1 (global loads issued before the MFMA phase of tile t),
+// LDS double buffer, one barrier per tile.  Wave w owns block rows w and NB-1-w of the upper
+// triangle (NB+1 blocks: balanced); accumulators stay in registers for the whole kernel.
+#include "kernels.hpp"
+
+namespace banet {
+
+struct SyrkArgs {
+  const float* basis;  // [B][N][K]
+  const float* rec;    // [B][N][8]
+  const int32_t* active;
+  int active_stride;
+  float* partials;     // [B][Gs][7K + K*K]
+  int N, K, Gs, tiles, pstride;
+};
+
+template <int NB>
+__global__ __launch_bounds__(kBlock, 2) void ba_syrk_kernel(const SyrkArgs a) {
+  constexpr int KPAD = NB * 16;
+  constexpr int KP = KPAD + 16;         // row stride: bank shift 16 per row -> conflict-free MFMA operand reads
+  constexpr int KV = KPAD >= 64 ? KPAD / 64 : 1;
+  constexpr int QPR = KPAD / 4;         // float4 per row
+  constexpr int QT = (kTilePix * QPR + kBlock - 1) / kBlock;  // float4 per thread per tile
+  constexpr int NSLOT = NB + 1;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sB0 = smem;                          // [2][64][KP]
+  float* sU0 = smem + 2 * kTilePix * KP;      // [2][64][8]
+  const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  if (a.active != nullptr && a.active[(size_t)b * a.active_stride] == 0) return;
+  const int w = wave_id();
+  const int N = a.N, K = a.K;
+  const float* __restrict__ bas_b = a.basis + (size_t)b * N * K;
+  const float* __restrict__ rec_b = a.rec + (size_t)b * N * 8;
+  const bool k4 = (K & 3) == 0;
+
+  float hcd[7][KV];
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int e = 0; e < KV; ++e) hcd[i][e] = 0.f;
+  f32x4 acc[NSLOT];
+#pragma unroll
+  for (int q = 0; q < NSLOT; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int npairs = (NB + 1) / 2;
+  const int i1 = w, i2 = NB - 1 - w;
+  const bool mf_on = w < npairs;
+  const int n1 = NB - i1;
+  const int nslots = (i2 != i1) ? NB + 1 : n1;
+
+  float4 pre[QT];
+  float4 preu = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load_tile = [&](int t) {
+    const int pt0 = t * kTilePix;
+#pragma unroll
+    for (int i = 0; i < QT; ++i) {
+      const int idx = tid + i * kBlock;
+      const int n = idx / QPR, q = idx - n * QPR;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < kTilePix * QPR && pt0 + n < N) {
+        const float* p = bas_b + (size_t)(pt0 + n) * K + 4 * q;
+        if (k4) {
+          if (4 * q < K) v = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (4 * q + 0 < K) v.x = p[0];
+          if (4 * q + 1 < K) v.y = p[1];
+          if (4 * q + 2 < K) v.z = p[2];
+          if (4 * q + 3 < K) v.w = p[3];
+        }
+      }
+      pre[i] = v;
+    }
+    preu = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 2 * kTilePix) {
+      const int n = tid >> 1;
+      if (pt0 + n < N) preu = *reinterpret_cast<const float4*>(rec_b + (size_t)(pt0 + n) * 8 + 4 * (tid & 1));
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* sB = sB0 + buf * kTilePix * KP;
+    float* sU = sU0 + buf * kTilePix * kUStrideS;
+#pragma unroll
+    for (int i = 0; i < QT; ++i) {
+      const int idx = tid + i * kBlock;
+      const int n = idx / QPR, q = idx - n * QPR;
+      if (idx < kTilePix * QPR) *reinterpret_cast<float4*>(sB + n * KP + 4 * q) = pre[i];
+    }
+    if (tid < 2 * kTilePix) *reinterpret_cast<float4*>(sU + (tid >> 1) * kUStrideS + 4 * (tid & 1)) = preu;
+  };
+
+  int t = g;
+  int cur = 0;
+  if (t < a.tiles) {
+    load_tile(t);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (; t < a.tiles; t += a.Gs) {
+    const bool more = t + a.Gs < a.tiles;
+    if (more) load_tile(t + a.Gs);          // global loads in flight during the compute below
+    const float* sB = sB0 + cur * kTilePix * KP;
+    const float* sU = sU0 + cur * kTilePix * kUStrideS;
+    // ---- H_cd += u_n b_n^T, Atb_d += r_n b_n ;  lane = coefficient(s), wave w pixels 16w.. ----
+    {
+      const int kb = lane * KV;
+      if (kb < KPAD) {
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+          const int n = 16 * w + i;
+          const float4 ua = *reinterpret_cast<const float4*>(sU + n * kUStrideS);
+          const float4 ub = *reinterpret_cast<const float4*>(sU + n * kUStrideS + 4);
+#pragma unroll
+          for (int e = 0; e < KV; ++e) {
+            const float bv = sB[n * KP + kb + e];
+            hcd[0][e] = fmaf(ua.x, bv, hcd[0][e]);
+            hcd[1][e] = fmaf(ua.y, bv, hcd[1][e]);
+            hcd[2][e] = fmaf(ua.z, bv, hcd[2][e]);
+            hcd[3][e] = fmaf(ua.w, bv, hcd[3][e]);
+            hcd[4][e] = fmaf(ub.x, bv, hcd[4][e]);
+            hcd[5][e] = fmaf(ub.y, bv, hcd[5][e]);
+            hcd[6][e] = fmaf(ub.w, bv, hcd[6][e]);
+          }
+        }
+      }
+    }
+    // ---- H_dd += sum_n s_n b_n b_n^T on the matrix cores ---------------------------------
+    if (mf_on) {
+      const int col = lane & 15, kq = lane >> 4;
+#pragma unroll 2
+      for (int kk = 0; kk < kTilePix / 4; ++kk) {
+        const int pix = 4 * kk + kq;
+        const float* row = sB + pix * KP + col;
+        const float sv = sU[pix * kUStrideS + 6];
+        const float a1 = sv * row[16 * i1];
+        const float a2 = sv * row[16 * i2];
+#pragma unroll
+        for (int q = 0; q < NSLOT; ++q) {
+          if (q < nslots) {  // wave-uniform
+            const bool first = q < n1;
+            const float bj = row[16 * (first ? i1 + q : i2 + q - n1)];
+            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(first ? a1 : a2, bj, acc[q], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------
+  float* __restrict__ part = a.partials + ((size_t)b * a.Gs + g) * a.pstride;
+  float* sH = smem;  // [4][8][KPAD] overlays the tile buffers (all waves are past the last barrier)
+  {
+    const int kb = lane * KV;
+    if (kb < KPAD) {
+#pragma unroll
+      for (int i = 0; i < 7; ++i)
+#pragma unroll
+        for (int e = 0; e < KV; ++e) sH[(w * 8 + i) * KPAD + kb + e] = hcd[i][e];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < 7 * K; e += kBlock) {
+    const int i = e / K, k = e - i * K;
+    part[e] = (sH[(0 * 8 + i) * KPAD + k] + sH[(1 * 8 + i) * KPAD + k]) +
+              (sH[(2 * 8 + i) * KPAD + k] + sH[(3 * 8 + i) * KPAD + k]);
+  }
+  if (mf_on) {
+    float* pd = part + 7 * K;
+    const int col = lane & 15, rq = (lane >> 4) * 4;
+#pragma unroll
+    for (int q = 0; q < NSLOT; ++q) {
+      if (q < nslots) {
+        const bool first = q < n1;
+        const int bi = first ? i1 : i2, bj = first ? i1 + q : i2 + q - n1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rr = 16 * bi + rq + r, cc = 16 * bj + col;
+          if (rr < K && cc < K && (bj > bi || rr <= cc)) {
+            pd[rr * K + cc] = acc[q][r];
+            pd[cc * K + rr] = acc[q][r];
+          }
+        }
+      }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------
+// fixed-order reduction of the per-workgroup partials of both kernels into AtA / Atb / |r| / nvalid
+// (the deterministic counterpart of utils.cu:181-198 ColumnReduceSimpleKernel)
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ba_reduce2_kernel(const float* __restrict__ gpart, int Gg, int gstride,
+                                                         const float* __restrict__ spart, int Gs, int sstride,
+                                                         const int32_t* active, int active_stride, int K, int C,
+                                                         float* __restrict__ AtA, float* __restrict__ Atb,
+                                                         float* __restrict__ absres, float* __restrict__ nvalid) {
+  const int b = blockIdx.y;
+  if (active != nullptr && active[(size_t)b * active_stride] == 0) return;
+  const int P = 6 + K;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = P * P + P + C + 1;
+  if (e >= total) return;
+  // which partial set / offset / sign?
+  int off;
+  bool from_s = false;
+  float sign = 1.f;
+  if (e < P * P) {
+    const int i = e / P, j = e - i * P;
+    if (i < 6 && j < 6) {
+      const int lo = i < j ? i : j, hi = i < j ? j : i;
+      off = 6 * lo - lo * (lo - 1) / 2 + (hi - lo);
+    } else if (i < 6 || j < 6) {     // H_cd: bundle sign (J = [-Jc | jd b], bundlenet.py:60)
+      const int c = i < 6 ? i : j, k = (i < 6 ? j : i) - 6;
+      off = c * K + k;
+      from_s = true;
+      sign = -1.f;
+    } else {
+      off = 7 * K + (i - 6) * K + (j - 6);
+      from_s = true;
+    }
+  } else if (e < P * P + P) {
+    const int i = e - P * P;
+    if (i < 6) {
+      off = 21 + i;
+    } else {                         // Atb_d: d = F1 - F2w (bundlenet.py:234)
+      off = 6 * K + (i - 6);
+      from_s = true;
+      sign = -1.f;
+    }
+  } else if (e < P * P + P + C) {
+    off = kGHdr + (e - P * P - P);
+  } else {
+    off = 27;
+  }
+  const float* p = from_s ? spart + (size_t)b * Gs * sstride + off : gpart + (size_t)b * Gg * gstride + off;
+  const int n = from_s ? Gs : Gg;
+  const size_t st = from_s ? sstride : gstride;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int i = 0;
+  for (; i + 3 < n; i += 4) {
+    s0 += p[(size_t)(i + 0) * st];
+    s1 += p[(size_t)(i + 1) * st];
+    s2 += p[(size_t)(i + 2) * st];
+    s3 += p[(size_t)(i + 3) * st];
+  }
+  for (; i < n; ++i) s0 += p[(size_t)i * st];
+  const float v = sign * ((s0 + s1) + (s2 + s3));
+  if (e < P * P)
+    AtA[(size_t)b * P * P + e] = v;
+  else if (e < P * P + P)
+    Atb[(size_t)b * P + (e - P * P)] = v;
+  else if (e < P * P + P + C)
+    absres[(size_t)b * C + (e - P * P - P)] = v;
+  else
+    nvalid[b] = v;
+}
+
+// --------------------------------------------------------------------------------------
+// host side
+// --------------------------------------------------------------------------------------
+static int nb_for_k(int K) {
+  if (K <= 0) return 0;
+  if (K <= 16) return 1;
+  if (K <= 32) return 2;
+  if (K <= 64) return 4;
+  if (K <= 128) return 8;
+  return -1;
+}
+
+int plan_syrk(int B, int N, int K, SyrkPlan* pl) {
+  pl->nb = nb_for_k(K);
+  if (pl->nb < 0) return BANET_ERR_UNSUPPORTED;
+  if (K == 0) {
+    pl->Gs = 0;
+    pl->tiles = 0;
+    pl->pstride = 0;
+    pl->partial_bytes = 0;
+    return BANET_OK;
+  }
+  pl->tiles = (N + kTilePix - 1) / kTilePix;
+  int target = (512 + B - 1) / B;   // 2 resident workgroups per CU
+  int G = pl->tiles / 4;
+  if (G > target) G = target;
+  if (G < 1) G = 1;
+  pl->Gs = G;
+  pl->pstride = (int)align_up((size_t)7 * K + (size_t)K * K, 4);
+  pl->partial_bytes = align_up((size_t)B * G * pl->pstride * sizeof(float), 256);
+  return BANET_OK;
+}
+
+template <int NB>
+static void launch_syrk_nb(const SyrkArgs& a, int B, hipStream_t s) {
+  constexpr int KPAD = NB * 16, KP = KPAD + 16;
+  size_t fl = (size_t)2 * kTilePix * KP + 2 * kTilePix * kUStrideS;
+  const size_t epi = (size_t)4 * 8 * KPAD;
+  if (fl < epi) fl = epi;
+  const size_t lds = fl * sizeof(float);
+  auto k = ba_syrk_kernel<NB>;
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k, dim3(a.Gs, B), dim3(kBlock), lds, s, a);
+}
+
+int launch_syrk(const float* basis, const float* rec, int B, int N, int K, const SyrkPlan& pl, const int32_t* active,
+                int active_stride, float* partials, hipStream_t s) {
+  SyrkArgs a{basis, rec, active, active_stride, partials, N, K, pl.Gs, pl.tiles, pl.pstride};
+  switch (pl.nb) {
+    case 1: launch_syrk_nb<1>(a, B, s); break;
+    case 2: launch_syrk_nb<2>(a, B, s); break;
+    case 4: launch_syrk_nb<4>(a, B, s); break;
+    case 8: launch_syrk_nb<8>(a, B, s); break;
+    default: return BANET_ERR_UNSUPPORTED;
+  }
+  return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;
+}
+
+void launch_reduce2(const float* gpart, int Gg, int gstride, const float* spart, int Gs, int sstride,
+                    const int32_t* active, int active_stride, int B, int K, int C, float* AtA, float* Atb, float* absres,
+                    float* nvalid, hipStream_t s) {
+  const int P = 6 + K, total = P * P + P + C + 1;
+  hipLaunchKernelGGL(ba_reduce2_kernel, dim3((total + 255) / 256, B), dim3(256), 0, s, gpart, Gg, gstride, spart, Gs,
+                     sstride, active, active_stride, K, C, AtA, Atb, absres, nvalid);
+}
+
+}  // namespace banet

@@ -22,15 +22,12 @@ R = torch.eye(3, device=dev).repeat(B, 1, 1)
 T = (gt["T"] * 0.7).reshape(B, 3, 1).to(dev)
 Wc = torch.zeros(B, max(K, 1), 1, device=dev)[:, :K]
 byts = ba.algorithmic_bytes_per_iteration(0) * B
-cases = [(0, "full"), (1, "no rim patch"), (2, "no H_cd"), (16, "no MFMA"), (18, "no H_cd, no MFMA"), (4, "no gather"),
-         (4 | 2 | 16, "no gather/H_cd/MFMA"), (4 | 2 | 16 | 8, "geometry + sync only")]
-for bits, name in cases:
-    if only is not None and int(only) != bits:
-        continue
+for bits, name in ((0, "full"), (1, "all taps -> texel(1,1)"), (4, "no depth dot"), (8, "no gather loop"), (12, "geometry only")):
     p.c.reserved_ = bits
     for _ in range(2):
         ops.ba_assemble(p, R, T, Wc if K else None)
     torch.cuda.synchronize()
+    ops.profile_begin(64)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n = 5
     e0.record()
@@ -38,5 +35,8 @@ for bits, name in cases:
         ops.ba_assemble(p, R, T, Wc if K else None)
     e1.record()
     torch.cuda.synchronize()
+    prof = ops.profile_end()
     ms = e0.elapsed_time(e1) / n
-    print("%-28s bits=%2d  %8.1f us/launch  %7.1f us/window  %7.1f GB/s" % (name, bits, ms * 1e3, ms * 1e3 / B, byts / ms / 1e6))
+    print("K=%d B=%d %-6s %8.1f us/launch  %7.1f us/window  %7.1f GB/s   kernels: %s" % (
+        K, B, name, ms * 1e3, ms * 1e3 / B, byts / ms / 1e6,
+        {("gather" if k > 0 else "syrk"): round(1e3 * v[1] / v[0] / B, 1) for k, v in prof.items()}))
