@@ -8,9 +8,26 @@
 //   update                       bundlenet.py:185-190,269-276 ; legacy/ba.py:208-213,295-302
 //   accept / terminate           legacy/ba.py:132-140,304-345
 // The matrix lives in LDS (P <= 134 -> 72 KB of the 160 KB per CU).
+#include <type_traits>
+
 #include "kernels.hpp"
 
 namespace banet {
+
+#ifdef BANET_TIMING
+__device__ __forceinline__ unsigned long long stick() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define STICK(v) const unsigned long long v = stick()
+#else
+#define STICK(v)
+#endif
+
+constexpr int kSolveThreads = 1024;   // 16 waves: 4 per SIMD, so the latency-bound phases overlap
+constexpr int kSolveWaves = kSolveThreads / 64;
+constexpr int kGrid = 32;              // 2-D cyclic thread grid of the register-resident solvers
 
 constexpr float kSeluAlpha = 1.6732632423543772848170429916717f;
 constexpr float kSeluScale = 1.0507009873554804934193349852946f;
@@ -28,16 +45,85 @@ __device__ float block_sum(float v, float* sred) {
   __syncthreads();
   if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = v;
   __syncthreads();
-  const float r = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+  float r = 0.f;
+#pragma unroll
+  for (int i = 0; i < kSolveWaves; ++i) r += sred[i];
   return r;
 }
 
-// one k=1 conv layer: out[o] = act(sum_i in[i] W[i][o] + b[o]);  act: 0 selu, 1 tanh
+// sum over the 64 lanes without the LDS crossbar; every lane gets the total
+__device__ __forceinline__ float wave_sum_fast(float v) {
+  v = row16_sum(v);
+  v = bfly_merge(v, v, 16);
+  return bfly_merge(v, v, 32);
+}
+
+// max / min over the 64 lanes on DPP + permlane swaps (every lane gets the result)
+__device__ __forceinline__ float wave_max_fast(float v) {
+  v = fmaxf(v, dpp_mov<kDppRor8>(v));
+  v = fmaxf(v, dpp_mov<kDppHalfMirror>(v));
+  v = fmaxf(v, dpp_mov<kDppXor2>(v));
+  v = fmaxf(v, dpp_mov<kDppXor1>(v));
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  v = fmaxf(a, b);
+  a = v;
+  b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ int wave_min_fast(int v) {
+  auto dpp = [](int x, auto ctrl) { return __builtin_amdgcn_update_dpp(0x7fffffff, x, decltype(ctrl)::value, 0xF, 0xF, false); };
+  v = min(v, dpp(v, std::integral_constant<int, kDppRor8>{}));
+  v = min(v, dpp(v, std::integral_constant<int, kDppHalfMirror>{}));
+  v = min(v, dpp(v, std::integral_constant<int, kDppXor2>{}));
+  v = min(v, dpp(v, std::integral_constant<int, kDppXor1>{}));
+  int a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  v = min(a, b);
+  a = v;
+  b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return min(a, b);
+}
+
+// one k=1 conv layer: out[o] = act(sum_i in[i] W[i][o] + b[o]);  act: 0 selu, 1 tanh.
+// Output quads x input slices over the 256 threads: 16-byte weight loads, 8 in flight per thread,
+// partial sums combined in fixed order through LDS (sPart: >= 1024 floats).
 __device__ void mlp_layer(const float* in, float* out, const float* __restrict__ Wt, const float* __restrict__ bias,
-                          int nin, int nout, int act, float* sred) {
+                          int nin, int nout, int act, float* sPart, float* sred) {
   const int tid = threadIdx.x;
-  if (nout >= 64) {
-    for (int o = tid; o < nout; o += kBlock) {
+  const int groups = nout >> 2;
+  if ((nout & 3) == 0 && groups <= kSolveThreads && ((reinterpret_cast<uintptr_t>(Wt) & 15) == 0)) {
+    int ksplit = kSolveThreads / groups;
+    if (ksplit > nin) ksplit = nin;
+    const int q = tid % groups, sl = tid / groups;
+    if (sl < ksplit) {
+      const int chunk = (nin + ksplit - 1) / ksplit;
+      const int i0 = sl * chunk, i1 = min(nin, i0 + chunk);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float* wp = Wt + 4 * q;
+#pragma unroll 8
+      for (int i = i0; i < i1; ++i) {
+        const float4 w4 = *reinterpret_cast<const float4*>(wp + (size_t)i * nout);
+        const float xv = in[i];
+        acc.x = fmaf(xv, w4.x, acc.x);
+        acc.y = fmaf(xv, w4.y, acc.y);
+        acc.z = fmaf(xv, w4.z, acc.z);
+        acc.w = fmaf(xv, w4.w, acc.w);
+      }
+      *reinterpret_cast<float4*>(sPart + sl * nout + 4 * q) = acc;
+    }
+    __syncthreads();
+    for (int o = tid; o < nout; o += kSolveThreads) {
+      float v = 0.f;
+      for (int k = 0; k < ksplit; ++k) v += sPart[k * nout + o];
+      v += bias[o];
+      out[o] = act == 0 ? selu(v) : tanhf(v);
+    }
+    __syncthreads();
+  } else if (nout >= 64) {
+    for (int o = tid; o < nout; o += kSolveThreads) {
       float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
       int i = 0;
       for (; i + 3 < nin; i += 4) {
@@ -54,7 +140,7 @@ __device__ void mlp_layer(const float* in, float* out, const float* __restrict__
   } else {
     for (int o = 0; o < nout; ++o) {
       float a = 0.f;
-      for (int i = tid; i < nin; i += kBlock) a = fmaf(in[i], Wt[(size_t)i * nout + o], a);
+      for (int i = tid; i < nin; i += kSolveThreads) a = fmaf(in[i], Wt[(size_t)i * nout + o], a);
       const float s = block_sum(a, sred);
       if (tid == 0) {
         const float v = s + bias[o];
@@ -99,62 +185,268 @@ __device__ void qr_solve_small(float* A, int ld, float* rhs, int n, float* x) {
   }
 }
 
-// LU with partial pivoting on the augmented matrix [A | b] in LDS, all 256 threads.
-__device__ void lu_solve(float* A, int ld, int n, float* x, int* spiv) {
+// LU with partial pivoting on the augmented matrix [A | b] in LDS (tf.matrix_solve's algorithm
+// class, bundlenet.py:183,267).  Rows are pivoted LOGICALLY (perm[]), multipliers are not stored
+// (the right-hand side rides along as column n), so a step is: wave 0 picks the pivot -> barrier
+// -> all 256 threads update the trailing block -> barrier.  Back-substitution runs inside wave 0.
+__device__ void lu_solve(float* A, int ld, int n, float* x, int* perm, float* spiv) {
   const int tid = threadIdx.x;
+  for (int i = tid; i < n; i += kSolveThreads) perm[i] = i;
+  __syncthreads();
   for (int k = 0; k < n; ++k) {
-    // pivot search in column k (wave 0)
     if (tid < 64) {
       float best = -1.f;
-      int bi = k;
-      for (int i = k + tid; i < n; i += 64) {
-        const float v = fabsf(A[i * ld + k]);
+      int br = k;
+      for (int r = k + tid; r < n; r += 64) {
+        const float v = fabsf(A[perm[r] * ld + k]);
         if (v > best) {
           best = v;
-          bi = i;
+          br = r;
         }
       }
 #pragma unroll
-      for (int s = 32; s >= 1; s >>= 1) {
-        const float ob = __shfl_xor(best, s, 64);
-        const int oi = __shfl_xor(bi, s, 64);
-        if (ob > best || (ob == best && oi < bi)) {
+      for (int sft = 32; sft >= 1; sft >>= 1) {
+        const float ob = __shfl_xor(best, sft, 64);
+        const int orr = __shfl_xor(br, sft, 64);
+        if (ob > best || (ob == best && orr < br)) {
           best = ob;
-          bi = oi;
+          br = orr;
         }
       }
-      if (tid == 0) *spiv = bi;
-    }
-    __syncthreads();
-    const int piv = *spiv;
-    if (piv != k) {
-      for (int j = tid; j <= n; j += kBlock) {
-        const float t0 = A[k * ld + j];
-        A[k * ld + j] = A[piv * ld + j];
-        A[piv * ld + j] = t0;
+      if (tid == 0) {
+        const int pk = perm[br];
+        perm[br] = perm[k];
+        perm[k] = pk;
+        *spiv = 1.f / A[pk * ld + k];
       }
     }
     __syncthreads();
-    const float inv = 1.f / A[k * ld + k];
-    __syncthreads();
-    for (int i = k + 1 + tid; i < n; i += kBlock) A[i * ld + k] *= inv;
-    __syncthreads();
-    const int m = n - k - 1;       // rows below
-    const int cols = n - k;        // columns k+1..n (n = augmented rhs)
-    for (int e = tid; e < m * cols; e += kBlock) {
-      const int i = k + 1 + e / cols, j = k + 1 + (e - (e / cols) * cols);
-      A[i * ld + j] = fmaf(-A[i * ld + k], A[k * ld + j], A[i * ld + j]);
+    const int p = perm[k];
+    const float inv = *spiv;
+    const int m = n - k - 1;   // logical rows below
+    const int cols = n - k;    // columns k+1 .. n (n = right-hand side)
+    for (int e = tid; e < m * cols; e += kSolveThreads) {
+      const int rr = e / cols;
+      const int i = perm[k + 1 + rr], j = k + 1 + (e - rr * cols);
+      A[i * ld + j] = fmaf(-(A[i * ld + k] * inv), A[p * ld + j], A[i * ld + j]);
     }
     __syncthreads();
   }
-  // back substitution, column oriented
-  for (int k = n - 1; k >= 0; --k) {
-    if (tid == 0) x[k] = A[k * ld + n] / A[k * ld + k];
-    __syncthreads();
-    const float xk = x[k];
-    for (int i = tid; i < k; i += kBlock) A[i * ld + n] = fmaf(-A[i * ld + k], xk, A[i * ld + n]);
-    __syncthreads();
+  // back substitution (U's row k is physical row perm[k]), wave 0 only
+  if (tid < 64) {
+    for (int k = n - 1; k >= 0; --k) {
+      const float* row = A + perm[k] * ld;
+      float part = 0.f;
+      for (int j = k + 1 + tid; j < n; j += 64) part = fmaf(row[j], x[j], part);
+      const float tot = wave_sum_fast(part);
+      if (tid == 0) x[k] = (row[n] - tot) / row[k];
+    }
   }
+  __syncthreads();
+}
+
+// Register-resident LU with partial pivoting for n <= 16*NR - 1: the augmented matrix is
+// distributed 2-D cyclically over the 16x16 thread grid (thread (ti,tj) owns rows ti+16r, columns
+// tj+16c), so the trailing update runs out of registers.  Per elimination step: owners publish
+// column k -> wave 0 picks the pivot among unused rows -> owners publish the pivot row -> everyone
+// updates its NRxNR register tile.  Rows are pivoted logically (order[]).  Ends by writing the
+// factor back to LDS and back-substituting inside wave 0.
+template <int NR>
+__device__ void lu_solve_regs(float* A, int ld, int n, float* x, int* order, float* colbuf /*[2][16*NR]*/,
+                              float* rowbuf /*[16*NR]*/, int* pv /*[16*NR]*/, float* spiv /*[2]*/) {
+  const int tid = threadIdx.x, ti = tid / kGrid, tj = tid % kGrid;
+  float a[NR][NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int c = 0; c < NR; ++c) {
+      const int i = ti + kGrid * r, j = tj + kGrid * c;
+      a[r][c] = (i < n && j <= n) ? A[i * ld + j] : 0.f;
+    }
+  for (int i = tid; i < kGrid * NR; i += kSolveThreads) pv[i] = (i < n) ? 0 : 1;
+  __syncthreads();
+#pragma unroll
+  for (int c0 = 0; c0 < NR; ++c0) {
+    for (int kk = 0; kk < kGrid; ++kk) {
+      const int k = kGrid * c0 + kk;
+      if (k >= n) break;  // uniform
+      float* cb = colbuf + (k & 1) * kGrid * NR;
+      if (tj == kk) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) cb[ti + kGrid * r] = a[r][c0];
+      }
+      __syncthreads();
+      if (tid < 64) {
+        float best = -1.f;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int u = 0; u < (kGrid * NR + 63) / 64; ++u) {
+          const int i = tid + 64 * u;
+          if (i < n) {
+            const float v = pv[i] ? -1.f : fabsf(cb[i]);
+            if (v > best) {
+              best = v;
+              bi = i;
+            }
+          }
+        }
+        const float mx = wave_max_fast(best);
+        const int pi = wave_min_fast(best == mx ? bi : 0x7fffffff);   // smallest row index among the maxima
+        if (tid == 0) {
+          pv[pi] = 1;
+          order[k] = pi;
+          spiv[0] = __int_as_float(pi);
+          spiv[1] = 1.f / cb[pi];
+        }
+      }
+      __syncthreads();
+      const int p = __float_as_int(spiv[0]);
+      const float inv = spiv[1];
+      if (ti == (p % kGrid)) {  // owners of the pivot row publish it
+        const int rsel = p / kGrid;
+#pragma unroll
+        for (int c = c0; c < NR; ++c) {
+          float v = a[0][c];
+#pragma unroll
+          for (int r = 1; r < NR; ++r) v = (r == rsel) ? a[r][c] : v;
+          rowbuf[tj + kGrid * c] = v;
+        }
+      }
+      __syncthreads();
+      float rb[NR];
+#pragma unroll
+      for (int c = c0; c < NR; ++c) rb[c] = rowbuf[tj + kGrid * c];
+      float lm[NR];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {  // rows already used as a pivot (pv = 1, also beyond n) get multiplier 0
+        const int i = ti + kGrid * r;
+        lm[r] = pv[i] ? 0.f : -(cb[i] * inv);
+      }
+#pragma unroll
+      for (int c = c0; c < NR; ++c) {
+        const float rbc = (tj + kGrid * c > k) ? rb[c] : 0.f;  // columns <= k are finished
+#pragma unroll
+        for (int r = 0; r < NR; ++r) a[r][c] = fmaf(lm[r], rbc, a[r][c]);
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int c = 0; c < NR; ++c) {
+      const int i = ti + kGrid * r, j = tj + kGrid * c;
+      if (i < n && j <= n) A[i * ld + j] = a[r][c];
+    }
+  __syncthreads();
+  if (tid < 64) {  // back substitution: U's row k is physical row order[k]
+    for (int k = n - 1; k >= 0; --k) {
+      const float* row = A + order[k] * ld;
+      float part = 0.f;
+      for (int j = k + 1 + tid; j < n; j += 64) part = fmaf(row[j], x[j], part);
+      const float tot = wave_sum_fast(part);
+      if (tid == 0) x[k] = (row[n] - tot) / row[k];
+    }
+  }
+  __syncthreads();
+}
+
+// Symmetric elimination (Cholesky-class, no pivot search) of the damped normal matrix, register
+// resident like lu_solve_regs.  AtA + damping is symmetric positive definite whenever the solve is
+// meaningful, so eliminating in natural order is stable and needs ONE barrier per column: owners
+// publish column k (= row k by symmetry) and the k-th right-hand-side entry, then every thread
+// applies  a_ij -= a_ik a_jk / a_kk  to its register tile (both triangles: the tile stays exactly
+// symmetric).  Same solution as the reference's pivoted LU (tf.matrix_solve) up to rounding --
+// checked at 1e-4 by the parity tests.  Back-substitution: wave 0, x kept in registers.
+template <int NR>
+__device__ void sym_solve_regs(float* A, int ld, int n, float* x, float* colbuf /*[2][16*NR + 16]*/,
+                               float* dinv /*[16*NR]: reciprocal pivots*/) {
+  constexpr int CB = kGrid * NR + kGrid;
+  const int tid = threadIdx.x, ti = tid / kGrid, tj = tid % kGrid;
+  float a[NR][NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int c = 0; c < NR; ++c) {
+      const int i = ti + kGrid * r, j = tj + kGrid * c;
+      a[r][c] = (i < n && j <= n) ? A[i * ld + j] : 0.f;
+    }
+  STICK(ts0);
+  const int nown_c = n / kGrid, nown_t = n % kGrid;  // the right-hand side (column n) lives at tile column n>>4 of threads tj == n&15
+#pragma unroll
+  for (int c0 = 0; c0 < NR; ++c0) {
+    for (int kk = 0; kk < kGrid; ++kk) {
+      const int k = kGrid * c0 + kk;
+      if (k >= n) break;  // uniform
+      float* cb = colbuf + (k & 1) * CB;
+      if (tj == kk) {  // column k of every owned row
+#pragma unroll
+        for (int r = 0; r < NR; ++r) cb[ti + kGrid * r] = a[r][c0];
+      }
+      if (ti == kk && tj == nown_t) {  // b_k = element (k, n)
+        float v = a[c0][0];
+#pragma unroll
+        for (int c = 1; c < NR; ++c) v = (c == nown_c) ? a[c0][c] : v;
+        cb[kGrid * NR] = v;
+      }
+      __syncthreads();
+      const float sinv = __builtin_amdgcn_rcpf(cb[k]);   // v_rcp_f32: <= 1 ulp, same order as the fmas' rounding
+      const float bk = cb[kGrid * NR];
+      if (tid == 0) dinv[k] = sinv;
+      float lm[NR], cj[NR];
+#pragma unroll
+      for (int r = c0; r < NR; ++r) {                    // tile rows r < c0 hold only rows <= k: finished
+        const int i = ti + kGrid * r;
+        lm[r] = (i > k && i < n) ? -(cb[i] * sinv) : 0.f;
+      }
+#pragma unroll
+      for (int c = c0; c < NR; ++c) {
+        const int j = tj + kGrid * c;
+        cj[c] = (j > k && j < n) ? cb[j] : ((j == n) ? bk : 0.f);
+      }
+#pragma unroll
+      for (int c = c0; c < NR; ++c)
+#pragma unroll
+        for (int r = c0; r < NR; ++r) a[r][c] = fmaf(lm[r], cj[c], a[r][c]);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int c = 0; c < NR; ++c) {
+      const int i = ti + kGrid * r, j = tj + kGrid * c;
+      if (i < n && j <= n) A[i * ld + j] = a[r][c];
+    }
+  __syncthreads();
+#ifdef BANET_TIMING
+  STICK(ts1);
+  if (tid == 0) colbuf[2 * CB] = (float)(ts1 - ts0);
+#endif
+  if (tid < 64) {  // back substitution on the upper triangle; lane l keeps x_l, x_{l+64}, x_{l+128}
+    constexpr int XR = (kGrid * NR + 63) / 64;
+    float xr[XR];
+#pragma unroll
+    for (int u = 0; u < XR; ++u) xr[u] = 0.f;
+    for (int k = n - 1; k >= 0; --k) {
+      const float* row = A + k * ld;
+      float part = 0.f;
+#pragma unroll
+      for (int u = 0; u < XR; ++u) {
+        const int j = tid + 64 * u;
+        if (j > k && j < n) part = fmaf(row[j], xr[u], part);
+      }
+      const float tot = wave_sum_fast(part);
+      const float xk = (row[n] - tot) * dinv[k];
+#pragma unroll
+      for (int u = 0; u < XR; ++u)
+        if (tid + 64 * u == k) xr[u] = xk;
+    }
+#pragma unroll
+    for (int u = 0; u < XR; ++u)
+      if (tid + 64 * u < n) x[tid + 64 * u] = xr[u];
+  }
+  __syncthreads();
 }
 
 __device__ void rodrigues(const float w[3], bool clamp, float Rw[9], float V[9]) {
@@ -191,29 +483,31 @@ __device__ void rodrigues(const float w[3], bool clamp, float Rw[9], float V[9])
   for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.f : 0.f) + a * Kx[i] + bq * K2[i];
 }
 
-__global__ __launch_bounds__(kBlock) void ba_solve_update_kernel(const SolveArgs a) {
+__global__ __launch_bounds__(kSolveThreads) void ba_solve_update_kernel(const SolveArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int P = a.P, C = a.C, K = a.K, ld = P + 2;
   float* sA = smem;                 // [P][ld] augmented
-  float* sX = sA + P * ld;          // [P]
+  float* sX = sA + ((P * ld + 3) & ~3);  // [P]  (every carve offset a multiple of 4 floats: float4 LDS accesses)
   float* sH0 = sX + ((P + 3) & ~3); // MLP ping
   float* sH1 = sH0 + 4 * C;         // MLP pong
   float* sAvg = sH1 + 4 * C;        // [C]
-  float* sRed = sAvg + C;           // [8]
-  int* sPiv = reinterpret_cast<int*>(sRed + 8);
-  float* sScal = sRed + 12;         // lambda, avg_scalar, flags
+  float* sRed = sAvg + ((C + 3) & ~3);  // [8]
+  float* sScal = sRed + 20;         // pivot reciprocal, -, flags
+  float* sPart = sRed + 24;         // [4096] MLP partial sums / solver scratch
+  int* sPerm = reinterpret_cast<int*>(sPart + 4096);  // [P]
 
   LmCtl* ctl = a.ctl ? a.ctl + b : nullptr;
   if (ctl && ctl->active == 0) return;
 
+  STICK(tk0);
   const bool legacy = a.variant == BANET_LEGACY_LM || a.variant == BANET_LEGACY_FIXED;
   const float Nf = (float)a.N;
   const float nval = a.nvalid[b];
   // ---- average residual -------------------------------------------------------------
   const float numvalid = Nf / nval;  // legacy/ba.py:257
   float ss = 0.f, sm = 0.f;
-  for (int c = tid; c < C; c += kBlock) {
+  for (int c = tid; c < C; c += kSolveThreads) {
     float v = a.absres[(size_t)b * C + c] / Nf;                 // reduce_mean over N
     if (a.variant == BANET_LEGACY_LM) v = numvalid * v;        // legacy/ba.py:268
     sAvg[c] = v;
@@ -226,11 +520,11 @@ __global__ __launch_bounds__(kBlock) void ba_solve_update_kernel(const SolveArgs
   float lam;
   if (a.use_mlp) {
     __syncthreads();
-    mlp_layer(sAvg, sH0, a.mlp.w[0], a.mlp.b[0], C, 2 * C, 0, sRed);
-    mlp_layer(sH0, sH1, a.mlp.w[1], a.mlp.b[1], 2 * C, 4 * C, 0, sRed);
-    mlp_layer(sH1, sH0, a.mlp.w[2], a.mlp.b[2], 4 * C, 2 * C, 0, sRed);
-    mlp_layer(sH0, sH1, a.mlp.w[3], a.mlp.b[3], 2 * C, C, 0, sRed);
-    mlp_layer(sH1, sH0, a.mlp.w[4], a.mlp.b[4], C, 1, 1, sRed);
+    mlp_layer(sAvg, sH0, a.mlp.w[0], a.mlp.b[0], C, 2 * C, 0, sPart, sRed);
+    mlp_layer(sH0, sH1, a.mlp.w[1], a.mlp.b[1], 2 * C, 4 * C, 0, sPart, sRed);
+    mlp_layer(sH1, sH0, a.mlp.w[2], a.mlp.b[2], 4 * C, 2 * C, 0, sPart, sRed);
+    mlp_layer(sH0, sH1, a.mlp.w[3], a.mlp.b[3], 2 * C, C, 0, sPart, sRed);
+    mlp_layer(sH1, sH0, a.mlp.w[4], a.mlp.b[4], C, 1, 1, sPart, sRed);
     const float y = sH0[0];
     const float e = legacy ? 1.f : 2.f;                          // ba.py:274 / bundlenet.py:173,249
     lam = powf(nrm, e + y);
@@ -238,6 +532,7 @@ __global__ __launch_bounds__(kBlock) void ba_solve_update_kernel(const SolveArgs
     lam = powf(nrm, 2.f);                                        // legacy/ba.py:190
   }
   if (a.variant == BANET_BUNDLE) lam *= a.l2_base;               // bundlenet.py:252-253
+  STICK(tk1);
   // ---- accept / terminate (legacy early termination) ----------------------------------
   if (ctl) {
     if (tid == 0) {
@@ -263,14 +558,15 @@ __global__ __launch_bounds__(kBlock) void ba_solve_update_kernel(const SolveArgs
   }
   // ---- damping ------------------------------------------------------------------------
   const float* A_g = a.AtA + (size_t)b * P * P;
-  for (int e = tid; e < P * P; e += kBlock) {
+  for (int e = tid; e < P * P; e += kSolveThreads) {
     const int i = e / P, j = e - i * P;
     float v = A_g[e];
     if (i == j && !(a.variant == BANET_BUNDLE && i == P - 1)) v = v + (v + 1e-5f) * lam;
     sA[i * ld + j] = v;
   }
-  for (int i = tid; i < P; i += kBlock) sA[i * ld + P] = a.Atb[(size_t)b * P + i];
+  for (int i = tid; i < P; i += kSolveThreads) sA[i * ld + P] = a.Atb[(size_t)b * P + i];
   __syncthreads();
+  STICK(tk2);
   // ---- solve --------------------------------------------------------------------------
   if (legacy && P == 6) {
     if (tid == 0) {
@@ -280,11 +576,23 @@ __global__ __launch_bounds__(kBlock) void ba_solve_update_kernel(const SolveArgs
     }
     __syncthreads();
   } else {
-    lu_solve(sA, ld, P, sX, sPiv);
+    float* sCol = sPart;                // the MLP scratch is free by now (4096 floats)
+    if (P <= kGrid - 1) {               // pose-only variants: pivoted LU as tf.matrix_solve
+      lu_solve_regs<1>(sA, ld, P, sX, sPerm, sCol, sCol + 2 * kGrid, reinterpret_cast<int*>(sCol + 3 * kGrid), sScal);
+    } else if (P <= 2 * kGrid - 1) {
+      sym_solve_regs<2>(sA, ld, P, sX, sCol, sCol + 2048);
+    } else if (P <= 3 * kGrid - 1) {
+      sym_solve_regs<3>(sA, ld, P, sX, sCol, sCol + 2048);
+    } else if (P <= 5 * kGrid - 1) {
+      sym_solve_regs<5>(sA, ld, P, sX, sCol, sCol + 2048);
+    } else {
+      lu_solve(sA, ld, P, sX, sPerm, sScal);
+    }
   }
+  STICK(tk3);
   // ---- update -------------------------------------------------------------------------
-  for (int k = tid; k < P; k += kBlock) a.st.delta[(size_t)b * P + k] = sX[k];
-  for (int k = tid; k < K; k += kBlock) a.st.Wc[(size_t)b * K + k] += sX[6 + k];   // bundlenet.py:276
+  for (int k = tid; k < P; k += kSolveThreads) a.st.delta[(size_t)b * P + k] = sX[k];
+  for (int k = tid; k < K; k += kSolveThreads) a.st.Wc[(size_t)b * K + k] += sX[6 + k];   // bundlenet.py:276
   if (tid == 0) {
     float w[3] = {sX[0], sX[1], sX[2]}, t[3] = {sX[3], sX[4], sX[5]};
     float Rw[9], V[9], Ro[9], To[3], Rn[9], Tn[3];
@@ -314,6 +622,18 @@ __global__ __launch_bounds__(kBlock) void ba_solve_update_kernel(const SolveArgs
     a.st.ratio[b] = (a.variant == BANET_LEGACY_FIXED) ? nval / Nf : numvalid;   // ba.py:214 / :344
     a.st.lambda_out[b] = lam;
   }
+#ifdef BANET_TIMING
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned long long tk4 = stick();
+    float* dp = a.st.delta + (size_t)b * P;
+    dp[0] = (float)(tk1 - tk0);  // avg + MLP
+    dp[1] = (float)(tk2 - tk1);  // accept logic + damping/load
+    dp[2] = (float)(tk3 - tk2);  // LU + back substitution
+    dp[3] = (float)(tk4 - tk3);  // update
+    dp[4] = sPart[2 * (kGrid * 5 + kGrid)];  // elimination only (P in 96..159)
+  }
+#endif
 }
 
 __global__ void lm_ctl_init_kernel(LmCtl* ctl, int32_t* iters, int B) {
@@ -333,7 +653,7 @@ __global__ void zero_iters_kernel(int32_t* iters, int B) {
 }
 
 size_t solve_lds_bytes(int P, int C) {
-  const size_t fl = (size_t)P * (P + 2) + ((P + 3) & ~3) + 8 * C + C + 8 + 8;
+  const size_t fl = (size_t)(((P * (P + 2)) + 3) & ~3) + ((P + 3) & ~3) + 8 * C + ((C + 3) & ~3) + 24 + 4096 + P + 8;
   return fl * sizeof(float);
 }
 
@@ -342,7 +662,7 @@ int launch_solve(const SolveArgs& a, hipStream_t s) {
   if (lds > 160 * 1024) return BANET_ERR_UNSUPPORTED;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)ba_solve_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(ba_solve_update_kernel, dim3(a.B), dim3(kBlock), lds, s, a);
+  hipLaunchKernelGGL(ba_solve_update_kernel, dim3(a.B), dim3(kSolveThreads), lds, s, a);
   return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;
 }
 
