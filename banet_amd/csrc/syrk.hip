@@ -59,28 +59,37 @@ __global__ __launch_bounds__(kBlock, 2) void ba_syrk_kernel(const SyrkArgs a) {
   float4 preu = make_float4(0.f, 0.f, 0.f, 0.f);
   auto load_tile = [&](int t) {
     const int pt0 = t * kTilePix;
+    if (k4) {  // uniform; kept OUTSIDE the unrolled loop and branch-free inside it, so that all row
+               // loads of the tile are in flight together (an `if` per load serialises them on vmcnt(0))
 #pragma unroll
-    for (int i = 0; i < QT; ++i) {
-      const int idx = tid + i * kBlock;
-      const int n = idx / QPR, q = idx - n * QPR;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < kTilePix * QPR && pt0 + n < N) {
-        const float* p = bas_b + (size_t)(pt0 + n) * K + 4 * q;
-        if (k4) {
-          if (4 * q < K) v = *reinterpret_cast<const float4*>(p);
-        } else {
+      for (int i = 0; i < QT; ++i) {
+        const int idx = tid + i * kBlock;
+        const int n = idx / QPR, q = idx - n * QPR;
+        const bool ok = idx < kTilePix * QPR && pt0 + n < N && 4 * q < K;
+        const float4 v = *reinterpret_cast<const float4*>(bas_b + (ok ? (size_t)(pt0 + n) * K + 4 * q : 0));
+        pre[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < QT; ++i) {
+        const int idx = tid + i * kBlock;
+        const int n = idx / QPR, q = idx - n * QPR;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < kTilePix * QPR && pt0 + n < N) {
+          const float* p = bas_b + (size_t)(pt0 + n) * K + 4 * q;
           if (4 * q + 0 < K) v.x = p[0];
           if (4 * q + 1 < K) v.y = p[1];
           if (4 * q + 2 < K) v.z = p[2];
           if (4 * q + 3 < K) v.w = p[3];
         }
+        pre[i] = v;
       }
-      pre[i] = v;
     }
-    preu = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < 2 * kTilePix) {
+    {
       const int n = tid >> 1;
-      if (pt0 + n < N) preu = *reinterpret_cast<const float4*>(rec_b + (size_t)(pt0 + n) * 8 + 4 * (tid & 1));
+      const bool ok = tid < 2 * kTilePix && pt0 + n < N;
+      const float4 v = *reinterpret_cast<const float4*>(rec_b + (ok ? (size_t)(pt0 + n) * 8 + 4 * (tid & 1) : 0));
+      preu = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto store_tile = [&](int buf) {
