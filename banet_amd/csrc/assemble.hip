@@ -90,17 +90,19 @@ int launch_assemble(const banet_level_t* lv, const AsmPlan& pl, const float* R, 
   float* rec = lv->K > 0 ? reinterpret_cast<float*>(base + pl.off_rec) : nullptr;
   float* spart = lv->K > 0 ? reinterpret_cast<float*>(base + pl.off_spart) : nullptr;
   int rc;
+  prepare_gather(lv, pl.g, gpart, s);
   {
     Timed t(s, lv->N);
     rc = launch_gather(lv, pl.g, R, T, Wc, active, active_stride, rec, gpart, s);
   }
   if (rc != BANET_OK) return rc;
+  const float* gred = finish_gather(lv, pl.g, active, active_stride, gpart, s);
   if (lv->K > 0) {
     Timed t(s, -lv->N);
     rc = launch_syrk(lv->basis, rec, lv->B, lv->N, lv->K, pl.s, active, active_stride, spart, s);
     if (rc != BANET_OK) return rc;
   }
-  launch_reduce2(gpart, pl.g.G, pl.g.pstride, spart, pl.s.Gs, pl.s.pstride, active, active_stride, lv->B, lv->K, lv->C,
+  launch_reduce2(gred, pl.g.frows, pl.g.pstride, spart, pl.s.Gs, pl.s.pstride, active, active_stride, lv->B, lv->K, lv->C,
                  AtA, Atb, absres, nvalid, s);
   return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;
 }

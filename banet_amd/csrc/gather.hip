@@ -426,6 +426,15 @@ __global__ __launch_bounds__(kBlock, BANET_GATHER_WAVES) void ba_gather_kernel(c
 // --------------------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------------------
+constexpr int kCUs = 256;
+constexpr int kGenericBlocksPerCU = BANET_GATHER_WAVES;  // ba_gather_kernel: launch bounds
+constexpr int kC128BlocksPerCU = BANET_G128_WAVES;       // ba_gather128_kernel: launch bounds (LDS: 18 KB)
+
+static bool use_c128(const banet_level_t* lv) {
+  // reserved_ bit 5 (A/B experiments only): force the generic kernel
+  return lv->C == 128 && !lv->tgt_has_grad && !(lv->reserved_ & 32) && (lv->K & 3) == 0 && lv->K <= 256;
+}
+
 int plan_gather(const banet_level_t* lv, GatherPlan* pl) {
   if (!lv || lv->B <= 0 || lv->N <= 0 || lv->C <= 0 || lv->K < 0 || lv->H < 4 || lv->W < 4) return BANET_ERR_INVALID_ARG;
   if (lv->C > 256 || lv->K > 256) return BANET_ERR_UNSUPPORTED;
@@ -439,17 +448,62 @@ int plan_gather(const banet_level_t* lv, GatherPlan* pl) {
     pl->tiles = (lv->N + kTilePix - 1) / kTilePix;
   }
   pl->groups = (pl->tiles + 3) / 4;
-  // ~4 resident workgroups per CU on 256 CUs, split across the windows; >= 2 groups each
-  int target = (1024 + lv->B - 1) / lv->B;
-  int G = pl->groups / 2;
+  pl->c128 = use_c128(lv) ? 1 : 0;
+  // One resident round: the gather is latency-bound per wave (measured: a second, partial round of
+  // workgroups takes as long as the first), so the grid is what the chip holds at once, split
+  // across the windows.
+  const int resident = kCUs * (pl->c128 ? kC128BlocksPerCU : kGenericBlocksPerCU);
+  int target = (resident + lv->B - 1) / lv->B;
+  int G = pl->groups;
   if (G > target) G = target;
   if (G < 1) G = 1;
   if (G >= 8) G &= ~7;
   pl->G = G;
+  pl->nbands = (G & 7) == 0 ? 8 : 1;
   pl->pstride = kGHdr + lv->C;
-  pl->partial_bytes = align_up((size_t)lv->B * G * pl->pstride * sizeof(float), 256);
+  pl->rows = pl->c128 ? pl->tiles : G;
+  pl->frows = pl->rows > kFoldRows ? (pl->rows + kFoldRows - 1) / kFoldRows : pl->rows;
+  const size_t row_bytes = (size_t)lv->B * pl->pstride * sizeof(float);
+  pl->off_fold = align_up(row_bytes * pl->rows, 256);
+  pl->off_queue = pl->off_fold + (pl->frows != pl->rows ? align_up(row_bytes * pl->frows, 256) : 0);
+  pl->partial_bytes = pl->off_queue + align_up((size_t)lv->B * 8 * sizeof(int), 256);
   pl->rec_bytes = lv->K > 0 ? align_up((size_t)lv->B * lv->N * 8 * sizeof(float), 256) : 0;
   return BANET_OK;
+}
+
+// sum kFoldRows consecutive partial rows (fixed order) -> one row
+__global__ __launch_bounds__(256) void ba_fold_kernel(const float* __restrict__ in, int rows, int stride,
+                                                      float* __restrict__ out, int frows, const int32_t* active,
+                                                      int active_stride) {
+  const int b = blockIdx.y, c = blockIdx.x, e = threadIdx.x;
+  if (active != nullptr && active[(size_t)b * active_stride] == 0) return;
+  if (e >= stride) return;
+  const int r0 = c * kFoldRows, r1 = min(rows, r0 + kFoldRows);
+  const float* p = in + ((size_t)b * rows + r0) * stride + e;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int i = 0;
+  const int n = r1 - r0;
+  for (; i + 3 < n; i += 4) {
+    s0 += p[(size_t)(i + 0) * stride];
+    s1 += p[(size_t)(i + 1) * stride];
+    s2 += p[(size_t)(i + 2) * stride];
+    s3 += p[(size_t)(i + 3) * stride];
+  }
+  for (; i < n; ++i) s0 += p[(size_t)i * stride];
+  out[((size_t)b * frows + c) * stride + e] = (s0 + s1) + (s2 + s3);
+}
+
+void prepare_gather(const banet_level_t* lv, const GatherPlan& pl, float* partials, hipStream_t s) {
+  if (pl.c128) (void)hipMemsetAsync(reinterpret_cast<char*>(partials) + pl.off_queue, 0, (size_t)lv->B * 8 * sizeof(int), s);
+}
+
+const float* finish_gather(const banet_level_t* lv, const GatherPlan& pl, const int32_t* active, int active_stride,
+                           float* partials, hipStream_t s) {
+  if (pl.frows == pl.rows) return partials;
+  float* out = reinterpret_cast<float*>(reinterpret_cast<char*>(partials) + pl.off_fold);
+  hipLaunchKernelGGL(ba_fold_kernel, dim3(pl.frows, lv->B), dim3(256), 0, s, partials, pl.rows, pl.pstride, out, pl.frows,
+                     active, active_stride);
+  return out;
 }
 
 template <int VEC, int CH, bool GRAD>
@@ -497,8 +551,10 @@ int launch_gather(const banet_level_t* lv, const GatherPlan& pl, const float* R,
   a.tiles_x = pl.tiles_x;
   a.tiles_y = pl.tiles_y;
   a.groups = pl.groups;
+  a.queue = reinterpret_cast<int*>(reinterpret_cast<char*>(partials) + pl.off_queue);
+  a.nbands = pl.nbands;
   int rc;
-  if (lv->C == 128 && !lv->tgt_has_grad && !(lv->reserved_ & 32))   // reserved_ bit 5: force the generic kernel (A/B)
+  if (pl.c128)
     rc = launch_gather128(a, lv->K, s);
   else
     rc = lv->tgt_has_grad ? launch_c<true>(a, lv->C, lv->K, s) : launch_c<false>(a, lv->C, lv->K, s);

@@ -1,6 +1,7 @@
 // ba_gather128_kernel -- the gather pass specialised for the reference's feature width C = 128
 // (legacy/feat.py:251, dec.py:174) with the gradient computed on the fly from the C-channel
-// target map.  Same arithmetic as ba_gather_kernel (gather.hip); different lane mapping:
+// target map.  Same arithmetic as ba_gather_kernel (gather.hip); different lane mapping and
+// scheduling:
 //
 //   * 16 lanes per pixel, 8 channels per lane: a wave instruction works on FOUR pixels (a 2x2
 //     block of the 8x8 patch, so their 12-texel stencils overlap and hit in L1), every texel row
@@ -9,8 +10,15 @@
 //   * the five channel sums per pixel are reduced inside one 16-lane DPP row
 //     (row_ror:8, row_half_mirror, quad_perm x2): no LDS crossbar, no cross-row traffic;
 //   * per-pixel parameters go from the geometry phase (lane = pixel) to the gather phase
-//     (lane = pixel-group x channel-slice) through a 2 KB per-wave LDS table: wave-private,
-//     so still no workgroup barrier anywhere in the main loop.
+//     (lane = pixel-group x channel-slice) through a 2 KB per-wave LDS table: wave-private, so
+//     there is no workgroup barrier anywhere -- a workgroup is just 4 independent waves;
+//   * the kernel is latency-bound per wave (measured: a wave's batch takes the same time with 1
+//     or 3 workgroups on the CU), so the grid is ONE resident round (plan_gather) and every wave
+//     pulls 8x8 tiles from a per-(window, XCD band) atomic queue until all bands are empty: no
+//     tail round, no static imbalance;
+//   * every tile publishes its own partial (28 pose sums via the transposing butterfly + C x
+//     sum|d|); ba_fold_kernel / ba_reduce2_kernel add the tile partials in tile order, so the
+//     result does not depend on which wave happened to process which tile (bit-reproducible).
 #include "gather_common.hpp"
 
 namespace banet {
@@ -23,12 +31,32 @@ __device__ __forceinline__ void morton8(int n, int& px, int& py) {  // pixel id 
   py = ((n >> 1) & 1) | ((n >> 2) & 2) | ((n >> 3) & 4);
 }
 
-template <int KVEC, int KCH>
-__global__ __launch_bounds__(kBlock, 3) void ba_gather128_kernel(const GatherArgs a) {
-  __shared__ float sH[kNumWaves][28][64];                 // per-lane H_cc / Atb_c / nvalid accumulators
-  __shared__ float sAbs[kNumWaves][kC128];
+__device__ __forceinline__ int brev5(int t) { return (int)(__brev((unsigned)t) >> 27); }
+
+// carry chain of the transposing butterfly over NL levels, first lane distance S0 (cf. carry_push)
+template <int NL, int S0>
+__device__ __forceinline__ void carry_push_n(float (&pend)[NL + 1], float v, int t) {
+  bool done = false;
+#pragma unroll
+  for (int L = 0; L < NL; ++L) {
+    if (!done) {
+      if (((t >> L) & 1) == 0) {
+        pend[L] = v;
+        done = true;
+      } else {
+        v = bfly_merge(pend[L], v, S0 >> L);
+      }
+    }
+  }
+  if (!done) pend[NL] = v;
+}
+
+// KV4 = number of 128-coefficient chunks of a basis row (0: pose only; K % 4 == 0, K <= 128 KV4)
+template <int KV4>
+__global__ __launch_bounds__(kBlock, BANET_G128_WAVES) void ba_gather128_kernel(const GatherArgs a) {
   __shared__ __attribute__((aligned(16))) float sPar[kNumWaves][64][kParStride];
   __shared__ __attribute__((aligned(16))) float sQ[kNumWaves][64][8];
+  __shared__ float sAbs[kNumWaves][kC128];
   const banet_level_t& lv = a.lv;
   const int b = blockIdx.y, g = blockIdx.x;
   if (a.active != nullptr && a.active[(size_t)b * a.active_stride] == 0) return;
@@ -40,43 +68,44 @@ __global__ __launch_bounds__(kBlock, 3) void ba_gather128_kernel(const GatherArg
   const float* __restrict__ tgt_b = lv.tgt + (size_t)b * H * W * C;
   const float* __restrict__ src_b = lv.src + (size_t)b * N * C;
   const float* __restrict__ dep_b = lv.depth + (size_t)b * N;
-  const float* __restrict__ bas_b = KCH ? lv.basis + (size_t)b * N * K : nullptr;
-  float* __restrict__ rec_b = KCH ? a.rec + (size_t)b * N * 8 : nullptr;
+  const float* __restrict__ bas_b = KV4 ? lv.basis + (size_t)b * N * K : nullptr;
+  float* __restrict__ rec_b = KV4 ? a.rec + (size_t)b * N * 8 : nullptr;
+  float* __restrict__ part_b = a.partials + (size_t)b * a.tiles * (kGHdr + C);
   const int grp = lane >> 4, sub = lane & 15;
+  const int half = lane >> 5, li = lane & 31;
 
+  float wreg[KV4 ? KV4 : 1][4];  // this lane's slice of the depth coefficients
+  if constexpr (KV4 > 0) {
 #pragma unroll
-  for (int i = 0; i < 28; ++i) sH[w][i][lane] = 0.f;
-  float absd8[8];   // |d| of channels {4 sub + e, 64 + 4 sub + e} over this lane group's pixels
+    for (int kc = 0; kc < KV4; ++kc)
 #pragma unroll
-  for (int i = 0; i < 8; ++i) absd8[i] = 0.f;
-  float absd2[1][2] = {{0.f, 0.f}};  // rim pixels (generic routine: channels 2 lane, 2 lane + 1)
-
-  float wreg[KCH ? KCH : 1][KVEC];
-  if constexpr (KCH > 0) {
-#pragma unroll
-    for (int kc = 0; kc < KCH; ++kc)
-#pragma unroll
-      for (int e = 0; e < KVEC; ++e) {
-        const int k = (kc * 64 + lane) * KVEC + e;
+      for (int e = 0; e < 4; ++e) {
+        const int k = kc * 128 + li * 4 + e;
         wreg[kc][e] = (k < K) ? a.Wc[(size_t)b * K + k] : 0.f;
       }
   }
 
-  int s_begin, s_end, s_step;
-  if ((a.G & 7) == 0) {
-    const int x = g & 7, s = g >> 3, per = a.G >> 3;
-    s_begin = (int)(((long long)a.groups * x) >> 3) + s;
-    s_end = (int)(((long long)a.groups * (x + 1)) >> 3);
-    s_step = per;
-  } else {
-    s_begin = g;
-    s_end = a.groups;
-    s_step = a.G;
-  }
+  // ---- tile queue: band x = tiles [tiles x / nb, tiles (x+1) / nb); home band = this workgroup's XCD
+  const int nb = a.nbands;
+  int* __restrict__ queue = a.queue + b * 8;
+  int band = nb > 1 ? (g & 7) : 0, left = nb;
+  auto band_lo = [&](int x) { return (int)(((long long)a.tiles * x) / nb); };
+  auto pop = [&](int x) {  // wave-uniform
+    int v = 0;
+    if (lane == 0) v = atomicAdd(&queue[x], 1);
+    return rfl(v) + band_lo(x);
+  };
+  int t_next = pop(band);
 
-  for (int sg = s_begin; sg < s_end; sg += s_step) {
-    const int t = sg * 4 + w;
-    if (t >= a.tiles) continue;  // wave-uniform
+  while (true) {
+    int t = t_next;
+    while (t >= band_lo(band + 1)) {  // this band is drained: move on (a drained band stays drained)
+      if (--left == 0) return;
+      band = band + 1 == nb ? 0 : band + 1;
+      t = pop(band);
+    }
+    t_next = pop(band);  // issued now, consumed after this tile: the atomic's latency is hidden
+    BANET_TICK(tb0);
     int tx = 0, ty = 0;
     if (dense) tile_coords(t, a.tiles_x, a.tiles_y, tx, ty);
     auto point_of = [&](int n, bool& valid) -> int {
@@ -93,33 +122,42 @@ __global__ __launch_bounds__(kBlock, 3) void ba_gather128_kernel(const GatherArg
     };
     bool valid;
     const int pt = point_of(lane, valid);
-
-    // ---- 1. depth: D_j = D0_j + b_j . W  (64 coalesced row loads, transposing butterfly) ----
-    float D = valid ? dep_b[pt] : 0.f;
-    if constexpr (KCH > 0) {
-      float pend[6], dsum = 0.f;
-      for (int q8 = 0; q8 < 8; ++q8) {
-        float part[8];
+    float absd8[8];   // |d| of channels {4 sub + e, 64 + 4 sub + e} over this lane group's pixels
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 8; ++i) absd8[i] = 0.f;
+    float absd2[1][2] = {{0.f, 0.f}};  // rim pixels (generic routine: channels 2 lane, 2 lane + 1)
+
+    // ---- 1. depth: D_j = D0_j + b_j . W.  A half wave reads one basis row per instruction
+    // (16 B per lane); 32 row pairs go through a 5-level transposing butterfly inside each half,
+    // leaf t of half h carrying pixel h*32 + brev5(t), so that pixel j's sum lands on lane j.
+    float D = valid ? dep_b[pt] : 0.f;
+    if constexpr (KV4 > 0) {
+      float pend[6];
+#pragma unroll
+      for (int q16 = 0; q16 < 2; ++q16) {
+        float part[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
           bool vj;
-          const int ptj = point_of(brev6(q8 * 8 + i), vj);   // leaf t ends on lane brev6(t)
+          const int ptj = point_of(half * 32 + brev5(q16 * 16 + i), vj);
           const float* row = bas_b + (size_t)ptj * K;
           float acc = 0.f;
 #pragma unroll
-          for (int kc = 0; kc < KCH; ++kc) {
-            const int k = (kc * 64 + lane) * KVEC;
-            const Vec<KVEC> bv = ldv_nt<KVEC>(row, k, k < K);
+          for (int kc = 0; kc < KV4; ++kc) {
+            const int k = kc * 128 + li * 4;
+            const bool ok = k < K;
+            const f32x4 bv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row + (ok ? k : 0)));
 #pragma unroll
-            for (int e = 0; e < KVEC; ++e) acc = fmaf(bv.v[e], wreg[kc][e], acc);
+            for (int e = 0; e < 4; ++e) acc = fmaf(ok ? bv[e] : 0.f, wreg[kc][e], acc);
           }
           part[i] = acc;
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) carry_push(pend, part[i], q8 * 8 + i, dsum);
+        for (int i = 0; i < 16; ++i) carry_push_n<5, 16>(pend, part[i], q16 * 16 + i);
       }
-      D += dsum;
+      D += pend[5];
     }
+    BANET_TICK(tb1);
 
     // ---- 2. geometry, lane = pixel -------------------------------------------------------
     float gw00 = 0.f, gw01 = 0.f, gw10 = 0.f, gw11 = 0.f, jd0 = 0.f, jd1 = 0.f;
@@ -216,15 +254,23 @@ __global__ __launch_bounds__(kBlock, 3) void ba_gather128_kernel(const GatherArg
       *reinterpret_cast<float4*>(&sPar[w][lane][4]) = pb;
     }
 
+    BANET_TICK(tb2);
     // ---- 3. gather: 16 steps x 4 pixels; lane = (pixel group, 8-channel slice) --------------
     const int rowC = W * C;
     for (int s = 0; s < 16; ++s) {
       const int j = 4 * s + grp;
       const float4 pa = *reinterpret_cast<const float4*>(&sPar[w][j][0]);
       const float4 pb = *reinterpret_cast<const float4*>(&sPar[w][j][4]);
+#ifdef BANET_ABLATE   // development aid (tools/prof_assemble.py): reserved_ bit 0 -> every tap reads texel (1,1) / point 0
+      const bool abl = (lv.reserved_ & 1) != 0;
+      const unsigned osrc = abl ? 0u : (unsigned)__float_as_int(pa.x), oa = abl ? (unsigned)((W + 1) * C) : (unsigned)__float_as_int(pa.y);
+#else
       const unsigned osrc = (unsigned)__float_as_int(pa.x), oa = (unsigned)__float_as_int(pa.y);
+#endif
       const float w00 = pa.z, w01 = pa.w, w10 = pb.x, w11 = pb.y, mk = pb.z;
-      Q5 q{0.f, 0.f, 0.f, 0.f, 0.f};
+      const float h00 = 0.5f * w00, h01 = 0.5f * w01, h10 = 0.5f * w10, h11 = 0.5f * w11;
+      typedef float v2f_ __attribute__((ext_vector_type(2)));
+      v2f_ qm11 = {0.f, 0.f}, qm12 = {0.f, 0.f}, qm22 = {0.f, 0.f}, qg1 = {0.f, 0.f}, qg2 = {0.f, 0.f};
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const unsigned co = 64u * h + 4u * sub;
@@ -240,31 +286,37 @@ __global__ __launch_bounds__(kBlock, 3) void ba_gather128_kernel(const GatherArg
                      b2 = *reinterpret_cast<const float4*>(rb + C), b3 = *reinterpret_cast<const float4*>(rb + 2 * C);
         const float4 m1 = *reinterpret_cast<const float4*>(rm), m2 = *reinterpret_cast<const float4*>(rm + C);
         const float4 p1 = *reinterpret_cast<const float4*>(rp), p2 = *reinterpret_cast<const float4*>(rp + C);
-        const float F1[4] = {f1.x, f1.y, f1.z, f1.w};
-        const float A0[4] = {a0.x, a0.y, a0.z, a0.w}, A1[4] = {a1.x, a1.y, a1.z, a1.w};
-        const float A2[4] = {a2.x, a2.y, a2.z, a2.w}, A3[4] = {a3.x, a3.y, a3.z, a3.w};
-        const float B0[4] = {b0.x, b0.y, b0.z, b0.w}, B1[4] = {b1.x, b1.y, b1.z, b1.w};
-        const float B2[4] = {b2.x, b2.y, b2.z, b2.w}, B3[4] = {b3.x, b3.y, b3.z, b3.w};
-        const float M1[4] = {m1.x, m1.y, m1.z, m1.w}, M2[4] = {m2.x, m2.y, m2.z, m2.w};
-        const float P1[4] = {p1.x, p1.y, p1.z, p1.w}, P2[4] = {p2.x, p2.y, p2.z, p2.w};
+        // packed fp32 (v_pk_fma_f32 / v_pk_add_f32): two channels per VALU instruction.  The 0.5 of
+        // the central difference is folded into the weights (exact: a power of two) and the mask
+        // into the residual's fma (mk is 0 or 1; f is already masked through the weights).
+        typedef float v2f __attribute__((ext_vector_type(2)));
+#define BANET_V2(v, k) (v2f){(k) ? (v).z : (v).x, (k) ? (v).w : (v).y}
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float f = ((A1[e] * w00 + A2[e] * w01) + B1[e] * w10) + B2[e] * w11;
-          const float gx00 = 0.5f * (A2[e] - A0[e]), gx01 = 0.5f * (A3[e] - A1[e]);
-          const float gx10 = 0.5f * (B2[e] - B0[e]), gx11 = 0.5f * (B3[e] - B1[e]);
-          const float gx = ((gx00 * w00 + gx01 * w01) + gx10 * w10) + gx11 * w11;
-          const float gy00 = 0.5f * (B1[e] - M1[e]), gy01 = 0.5f * (B2[e] - M2[e]);
-          const float gy10 = 0.5f * (P1[e] - A1[e]), gy11 = 0.5f * (P2[e] - A2[e]);
-          const float gy = ((gy00 * w00 + gy01 * w01) + gy10 * w10) + gy11 * w11;
-          const float d = mk * (f - F1[e]);
-          q.m11 = fmaf(gx, gx, q.m11);
-          q.m12 = fmaf(gx, gy, q.m12);
-          q.m22 = fmaf(gy, gy, q.m22);
-          q.g1 = fmaf(gx, d, q.g1);
-          q.g2 = fmaf(gy, d, q.g2);
-          absd8[h * 4 + e] += fabsf(d);
+        for (int k = 0; k < 2; ++k) {
+          const v2f F1 = BANET_V2(f1, k);
+          const v2f A0 = BANET_V2(a0, k), A1 = BANET_V2(a1, k), A2 = BANET_V2(a2, k), A3 = BANET_V2(a3, k);
+          const v2f B0 = BANET_V2(b0, k), B1 = BANET_V2(b1, k), B2 = BANET_V2(b2, k), B3 = BANET_V2(b3, k);
+          const v2f M1 = BANET_V2(m1, k), M2 = BANET_V2(m2, k), P1 = BANET_V2(p1, k), P2 = BANET_V2(p2, k);
+          const v2f f = ((A1 * w00 + A2 * w01) + B1 * w10) + B2 * w11;
+          const v2f gx = (((A2 - A0) * h00 + (A3 - A1) * h01) + (B2 - B0) * h10) + (B3 - B1) * h11;
+          const v2f gy = (((B1 - M1) * h00 + (B2 - M2) * h01) + (P1 - A1) * h10) + (P2 - A2) * h11;
+          const v2f d = f - F1 * mk;
+          qm11 += gx * gx;
+          qm12 += gx * gy;
+          qm22 += gy * gy;
+          qg1 += gx * d;
+          qg2 += gy * d;
+          absd8[h * 4 + 2 * k] += fabsf(d.x);
+          absd8[h * 4 + 2 * k + 1] += fabsf(d.y);
         }
+#undef BANET_V2
       }
+      Q5 q;
+      q.m11 = qm11.x + qm11.y;
+      q.m12 = qm12.x + qm12.y;
+      q.m22 = qm22.x + qm22.y;
+      q.g1 = qg1.x + qg1.y;
+      q.g2 = qg2.x + qg2.y;
       q.m11 = row16_sum(q.m11);
       q.m12 = row16_sum(q.m12);
       q.m22 = row16_sum(q.m22);
@@ -307,7 +359,10 @@ __global__ __launch_bounds__(kBlock, 3) void ba_gather128_kernel(const GatherArg
       }
     }
 
-    // ---- 4. per-pixel 6x6 algebra, lane = pixel ------------------------------------------
+    BANET_TICK(tb3);
+
+    // ---- 4. per-pixel 6x6 algebra (lane = pixel), then the tile's 28 pose sums --------------
+    float* __restrict__ part = part_b + (size_t)t * (kGHdr + C);
     {
       float mj[12];
 #pragma unroll
@@ -315,18 +370,28 @@ __global__ __launch_bounds__(kBlock, 3) void ba_gather128_kernel(const GatherArg
         mj[i] = q.m11 * jc[i] + q.m12 * jc[6 + i];
         mj[6 + i] = q.m12 * jc[i] + q.m22 * jc[6 + i];
       }
+      // leaves 0..20: upper triangle of Jc^T M Jc, 21..26: Jc^T g, 27: valid count, 28..31: zero.
+      // 5 levels (lane distance 32..2) + one xor-1 add: lane l ends with leaf brev5(l >> 1).
+      float pend[6];
       int o = 0;
 #pragma unroll
       for (int i = 0; i < 6; ++i)
 #pragma unroll
         for (int jj = i; jj < 6; ++jj) {
-          atomicAdd(&sH[w][o][lane], jc[i] * mj[jj] + jc[6 + i] * mj[6 + jj]);
+          carry_push_n<5, 32>(pend, jc[i] * mj[jj] + jc[6 + i] * mj[6 + jj], o);
           ++o;
         }
 #pragma unroll
-      for (int i = 0; i < 6; ++i) atomicAdd(&sH[w][21 + i][lane], jc[i] * q.g1 + jc[6 + i] * q.g2);
-      atomicAdd(&sH[w][27][lane], (float)(gflags & 1));
-      if constexpr (KCH > 0) {
+      for (int i = 0; i < 6; ++i) carry_push_n<5, 32>(pend, jc[i] * q.g1 + jc[6 + i] * q.g2, 21 + i);
+      carry_push_n<5, 32>(pend, (float)(gflags & 1), 27);
+#pragma unroll
+      for (int i = 28; i < 32; ++i) carry_push_n<5, 32>(pend, 0.f, i);
+      float tot = pend[5];
+      tot += dpp_mov<kDppXor1>(tot);
+      const int leaf = brev5(lane >> 1);
+      if ((lane & 1) == 0 && leaf < 28) part[leaf] = tot;
+
+      if constexpr (KV4 > 0) {
         if (valid) {
           const float md0 = q.m11 * jd0 + q.m12 * jd1, md1 = q.m12 * jd0 + q.m22 * jd1;
           float4 ua, ub;
@@ -344,44 +409,41 @@ __global__ __launch_bounds__(kBlock, 3) void ba_gather128_kernel(const GatherArg
         }
       }
     }
-  }  // tiles
 
-  // ---- epilogue: one small partial per workgroup -------------------------------------------
+    // ---- 5. the tile's C x sum|d| ------------------------------------------------------------
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {  // fold the 4 pixel groups (fixed order), group 0 publishes
-    float v = absd8[i];
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    if (grp == 0) sAbs[w][(i >> 2) * 64 + 4 * sub + (i & 3)] = v;
-  }
-  sAbs[w][2 * lane] += absd2[0][0];       // same wave: LDS operations retire in program order
-  sAbs[w][2 * lane + 1] += absd2[0][1];
-  __syncthreads();
-  float* __restrict__ part = a.partials + ((size_t)b * a.G + g) * (kGHdr + C);
-  if (tid < 4 * 28) {
-    const int ww = tid / 28, i = tid - ww * 28;
-    float s = 0.f;
-    for (int l = 0; l < 64; ++l) s += sH[ww][i][l];
-    sH[ww][i][0] = s;
-  }
-  __syncthreads();
-  if (tid < 28) part[tid] = (sH[0][tid][0] + sH[1][tid][0]) + (sH[2][tid][0] + sH[3][tid][0]);
-  for (int c = tid; c < C; c += kBlock) part[kGHdr + c] = (sAbs[0][c] + sAbs[1][c]) + (sAbs[2][c] + sAbs[3][c]);
+    for (int i = 0; i < 8; ++i) {  // fold the 4 pixel groups (fixed order), group 0 publishes
+      float v = absd8[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (grp == 0) sAbs[w][(i >> 2) * 64 + 4 * sub + (i & 3)] = v;
+    }
+    sAbs[w][2 * lane] += absd2[0][0];       // same wave: LDS operations retire in program order
+    sAbs[w][2 * lane + 1] += absd2[0][1];
+    part[kGHdr + lane] = sAbs[w][lane];
+    part[kGHdr + 64 + lane] = sAbs[w][64 + lane];
+#ifdef BANET_TIMING
+    {
+      BANET_TICK(tb9);
+      if (lane == 0) {
+        part[28] = (float)(tb3 - tb2);  // 16 gather steps
+        part[29] = (float)(tb9 - tb3);  // rim patch + algebra + partial + rec store
+        part[30] = (float)(tb1 - tb0);  // depth dot
+        part[31] = (float)(tb9 - tb0);  // whole tile
+      }
+    }
+#endif
+  }  // tiles
 }
 
 int launch_gather128(const GatherArgs& a, int K, hipStream_t s) {
   dim3 grid(a.G, a.lv.B), block(kBlock);
-  const bool keven = (K & 1) == 0;
   if (K == 0)
-    hipLaunchKernelGGL((ba_gather128_kernel<1, 0>), grid, block, 0, s, a);
-  else if (keven && K <= 128)
-    hipLaunchKernelGGL((ba_gather128_kernel<2, 1>), grid, block, 0, s, a);
-  else if (keven && K <= 256)
-    hipLaunchKernelGGL((ba_gather128_kernel<2, 2>), grid, block, 0, s, a);
-  else if (K <= 64)
-    hipLaunchKernelGGL((ba_gather128_kernel<1, 1>), grid, block, 0, s, a);
-  else if (K <= 128)
-    hipLaunchKernelGGL((ba_gather128_kernel<1, 2>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((ba_gather128_kernel<0>), grid, block, 0, s, a);
+  else if ((K & 3) == 0 && K <= 128)
+    hipLaunchKernelGGL((ba_gather128_kernel<1>), grid, block, 0, s, a);
+  else if ((K & 3) == 0 && K <= 256)
+    hipLaunchKernelGGL((ba_gather128_kernel<2>), grid, block, 0, s, a);
   else
     return BANET_ERR_UNSUPPORTED;
   return BANET_OK;

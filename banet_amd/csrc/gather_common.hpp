@@ -15,6 +15,8 @@ struct GatherArgs {
   float* rec;       // [B][N][8]  u0..u5, s, r   (bundle only)
   float* partials;  // [B][G][kGHdr + C]
   int G, tiles, tiles_x, tiles_y, groups;
+  int* queue;       // [B][8] tile-queue heads (ba_gather128_kernel), zero at launch
+  int nbands;
 };
 
 template <int VEC>
@@ -110,6 +112,11 @@ __device__ __forceinline__ unsigned long long tick() {
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
   return t;
 }
+__device__ __forceinline__ unsigned long long realtime() {  // 100 MHz, synchronised across the chip
+  unsigned long long t;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
 #define BANET_TICK(var) const unsigned long long var = tick()
 #define BANET_TACC(acc, a, b) acc += (float)((b) - (a))
 #else
@@ -177,6 +184,9 @@ __device__ __noinline__ Q5 border_pixel_q5(int x0, int y0, float w00, float w01,
   return q;
 }
 
+#ifndef BANET_G128_WAVES
+#define BANET_G128_WAVES 3   // ba_gather128_kernel: workgroups per CU (= waves per SIMD) of its launch bounds
+#endif
 int launch_gather128(const GatherArgs& a, int K, hipStream_t s);  // gather128.hip
 
 }  // namespace banet

@@ -10,11 +10,22 @@ constexpr int kUStrideS = 8;    // per-pixel record: u0..u5, s, r
 // ---- gather.hip ------------------------------------------------------------------------
 struct GatherPlan {
   int G, tiles, tiles_x, tiles_y, groups, pstride;
+  int c128;     // 1: ba_gather128_kernel (dynamic tile queue, one partial row per tile)
+  int rows;     // partial rows per window written by the gather kernel (tiles or G)
+  int frows;    // rows per window handed to ba_reduce2_kernel (after ba_fold_kernel when rows > kFoldRows)
+  int nbands;   // tile-queue bands (8 = one per XCD)
+  size_t off_fold, off_queue;   // inside the partial region
   size_t partial_bytes, rec_bytes;
 };
+constexpr int kFoldRows = 64;
 int plan_gather(const banet_level_t* lv, GatherPlan* pl);
+// prepare (reset the tile queue) -> launch (the gather kernel alone: this is what the profiler times)
+// -> finish (fold the tile partials); `reduced` returns the rows ba_reduce2_kernel should read
+void prepare_gather(const banet_level_t* lv, const GatherPlan& pl, float* partials, hipStream_t s);
 int launch_gather(const banet_level_t* lv, const GatherPlan& pl, const float* R, const float* T, const float* Wc,
                   const int32_t* active, int active_stride, float* rec, float* partials, hipStream_t s);
+const float* finish_gather(const banet_level_t* lv, const GatherPlan& pl, const int32_t* active, int active_stride,
+                           float* partials, hipStream_t s);
 
 // ---- syrk.hip --------------------------------------------------------------------------
 struct SyrkPlan {

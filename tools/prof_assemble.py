@@ -11,7 +11,8 @@ from banet_amd import dense as bdense, ops, synth as bsynth  # noqa: E402
 from banet_amd.bundlenet import he_normal_lambda_weights  # noqa: E402
 
 B = int(os.environ.get("PB", "4"))
-H, W, C, K = 480, 640, 128, int(os.environ.get("PK", "128"))
+H, W = int(os.environ.get("PH", "480")), int(os.environ.get("PW", "640"))
+C, K = 128, int(os.environ.get("PK", "128"))
 only = os.environ.get("PONLY")
 dev = torch.device("cuda:0")
 intr, levels, gt = bsynth.make_dense_windows(B, H, W, C, K, [1], 5, dev, trans_mag=0.06)
@@ -22,7 +23,9 @@ R = torch.eye(3, device=dev).repeat(B, 1, 1)
 T = (gt["T"] * 0.7).reshape(B, 3, 1).to(dev)
 Wc = torch.zeros(B, max(K, 1), 1, device=dev)[:, :K]
 byts = ba.algorithmic_bytes_per_iteration(0) * B
-for bits, name in ((0, "full"), (1, "all taps -> texel(1,1)"), (4, "no depth dot"), (8, "no gather loop"), (12, "geometry only")):
+ALL = ((0, "full"), (32, "generic kernel"), (1, "all taps -> texel(1,1)"), (4, "no depth dot"), (8, "no gather loop"), (12, "geometry only"))
+sel = [int(x) for x in os.environ.get("PBITS", "0").split(",")]
+for bits, name in [a for a in ALL if a[0] in sel]:
     p.c.reserved_ = bits
     for _ in range(2):
         ops.ba_assemble(p, R, T, Wc if K else None)
@@ -37,6 +40,6 @@ for bits, name in ((0, "full"), (1, "all taps -> texel(1,1)"), (4, "no depth dot
     torch.cuda.synchronize()
     prof = ops.profile_end()
     ms = e0.elapsed_time(e1) / n
-    print("K=%d B=%d %-6s %8.1f us/launch  %7.1f us/window  %7.1f GB/s   kernels: %s" % (
-        K, B, name, ms * 1e3, ms * 1e3 / B, byts / ms / 1e6,
+    print("%dx%d K=%d B=%d %-6s %8.1f us/launch  %7.1f us/window  %7.1f GB/s   kernels: %s" % (
+        W, H, K, B, name, ms * 1e3, ms * 1e3 / B, byts / ms / 1e6,
         {("gather" if k > 0 else "syrk"): round(1e3 * v[1] / v[0] / B, 1) for k, v in prof.items()}))

@@ -30,15 +30,19 @@ for _ in range(3):
                                        capi.ptr(AtA), capi.ptr(Atb), capi.ptr(absres), capi.ptr(nvalid),
                                        ctypes.c_void_p(ws.data_ptr()), ws.numel(), capi.stream()))
 torch.cuda.synchronize()
-G = 256  # plan: min(groups/2, 1024/B) rounded to 8
-groups = (80 * 60 + 3) // 4
-G = min(groups // 2, (1024 + B - 1) // B) & ~7
-part = ws[:B * G * (32 + C) * 4].view(torch.float32).reshape(B, G, 32 + C)
+tiles = 80 * 60
+part = ws[:B * tiles * (32 + C) * 4].view(torch.float32).reshape(B, tiles, 32 + C)
 t = part[:, :, 28:32].reshape(-1, 4).cpu()
-batches = groups / G      # batches per wave
-print("G=%d batches/wave=%.2f" % (G, batches))
-names = ["loads+channel math", "butterfly merges", "depth dot", "whole batch"]
+names = ["16 gather steps", "rim+algebra+partials", "depth dot", "whole tile"]
 for i, nme in enumerate(names):
     v = t[:, i]
-    print("%-22s mean %10.0f cycles/wave   %8.0f cycles/batch   %7.1f cycles/pixel-pair-trip" % (
-        nme, v.mean(), v.mean() / batches, v.mean() / batches / 32))
+    print("%-22s mean %9.0f cycles/tile  (p10 %9.0f  p90 %9.0f)  %7.1f cycles/step" % (
+        nme, v.mean(), v.quantile(0.1), v.quantile(0.9), v.mean() / 16))
+e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    capi.check(L.banet_ba_assemble_f32(ctypes.byref(p.c), capi.ptr(R), capi.ptr(T), capi.ptr(Wc) if K else None,
+                                       capi.ptr(AtA), capi.ptr(Atb), capi.ptr(absres), capi.ptr(nvalid),
+                                       ctypes.c_void_p(ws.data_ptr()), ws.numel(), capi.stream()))
+e1.record(); torch.cuda.synchronize()
+print("assemble (gather+syrk+reduce) %.1f us per call" % (e0.elapsed_time(e1) * 100))
