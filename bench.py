@@ -129,7 +129,7 @@ def main():
     if rank == 0:
         iters_per_step = sum(ITERS)
         value = total_windows * iters_per_step * args.steps / elapsed
-        # roofline of the dominant kernel (ba_gather_kernel): algorithmic bytes of the pass it streams
+        # roofline of the dominant kernel (ba_gather128_kernel): algorithmic bytes of the pass it streams
         # / its measured time, summed over every launch of the timed region (all levels)
         alg_bytes, kern_ms, nlaunch, per_level, syrk_ms, syrk_n = 0.0, 0.0, 0, {}, 0.0, 0
         for li, p in enumerate(ba.problems):
@@ -164,7 +164,7 @@ def main():
                        "parallelism": "windows sharded, dp%d" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "ba_gather_kernel<VEC=2,CH=1,GRAD=0,KVEC=2,KCH=1>",
+                         "kernel": "ba_gather128_kernel<1>",
                          "launches": nlaunch, "avg_launch_us": round(1e3 * kern_ms / max(nlaunch, 1), 2),
                          "algorithmic_bytes_per_launch": round(alg_bytes / max(nlaunch, 1)),
                          "kernel_time_share": round(kern_ms / (1e3 * elapsed), 4),
