@@ -185,66 +185,6 @@ __device__ void qr_solve_small(float* A, int ld, float* rhs, int n, float* x) {
   }
 }
 
-// LU with partial pivoting on the augmented matrix [A | b] in LDS (tf.matrix_solve's algorithm
-// class, bundlenet.py:183,267).  Rows are pivoted LOGICALLY (perm[]), multipliers are not stored
-// (the right-hand side rides along as column n), so a step is: wave 0 picks the pivot -> barrier
-// -> all 256 threads update the trailing block -> barrier.  Back-substitution runs inside wave 0.
-__device__ void lu_solve(float* A, int ld, int n, float* x, int* perm, float* spiv) {
-  const int tid = threadIdx.x;
-  for (int i = tid; i < n; i += kSolveThreads) perm[i] = i;
-  __syncthreads();
-  for (int k = 0; k < n; ++k) {
-    if (tid < 64) {
-      float best = -1.f;
-      int br = k;
-      for (int r = k + tid; r < n; r += 64) {
-        const float v = fabsf(A[perm[r] * ld + k]);
-        if (v > best) {
-          best = v;
-          br = r;
-        }
-      }
-#pragma unroll
-      for (int sft = 32; sft >= 1; sft >>= 1) {
-        const float ob = __shfl_xor(best, sft, 64);
-        const int orr = __shfl_xor(br, sft, 64);
-        if (ob > best || (ob == best && orr < br)) {
-          best = ob;
-          br = orr;
-        }
-      }
-      if (tid == 0) {
-        const int pk = perm[br];
-        perm[br] = perm[k];
-        perm[k] = pk;
-        *spiv = 1.f / A[pk * ld + k];
-      }
-    }
-    __syncthreads();
-    const int p = perm[k];
-    const float inv = *spiv;
-    const int m = n - k - 1;   // logical rows below
-    const int cols = n - k;    // columns k+1 .. n (n = right-hand side)
-    for (int e = tid; e < m * cols; e += kSolveThreads) {
-      const int rr = e / cols;
-      const int i = perm[k + 1 + rr], j = k + 1 + (e - rr * cols);
-      A[i * ld + j] = fmaf(-(A[i * ld + k] * inv), A[p * ld + j], A[i * ld + j]);
-    }
-    __syncthreads();
-  }
-  // back substitution (U's row k is physical row perm[k]), wave 0 only
-  if (tid < 64) {
-    for (int k = n - 1; k >= 0; --k) {
-      const float* row = A + perm[k] * ld;
-      float part = 0.f;
-      for (int j = k + 1 + tid; j < n; j += 64) part = fmaf(row[j], x[j], part);
-      const float tot = wave_sum_fast(part);
-      if (tid == 0) x[k] = (row[n] - tot) / row[k];
-    }
-  }
-  __syncthreads();
-}
-
 // Register-resident LU with partial pivoting for n <= 16*NR - 1: the augmented matrix is
 // distributed 2-D cyclically over the 16x16 thread grid (thread (ti,tj) owns rows ti+16r, columns
 // tj+16c), so the trailing update runs out of registers.  Per elimination step: owners publish
@@ -351,100 +291,172 @@ __device__ void lu_solve_regs(float* A, int ld, int n, float* x, int* order, flo
   __syncthreads();
 }
 
-// Symmetric elimination (Cholesky-class, no pivot search) of the damped normal matrix, register
-// resident like lu_solve_regs.  AtA + damping is symmetric positive definite whenever the solve is
-// meaningful, so eliminating in natural order is stable and needs ONE barrier per column: owners
-// publish column k (= row k by symmetry) and the k-th right-hand-side entry, then every thread
-// applies  a_ij -= a_ik a_jk / a_kk  to its register tile (both triangles: the tile stays exactly
-// symmetric).  Same solution as the reference's pivoted LU (tf.matrix_solve) up to rounding --
-// checked at 1e-4 by the parity tests.  Back-substitution: wave 0, x kept in registers.
-template <int NR>
-__device__ void sym_solve_regs(float* A, int ld, int n, float* x, float* colbuf /*[2][16*NR + 16]*/,
-                               float* dinv /*[16*NR]: reciprocal pivots*/) {
-  constexpr int CB = kGrid * NR + kGrid;
-  const int tid = threadIdx.x, ti = tid / kGrid, tj = tid % kGrid;
-  float a[NR][NR];
+// --------------------------------------------------------------------------------------
+// Blocked LDL^T for the bundle variants (32 <= n): the damped normal matrix is symmetric positive
+// definite (PSD Gram matrix + positive damping), so the pivoted LU of tf.matrix_solve
+// (bundlenet.py:267) reduces to elimination in natural order; same solution up to rounding
+// (checked at 1e-4 by the parity tests).  Storage: lower triangle of A in rows 0..n-1, the right-hand
+// side as ROW n -- eliminating it like any other row leaves w = D^-1 L^-1 b there, the right-hand
+// side of the back substitution L^T x = w.  Right-looking, 16 columns per panel:
+//   A  wave 0 factors the 16x16 diagonal block in registers (lane = row, pivot rows broadcast with
+//      v_readlane) and publishes U11 and the reciprocal pivots;
+//   B  one thread per remaining row eliminates its 16 panel entries against U11 (broadcast LDS
+//      reads), keeps the multipliers in place and the unscaled entries d_j l_ij as W^T;
+//   C  trailing update A22 -= L21 W (lower triangle + rhs row), one 4x4 register tile per thread.
+// 3 barriers per panel instead of one per column, and no redundant upper-triangle work.
+// --------------------------------------------------------------------------------------
+constexpr int kPanel = 16;
+
+__host__ __device__ inline int ldlt_ld(int n) {  // row stride: >= round16(n), odd multiple of 4 (conflict-free b128 by row)
+  int ld = ((n + 15) & ~15) + 4;
+  while ((ld & 7) != 4) ld += 4;
+  return ld;
+}
+__host__ __device__ inline int ldlt_ldw(int n) { return ((n + 1 + 3) & ~3) + 4; }   // W^T row stride
+
+__device__ __forceinline__ float rdlane(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+__device__ void ldlt_solve_blocked(float* A, int ld, int n, float* x, float* scratch /* >= 16*ldw + 272 floats */) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int m = n + 1;                 // rows including the right-hand side
+  const int ldw = ldlt_ldw(n);
+  float* sWT = scratch;                // [16][ldw]
+  float* sU = sWT + kPanel * ldw;      // [16][16]  upper part of the factored diagonal block
+  float* sDinv = sU + kPanel * kPanel; // [16]
+  for (int k0 = 0; k0 < n; k0 += kPanel) {
+    const int nb = min(kPanel, n - k0);
+    // ---- A: diagonal block (wave 0) ------------------------------------------------------
+    if (tid < 64) {
+      const int row = lane & 15;
+      float a[kPanel];
 #pragma unroll
-  for (int r = 0; r < NR; ++r)
+      for (int c = 0; c < kPanel; ++c) {
+        const bool in = row < nb && c < nb;
+        const int r = k0 + row, cc = k0 + c;
+        const int idx = in ? (c <= row ? r * ld + cc : cc * ld + r) : 0;   // symmetric read from the lower triangle
+        const float v = A[idx];
+        a[c] = in ? v : (c == row ? 1.f : 0.f);                          // identity padding of a partial panel
+      }
+      float myinv = 1.f;
 #pragma unroll
-    for (int c = 0; c < NR; ++c) {
-      const int i = ti + kGrid * r, j = tj + kGrid * c;
-      a[r][c] = (i < n && j <= n) ? A[i * ld + j] : 0.f;
+      for (int j = 0; j < kPanel; ++j) {
+        const float inv = __builtin_amdgcn_rcpf(rdlane(a[j], j));        // v_rcp_f32: <= 1 ulp
+        if (row == j) myinv = inv;
+        const float l = row > j ? a[j] * inv : 0.f;
+#pragma unroll
+        for (int c = j + 1; c < kPanel; ++c) a[c] = fmaf(-l, rdlane(a[c], j), a[c]);
+        a[j] = row > j ? l : a[j];
+      }
+      if (lane < kPanel) {
+        sDinv[row] = myinv;
+#pragma unroll
+        for (int c = 0; c < kPanel; ++c) {
+          if (c <= row) {
+            if (row < nb && c < nb) A[(k0 + row) * ld + k0 + c] = a[c];
+          } else {
+            sU[row * kPanel + c] = a[c];
+          }
+        }
+      }
     }
-  STICK(ts0);
-  const int nown_c = n / kGrid, nown_t = n % kGrid;  // the right-hand side (column n) lives at tile column n>>4 of threads tj == n&15
+    __syncthreads();
+    // ---- B: panel rows below the block ---------------------------------------------------
+    const int base = k0 + nb, mrem = m - base;
+    for (int t = tid; t < mrem; t += kSolveThreads) {
+      float* rowp = A + (base + t) * ld + k0;
+      float a[kPanel];
 #pragma unroll
-  for (int c0 = 0; c0 < NR; ++c0) {
-    for (int kk = 0; kk < kGrid; ++kk) {
-      const int k = kGrid * c0 + kk;
-      if (k >= n) break;  // uniform
-      float* cb = colbuf + (k & 1) * CB;
-      if (tj == kk) {  // column k of every owned row
-#pragma unroll
-        for (int r = 0; r < NR; ++r) cb[ti + kGrid * r] = a[r][c0];
-      }
-      if (ti == kk && tj == nown_t) {  // b_k = element (k, n)
-        float v = a[c0][0];
-#pragma unroll
-        for (int c = 1; c < NR; ++c) v = (c == nown_c) ? a[c0][c] : v;
-        cb[kGrid * NR] = v;
-      }
-      __syncthreads();
-      const float sinv = __builtin_amdgcn_rcpf(cb[k]);   // v_rcp_f32: <= 1 ulp, same order as the fmas' rounding
-      const float bk = cb[kGrid * NR];
-      if (tid == 0) dinv[k] = sinv;
-      float lm[NR], cj[NR];
-#pragma unroll
-      for (int r = c0; r < NR; ++r) {                    // tile rows r < c0 hold only rows <= k: finished
-        const int i = ti + kGrid * r;
-        lm[r] = (i > k && i < n) ? -(cb[i] * sinv) : 0.f;
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(rowp + 4 * q);
+        a[4 * q + 0] = (4 * q + 0 < nb) ? v.x : 0.f;
+        a[4 * q + 1] = (4 * q + 1 < nb) ? v.y : 0.f;
+        a[4 * q + 2] = (4 * q + 2 < nb) ? v.z : 0.f;
+        a[4 * q + 3] = (4 * q + 3 < nb) ? v.w : 0.f;
       }
 #pragma unroll
-      for (int c = c0; c < NR; ++c) {
-        const int j = tj + kGrid * c;
-        cj[c] = (j > k && j < n) ? cb[j] : ((j == n) ? bk : 0.f);
+      for (int j = 0; j < kPanel; ++j) {
+        sWT[j * ldw + t] = a[j];                        // d_j l_ij
+        const float l = a[j] * sDinv[j];
+        a[j] = l;
+#pragma unroll
+        for (int c = j + 1; c < kPanel; ++c) a[c] = fmaf(-l, sU[j * kPanel + c], a[c]);
       }
 #pragma unroll
-      for (int c = c0; c < NR; ++c)
-#pragma unroll
-        for (int r = c0; r < NR; ++r) a[r][c] = fmaf(lm[r], cj[c], a[r][c]);
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(rowp + 4 * q) = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
     }
+    __syncthreads();
+    // ---- C: trailing update, 4x4 tiles of the lower triangle ---------------------------------
+    const int mt = (mrem + 3) >> 2, ntiles = mt * (mt + 1) / 2;
+    for (int t = tid; t < ntiles; t += kSolveThreads) {
+      int I4 = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+      while ((I4 + 1) * (I4 + 2) / 2 <= t) ++I4;
+      while (I4 * (I4 + 1) / 2 > t) --I4;
+      const int C4 = t - I4 * (I4 + 1) / 2;
+      float acc[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = 0.f;
+      const float* Lp = A + (base + 4 * I4) * ld + k0;
+      const float* Wp = sWT + 4 * C4;
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4) {
+        float4 Lr[4], Wj[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Lr[r] = *reinterpret_cast<const float4*>(Lp + r * ld + 4 * j4);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) Wj[jj] = *reinterpret_cast<const float4*>(Wp + (4 * j4 + jj) * ldw);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float lr[4] = {Lr[r].x, Lr[r].y, Lr[r].z, Lr[r].w};
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            acc[r][0] = fmaf(lr[jj], Wj[jj].x, acc[r][0]);
+            acc[r][1] = fmaf(lr[jj], Wj[jj].y, acc[r][1]);
+            acc[r][2] = fmaf(lr[jj], Wj[jj].z, acc[r][2]);
+            acc[r][3] = fmaf(lr[jj], Wj[jj].w, acc[r][3]);
+          }
+        }
+      }
+      float* Cp = A + (base + 4 * I4) * ld + base + 4 * C4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float4 cv = *reinterpret_cast<float4*>(Cp + r * ld);
+        cv.x -= acc[r][0];
+        cv.y -= acc[r][1];
+        cv.z -= acc[r][2];
+        cv.w -= acc[r][3];
+        *reinterpret_cast<float4*>(Cp + r * ld) = cv;
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
+  // ---- back substitution L^T x = w (wave 0), panels from the last to the first ---------------
+  if (tid < 64) {
+    const int li = lane & 15, part = lane >> 4;
+    const int npan = (n + kPanel - 1) / kPanel;
+    for (int p = npan - 1; p >= 0; --p) {
+      const int k0 = p * kPanel, nb = min(kPanel, n - k0), base = k0 + nb;
+      // t_l = w_l - sum_{j >= base} L[j][k0 + l] x_j : 4 interleaved slices of j, one per 16-lane row
+      float tsum = 0.f;
+      if (li < nb)
+        for (int j = base + part; j < n; j += 4) tsum = fmaf(A[j * ld + k0 + li], x[j], tsum);
+      tsum += __shfl_xor(tsum, 16, 64);
+      tsum += __shfl_xor(tsum, 32, 64);
+      float tl = (li < nb ? A[n * ld + k0 + li] : 0.f) - tsum;
+      float col[kPanel];   // column l of the block's unit lower triangle: L[k0 + i][k0 + l], i > l
 #pragma unroll
-  for (int r = 0; r < NR; ++r)
+      for (int i = 0; i < kPanel; ++i) col[i] = (i > li && i < nb) ? A[(k0 + i) * ld + k0 + li] : 0.f;
 #pragma unroll
-    for (int c = 0; c < NR; ++c) {
-      const int i = ti + kGrid * r, j = tj + kGrid * c;
-      if (i < n && j <= n) A[i * ld + j] = a[r][c];
-    }
-  __syncthreads();
-#ifdef BANET_TIMING
-  STICK(ts1);
-  if (tid == 0) colbuf[2 * CB] = (float)(ts1 - ts0);
-#endif
-  if (tid < 64) {  // back substitution on the upper triangle; lane l keeps x_l, x_{l+64}, x_{l+128}
-    constexpr int XR = (kGrid * NR + 63) / 64;
-    float xr[XR];
-#pragma unroll
-    for (int u = 0; u < XR; ++u) xr[u] = 0.f;
-    for (int k = n - 1; k >= 0; --k) {
-      const float* row = A + k * ld;
-      float part = 0.f;
-#pragma unroll
-      for (int u = 0; u < XR; ++u) {
-        const int j = tid + 64 * u;
-        if (j > k && j < n) part = fmaf(row[j], xr[u], part);
+      for (int i = kPanel - 1; i >= 1; --i) {
+        const float xi = rdlane(tl, i);      // final once rows > i have been applied
+        tl = fmaf(-col[i], xi, tl);
       }
-      const float tot = wave_sum_fast(part);
-      const float xk = (row[n] - tot) * dinv[k];
-#pragma unroll
-      for (int u = 0; u < XR; ++u)
-        if (tid + 64 * u == k) xr[u] = xk;
+      if (lane < nb) x[k0 + lane] = tl;
     }
-#pragma unroll
-    for (int u = 0; u < XR; ++u)
-      if (tid + 64 * u < n) x[tid + 64 * u] = xr[u];
   }
   __syncthreads();
 }
@@ -486,9 +498,12 @@ __device__ void rodrigues(const float w[3], bool clamp, float Rw[9], float V[9])
 __global__ __launch_bounds__(kSolveThreads) void ba_solve_update_kernel(const SolveArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int P = a.P, C = a.C, K = a.K, ld = P + 2;
-  float* sA = smem;                 // [P][ld] augmented
-  float* sX = sA + ((P * ld + 3) & ~3);  // [P]  (every carve offset a multiple of 4 floats: float4 LDS accesses)
+  const int P = a.P, C = a.C, K = a.K;
+  const bool blocked = P >= kGrid;                   // bundle variants: blocked LDL^T, rhs stored as row P
+  const int ld = blocked ? ldlt_ld(P) : P + 2;
+  const int arows = blocked ? P + 4 : P;
+  float* sA = smem;                 // [arows][ld] augmented
+  float* sX = sA + ((arows * ld + 3) & ~3);  // [P]  (every carve offset a multiple of 4 floats: float4 LDS accesses)
   float* sH0 = sX + ((P + 3) & ~3); // MLP ping
   float* sH1 = sH0 + 4 * C;         // MLP pong
   float* sAvg = sH1 + 4 * C;        // [C]
@@ -564,7 +579,7 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve_update_kernel(const So
     if (i == j && !(a.variant == BANET_BUNDLE && i == P - 1)) v = v + (v + 1e-5f) * lam;
     sA[i * ld + j] = v;
   }
-  for (int i = tid; i < P; i += kSolveThreads) sA[i * ld + P] = a.Atb[(size_t)b * P + i];
+  for (int i = tid; i < P; i += kSolveThreads) sA[blocked ? P * ld + i : i * ld + P] = a.Atb[(size_t)b * P + i];
   __syncthreads();
   STICK(tk2);
   // ---- solve --------------------------------------------------------------------------
@@ -579,14 +594,8 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve_update_kernel(const So
     float* sCol = sPart;                // the MLP scratch is free by now (4096 floats)
     if (P <= kGrid - 1) {               // pose-only variants: pivoted LU as tf.matrix_solve
       lu_solve_regs<1>(sA, ld, P, sX, sPerm, sCol, sCol + 2 * kGrid, reinterpret_cast<int*>(sCol + 3 * kGrid), sScal);
-    } else if (P <= 2 * kGrid - 1) {
-      sym_solve_regs<2>(sA, ld, P, sX, sCol, sCol + 2048);
-    } else if (P <= 3 * kGrid - 1) {
-      sym_solve_regs<3>(sA, ld, P, sX, sCol, sCol + 2048);
-    } else if (P <= 5 * kGrid - 1) {
-      sym_solve_regs<5>(sA, ld, P, sX, sCol, sCol + 2048);
     } else {
-      lu_solve(sA, ld, P, sX, sPerm, sScal);
+      ldlt_solve_blocked(sA, ld, P, sX, sCol);
     }
   }
   STICK(tk3);
@@ -631,7 +640,7 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve_update_kernel(const So
     dp[1] = (float)(tk2 - tk1);  // accept logic + damping/load
     dp[2] = (float)(tk3 - tk2);  // LU + back substitution
     dp[3] = (float)(tk4 - tk3);  // update
-    dp[4] = sPart[2 * (kGrid * 5 + kGrid)];  // elimination only (P in 96..159)
+    dp[4] = 0.f;
   }
 #endif
 }
@@ -653,7 +662,9 @@ __global__ void zero_iters_kernel(int32_t* iters, int B) {
 }
 
 size_t solve_lds_bytes(int P, int C) {
-  const size_t fl = (size_t)(((P * (P + 2)) + 3) & ~3) + ((P + 3) & ~3) + 8 * C + ((C + 3) & ~3) + 24 + 4096 + P + 8;
+  const bool blocked = P >= kGrid;
+  const int ld = blocked ? ldlt_ld(P) : P + 2, arows = blocked ? P + 4 : P;
+  const size_t fl = (size_t)((arows * ld + 3) & ~3) + ((P + 3) & ~3) + 8 * C + ((C + 3) & ~3) + 24 + 4096 + P + 8;
   return fl * sizeof(float);
 }
 

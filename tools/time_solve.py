@@ -18,3 +18,9 @@ torch.cuda.synchronize()
 d = st.delta[:, :5].cpu()
 for i, n in enumerate(["avg+MLP", "accept+damp/load", "LU+backsub", "update", "  elimination only"]):
     print("%-18s %10.0f cycles  (%.1f us @2.3GHz)" % (n, d[:, i].mean(), d[:, i].mean() / 2300))
+e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    ops.ba_solve_update(p, ba.mlps[0], 1000.0, *out, st)
+e1.record(); torch.cuda.synchronize()
+print("solve launch: %.1f us" % (e0.elapsed_time(e1) * 50))
