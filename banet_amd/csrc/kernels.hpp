@@ -30,6 +30,7 @@ const float* finish_gather(const banet_level_t* lv, const GatherPlan& pl, const 
 // ---- syrk.hip --------------------------------------------------------------------------
 struct SyrkPlan {
   int Gs, tiles, pstride, nb;
+  int direct;   // 1: ba_syrk_direct_kernel (K = 64 / 128), 0: the LDS-tiled kernel
   size_t partial_bytes;
 };
 int plan_syrk(int B, int N, int K, SyrkPlan* pl);

@@ -325,8 +325,13 @@ __device__ void ldlt_solve_blocked(float* A, int ld, int n, float* x, float* scr
   float* sWT = scratch;                // [16][ldw]
   float* sU = sWT + kPanel * ldw;      // [16][16]  upper part of the factored diagonal block
   float* sDinv = sU + kPanel * kPanel; // [16]
+#ifdef BANET_TIMING
+  __shared__ float sDbg[4];
+  float dA = 0.f, dB = 0.f, dC = 0.f;
+#endif
   for (int k0 = 0; k0 < n; k0 += kPanel) {
     const int nb = min(kPanel, n - k0);
+    STICK(pa);
     // ---- A: diagonal block (wave 0) ------------------------------------------------------
     if (tid < 64) {
       const int row = lane & 15;
@@ -362,6 +367,7 @@ __device__ void ldlt_solve_blocked(float* A, int ld, int n, float* x, float* scr
       }
     }
     __syncthreads();
+    STICK(pb);
     // ---- B: panel rows below the block ---------------------------------------------------
     const int base = k0 + nb, mrem = m - base;
     for (int t = tid; t < mrem; t += kSolveThreads) {
@@ -388,6 +394,7 @@ __device__ void ldlt_solve_blocked(float* A, int ld, int n, float* x, float* scr
         *reinterpret_cast<float4*>(rowp + 4 * q) = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
     }
     __syncthreads();
+    STICK(pc);
     // ---- C: trailing update, 4x4 tiles of the lower triangle ---------------------------------
     const int mt = (mrem + 3) >> 2, ntiles = mt * (mt + 1) / 2;
     for (int t = tid; t < ntiles; t += kSolveThreads) {
@@ -433,7 +440,16 @@ __device__ void ldlt_solve_blocked(float* A, int ld, int n, float* x, float* scr
       }
     }
     __syncthreads();
+#ifdef BANET_TIMING
+    {
+      STICK(pd);
+      dA += (float)(pb - pa);
+      dB += (float)(pc - pb);
+      dC += (float)(pd - pc);
+    }
+#endif
   }
+  STICK(pe);
   // ---- back substitution L^T x = w (wave 0), panels from the last to the first ---------------
   if (tid < 64) {
     const int li = lane & 15, part = lane >> 4;
@@ -442,8 +458,20 @@ __device__ void ldlt_solve_blocked(float* A, int ld, int n, float* x, float* scr
       const int k0 = p * kPanel, nb = min(kPanel, n - k0), base = k0 + nb;
       // t_l = w_l - sum_{j >= base} L[j][k0 + l] x_j : 4 interleaved slices of j, one per 16-lane row
       float tsum = 0.f;
-      if (li < nb)
-        for (int j = base + part; j < n; j += 4) tsum = fmaf(A[j * ld + k0 + li], x[j], tsum);
+      {
+        const float* Lc = A + k0 + (li < nb ? li : 0);
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+        int j = base + part;
+        for (; j + 12 < n; j += 16) {   // 4 independent loads in flight per lane
+          const float l0 = Lc[j * ld], l1 = Lc[(j + 4) * ld], l2 = Lc[(j + 8) * ld], l3 = Lc[(j + 12) * ld];
+          t0 = fmaf(l0, x[j], t0);
+          t1 = fmaf(l1, x[j + 4], t1);
+          t2 = fmaf(l2, x[j + 8], t2);
+          t3 = fmaf(l3, x[j + 12], t3);
+        }
+        for (; j < n; j += 4) t0 = fmaf(Lc[j * ld], x[j], t0);
+        tsum = li < nb ? (t0 + t1) + (t2 + t3) : 0.f;
+      }
       tsum += __shfl_xor(tsum, 16, 64);
       tsum += __shfl_xor(tsum, 32, 64);
       float tl = (li < nb ? A[n * ld + k0 + li] : 0.f) - tsum;
@@ -459,6 +487,19 @@ __device__ void ldlt_solve_blocked(float* A, int ld, int n, float* x, float* scr
     }
   }
   __syncthreads();
+#ifdef BANET_TIMING
+  {
+    STICK(pf);
+    if (tid == 0) {
+      sDbg[0] = dA;
+      sDbg[1] = dB;
+      sDbg[2] = dC;
+      sDbg[3] = (float)(pf - pe);
+      x[n + 0] = dA; x[n + 1] = dB; x[n + 2] = dC; x[n + 3] = (float)(pf - pe);
+    }
+    __syncthreads();
+  }
+#endif
 }
 
 __device__ void rodrigues(const float w[3], bool clamp, float Rw[9], float V[9]) {
@@ -640,7 +681,7 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve_update_kernel(const So
     dp[1] = (float)(tk2 - tk1);  // accept logic + damping/load
     dp[2] = (float)(tk3 - tk2);  // LU + back substitution
     dp[3] = (float)(tk4 - tk3);  // update
-    dp[4] = 0.f;
+    dp[4] = sX[P]; dp[5] = sX[P + 1]; dp[6] = sX[P + 2]; dp[7] = sX[P + 3];
   }
 #endif
 }

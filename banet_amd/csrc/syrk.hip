@@ -204,6 +204,156 @@ __global__ __launch_bounds__(kBlock, 2) void ba_syrk_kernel(const SyrkArgs a) {
 }
 
 // --------------------------------------------------------------------------------------
+// ba_syrk_direct_kernel -- K = 64 KH (the reference's K = 128 is KH = 2): the same sums without LDS
+// and without workgroup barriers.  A wave owns a contiguous run of pixel quads and ALL 16x16
+// blocks of the upper triangle (36 for K = 128: 144 accumulator registers).  Lane (m, kq) of a
+// quad loads pixel 4q + kq's coefficients {4m..4m+3} + 64h as 16-byte loads (a wave instruction =
+// 4 x 256 contiguous bytes) and uses every loaded value as the A operand (scaled by s_n) of one
+// "virtual" block row and the B operand of one virtual block column: virtual block i' holds the
+// coefficients 64 (i' >> 2) + 4 m + (i' & 3), m = 0..15 -- a permutation that is undone when the
+// partial is written.  Loads run one batch of quads ahead of the matrix cores (register double
+// buffer); H_cd / Atb_d are packed-fp32 FMAs issued in the shadow of the MFMAs.
+// --------------------------------------------------------------------------------------
+constexpr int kSyrkBatch = 4;
+
+template <int KH>
+__global__ __launch_bounds__(kBlock, 1) void ba_syrk_direct_kernel(const SyrkArgs a) {
+  constexpr int NBV = 4 * KH, NPAIR = NBV * (NBV + 1) / 2, K = 64 * KH, NV = 4 * KH;
+  __shared__ float sAcc[NPAIR + NBV][4][64];
+  const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  if (a.active != nullptr && a.active[(size_t)b * a.active_stride] == 0) return;
+  const int w = wave_id();
+  const int N = a.N;
+  const int m = lane & 15, kq = lane >> 4;
+  const float* __restrict__ bas_b = a.basis + (size_t)b * N * K;
+  const float* __restrict__ rec_b = a.rec + (size_t)b * N * 8;
+  // record word this lane feeds to the H_cd / Atb_d block row: rows 0..5 = u0..u5, row 6 = r
+  const int uword = m < 6 ? m : 7;
+
+  f32x4 acc[NPAIR];   // H_dd, upper triangle of virtual blocks
+  f32x4 acu[NBV];     // rows 0..6: H_cd (6) and Atb_d (1) against every virtual block column
+#pragma unroll
+  for (int q = 0; q < NPAIR; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < NBV; ++q) acu[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // this wave's run of quads
+  const int nq = (N + 3) >> 2, nwaves = a.Gs * kNumWaves, gw = g * kNumWaves + w;
+  const int q0 = (int)(((long long)nq * gw) / nwaves), q1 = (int)(((long long)nq * (gw + 1)) / nwaves);
+
+  // register double buffer, kSyrkBatch quads per batch: the loads of batch t+1 are issued (and pinned
+  // with a scheduling barrier) before batch t is multiplied, so they have a whole batch of MFMAs
+  // (kSyrkBatch x 44 x 32 cycles) to arrive
+  struct Batch {
+    f32x4 pb[kSyrkBatch][KH];
+    float ps[kSyrkBatch], pu[kSyrkBatch];
+  };
+  auto issue = [&](Batch& B_, int q) __attribute__((always_inline)) {
+#pragma unroll
+    for (int d = 0; d < kSyrkBatch; ++d) {
+      const int pix = 4 * (q + d) + kq;
+      const size_t p = (q + d < q1 && pix < N) ? (size_t)pix : 0;
+#pragma unroll
+      for (int h = 0; h < KH; ++h)
+        B_.pb[d][h] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(bas_b + p * K + 64 * h + 4 * m));
+      B_.ps[d] = rec_b[p * 8 + 6];
+      B_.pu[d] = rec_b[p * 8 + uword];
+    }
+  };
+  auto consume = [&](const Batch& B_, int q) __attribute__((always_inline)) {
+#pragma unroll
+    for (int d = 0; d < kSyrkBatch; ++d) {
+      const bool ok = q + d < q1 && 4 * (q + d) + kq < N;
+      const float sv = ok ? B_.ps[d] : 0.f;                 // zero records switch the pixel off
+      const float uv = (ok && m < 7) ? B_.pu[d] : 0.f;
+      float bv[NV], av[NV];
+#pragma unroll
+      for (int h = 0; h < KH; ++h)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          bv[4 * h + e] = B_.pb[d][h][e];
+          av[4 * h + e] = sv * B_.pb[d][h][e];
+        }
+      int idx = 0;
+#pragma unroll
+      for (int bi = 0; bi < NBV; ++bi)
+#pragma unroll
+        for (int bj = bi; bj < NBV; ++bj) {
+          acc[idx] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[bi], bv[bj], acc[idx], 0, 0, 0);
+          ++idx;
+        }
+#pragma unroll
+      for (int bj = 0; bj < NBV; ++bj) acu[bj] = __builtin_amdgcn_mfma_f32_16x16x4f32(uv, bv[bj], acu[bj], 0, 0, 0);
+    }
+  };
+#ifdef BANET_TIMING
+  unsigned long long tm0, tr0;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm0), "=s"(tr0)::"memory");
+#endif
+  Batch R0, R1;
+  issue(R0, q0);
+  for (int q = q0; q < q1; q += 2 * kSyrkBatch) {
+    issue(R1, q + kSyrkBatch);
+    __builtin_amdgcn_sched_barrier(0);   // the scheduler would otherwise sink the loads next to their use
+    consume(R0, q);
+    __builtin_amdgcn_sched_barrier(0);
+    issue(R0, q + 2 * kSyrkBatch);
+    __builtin_amdgcn_sched_barrier(0);
+    consume(R1, q + kSyrkBatch);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+#ifdef BANET_TIMING
+  unsigned long long tm1, tr1;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm1), "=s"(tr1)::"memory");
+#endif
+  // ---- epilogue: add the 4 waves in fixed order through LDS, un-permute, publish ---------------
+  for (int ww = 0; ww < kNumWaves; ++ww) {
+    if (w == ww) {
+#pragma unroll
+      for (int q = 0; q < NPAIR; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sAcc[q][r][lane] = (ww == 0 ? 0.f : sAcc[q][r][lane]) + acc[q][r];
+#pragma unroll
+      for (int q = 0; q < NBV; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sAcc[NPAIR + q][r][lane] = (ww == 0 ? 0.f : sAcc[NPAIR + q][r][lane]) + acu[q][r];
+    }
+    __syncthreads();
+  }
+  float* __restrict__ part = a.partials + ((size_t)b * a.Gs + g) * a.pstride;
+  // thread (w, lane) publishes accumulator register r = w of every block: row 4 kq + r, column m
+  const int r = w, brow = 4 * kq + r;
+  if (brow < 7) {
+#pragma unroll
+    for (int bj = 0; bj < NBV; ++bj) part[brow * K + 64 * (bj >> 2) + 4 * m + (bj & 3)] = sAcc[NPAIR + bj][r][lane];
+  }
+#ifdef BANET_TIMING
+  __syncthreads();
+  if (tid == 0) {   // development aid (tools/time_syrk.py): overwrites 4 words of the partial
+    part[0] = (float)(tm1 - tm0);
+    part[1] = (float)(tr1 - tr0);
+    part[2] = (float)(q1 - q0);
+  }
+  return;
+#endif
+  float* pd = part + 7 * K;
+  {
+    int idx = 0;
+    for (int bi = 0; bi < NBV; ++bi)
+      for (int bj = bi; bj < NBV; ++bj) {
+        const int rr = 64 * (bi >> 2) + 4 * brow + (bi & 3), cc = 64 * (bj >> 2) + 4 * m + (bj & 3);
+        const float v = sAcc[idx][r][lane];
+        if (bj > bi || rr <= cc) {
+          pd[rr * K + cc] = v;
+          pd[cc * K + rr] = v;
+        }
+        ++idx;
+      }
+  }
+}
+
+// --------------------------------------------------------------------------------------
 // fixed-order reduction of the per-workgroup partials of both kernels into AtA / Atb / |r| / nvalid
 // (the deterministic counterpart of utils.cu:181-198 ColumnReduceSimpleKernel)
 // --------------------------------------------------------------------------------------
@@ -296,8 +446,9 @@ int plan_syrk(int B, int N, int K, SyrkPlan* pl) {
     return BANET_OK;
   }
   pl->tiles = (N + kTilePix - 1) / kTilePix;
-  int target = (512 + B - 1) / B;   // 2 resident workgroups per CU
-  int G = pl->tiles / 4;
+  pl->direct = (K == 64 || K == 128) ? 1 : 0;   // ba_syrk_direct_kernel: one wave per SIMD, 256 workgroups in all
+  int target = ((pl->direct ? 256 : 512) + B - 1) / B;   // LDS kernel: 2 resident workgroups per CU
+  int G = pl->direct ? (N + 4 * 4 * 16 - 1) / (4 * 4 * 16) : pl->tiles / 4;   // direct: >= 16 quads per wave
   if (G > target) G = target;
   if (G < 1) G = 1;
   pl->Gs = G;
@@ -321,6 +472,13 @@ static void launch_syrk_nb(const SyrkArgs& a, int B, hipStream_t s) {
 int launch_syrk(const float* basis, const float* rec, int B, int N, int K, const SyrkPlan& pl, const int32_t* active,
                 int active_stride, float* partials, hipStream_t s) {
   SyrkArgs a{basis, rec, active, active_stride, partials, N, K, pl.Gs, pl.tiles, pl.pstride};
+  if (pl.direct) {
+    if (K == 128)
+      hipLaunchKernelGGL(ba_syrk_direct_kernel<2>, dim3(a.Gs, B), dim3(kBlock), 0, s, a);
+    else
+      hipLaunchKernelGGL(ba_syrk_direct_kernel<1>, dim3(a.Gs, B), dim3(kBlock), 0, s, a);
+    return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;
+  }
   switch (pl.nb) {
     case 1: launch_syrk_nb<1>(a, B, s); break;
     case 2: launch_syrk_nb<2>(a, B, s); break;

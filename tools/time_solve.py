@@ -15,8 +15,8 @@ out = ops.ba_assemble(p, st.R, st.T, st.Wc)
 for _ in range(3):
     ops.ba_solve_update(p, ba.mlps[0], 1000.0, *out, st)
 torch.cuda.synchronize()
-d = st.delta[:, :5].cpu()
-for i, n in enumerate(["avg+MLP", "accept+damp/load", "LU+backsub", "update", "  elimination only"]):
+d = st.delta[:, :8].cpu()
+for i, n in enumerate(["avg+MLP", "accept+damp/load", "LU+backsub", "update", "  A diag blocks", "  B panel rows", "  C trailing", "  back-subst"]):
     print("%-18s %10.0f cycles  (%.1f us @2.3GHz)" % (n, d[:, i].mean(), d[:, i].mean() / 2300))
 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
 e0.record()
