@@ -11,6 +11,8 @@ static int check_level(const banet_level_t* lv) {
   if (lv->variant < BANET_LEGACY_LM || lv->variant > BANET_BUNDLE) return BANET_ERR_INVALID_ARG;
   if (lv->K > 0 && !lv->basis) return BANET_ERR_INVALID_ARG;
   if ((lv->variant == BANET_BUNDLE) != (lv->K > 0)) return BANET_ERR_INVALID_ARG;
+  if (lv->pairs < 0 || lv->pad_ != 0) return BANET_ERR_INVALID_ARG;
+  if (lv->pairs > 1 && lv->variant != BANET_BUNDLE && lv->variant != BANET_BUNDLE_CAMERA) return BANET_ERR_INVALID_ARG;
   if (lv->dense) {
     if (!lv->intr || !(lv->scale > 0.f)) return BANET_ERR_INVALID_ARG;
   } else {
@@ -55,7 +57,8 @@ static SolveArgs make_solve_args(const banet_level_t* lv, const banet_mlp_t* mlp
   a.N = lv->N;
   a.C = lv->C;
   a.K = lv->K;
-  a.P = 6 + lv->K;
+  a.pairs = npairs(lv);
+  a.P = 6 * a.pairs + lv->K;
   a.variant = lv->variant;
   a.l2_base = l2_base;
   a.max_iters = 0;
@@ -150,7 +153,8 @@ int banet_ba_solve_update_f32(const banet_level_t* lv, const banet_mlp_t* mlp, f
                               const float* Atb, const float* absres, const float* nvalid, banet_state_t* st,
                               banet_stream_t stream) {
   if (!lv || !AtA || !Atb || !absres || !nvalid) return BANET_ERR_INVALID_ARG;
-  if (lv->variant < BANET_LEGACY_LM || lv->variant > BANET_BUNDLE || lv->B <= 0 || lv->N <= 0 || lv->C <= 0 || lv->K < 0)
+  if (lv->variant < BANET_LEGACY_LM || lv->variant > BANET_BUNDLE || lv->B <= 0 || lv->N <= 0 || lv->C <= 0 || lv->K < 0 ||
+      lv->pairs < 0)
     return BANET_ERR_INVALID_ARG;
   const int rc = check_state(lv, mlp, st);
   if (rc != BANET_OK) return rc;

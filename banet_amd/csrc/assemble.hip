@@ -72,9 +72,9 @@ int profile_end(int max_tags, int32_t* tag_points, int32_t* tag_launches, double
 int plan_assemble(const banet_level_t* lv, AsmPlan* pl) {
   int rc = plan_gather(lv, &pl->g);
   if (rc != BANET_OK) return rc;
-  rc = plan_syrk(lv->B, lv->N, lv->K, &pl->s);
+  rc = plan_syrk(lv->B, lv->N, lv->K, npairs(lv), &pl->s);
   if (rc != BANET_OK) return rc;
-  pl->P = 6 + lv->K;
+  pl->P = 6 * npairs(lv) + lv->K;
   pl->off_rec = pl->g.partial_bytes;
   pl->off_spart = pl->off_rec + pl->g.rec_bytes;
   pl->ws_bytes = pl->off_spart + pl->s.partial_bytes;
@@ -99,11 +99,11 @@ int launch_assemble(const banet_level_t* lv, const AsmPlan& pl, const float* R, 
   const float* gred = finish_gather(lv, pl.g, active, active_stride, gpart, s);
   if (lv->K > 0) {
     Timed t(s, -lv->N);
-    rc = launch_syrk(lv->basis, rec, lv->B, lv->N, lv->K, pl.s, active, active_stride, spart, s);
+    rc = launch_syrk(lv->basis, rec, lv->B, lv->N, lv->K, npairs(lv), pl.s, active, active_stride, spart, s);
     if (rc != BANET_OK) return rc;
   }
   launch_reduce2(gred, pl.g.frows, pl.g.pstride, spart, pl.s.Gs, pl.s.pstride, active, active_stride, lv->B, lv->K, lv->C,
-                 AtA, Atb, absres, nvalid, s);
+                 npairs(lv), AtA, Atb, absres, nvalid, s);
   return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;
 }
 

@@ -37,7 +37,8 @@ __global__ __launch_bounds__(kBlock, BANET_GATHER_WAVES) void ba_gather_kernel(c
   __shared__ float sH[kNumWaves][28][64];   // per-wave, per-lane accumulators of H_cc / Atb_c / nvalid
   __shared__ float sAbs[kNumWaves][256];
   const banet_level_t& lv = a.lv;
-  const int b = blockIdx.y, g = blockIdx.x;
+  const int vb = blockIdx.y, g = blockIdx.x;   // vb = (window, pair), see gather128.hip
+  const int b = vb / a.pairs;
   if (a.active != nullptr && a.active[(size_t)b * a.active_stride] == 0) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = wave_id();
@@ -45,11 +46,11 @@ __global__ __launch_bounds__(kBlock, BANET_GATHER_WAVES) void ba_gather_kernel(c
   const int Ct = GRAD ? 3 * C : C;
   const bool dense = lv.dense != 0;
   const int dbg = lv.reserved_;  // profiling ablation bits (tools/prof_assemble.py); 0 in production
-  const float* __restrict__ tgt_b = lv.tgt + (size_t)b * H * W * Ct;
+  const float* __restrict__ tgt_b = lv.tgt + (size_t)vb * H * W * Ct;
   const float* __restrict__ src_b = lv.src + (size_t)b * N * C;
   const float* __restrict__ dep_b = lv.depth + (size_t)b * N;
   const float* __restrict__ bas_b = KCH ? lv.basis + (size_t)b * N * K : nullptr;
-  float* __restrict__ rec_b = KCH ? a.rec + (size_t)b * N * 8 : nullptr;
+  float* __restrict__ rec_b = KCH ? a.rec + (size_t)vb * N * 8 : nullptr;
 
 #pragma unroll
   for (int i = 0; i < 28; ++i) sH[w][i][lane] = 0.f;
@@ -179,8 +180,8 @@ __global__ __launch_bounds__(kBlock, BANET_GATHER_WAVES) void ba_gather_kernel(c
           oy = lv.oy[q];
         }
       }
-      const float* Rm = a.R + b * 9;
-      const float* Tv = a.T + b * 3;
+      const float* Rm = a.R + vb * 9;
+      const float* Tv = a.T + vb * 3;
       const float rx = Rm[0] * p0 + Rm[1] * p1 + Rm[2] * p2;
       const float ry = Rm[3] * p0 + Rm[4] * p1 + Rm[5] * p2;
       const float rz = Rm[6] * p0 + Rm[7] * p1 + Rm[8] * p2;
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(kBlock, BANET_GATHER_WAVES) void ba_gather_kernel(c
   }  // tiles
 #ifdef BANET_TIMING
   if (tid == 0) {
-    float* dp = a.partials + ((size_t)b * a.G + g) * (kGHdr + C);
+    float* dp = a.partials + ((size_t)vb * a.G + g) * (kGHdr + C);
     dp[28] = tim0;  // cycles: two pixels' loads + channel math
     dp[29] = tim1;  // cycles: butterfly merges
     dp[30] = tim2;  // cycles: depth dot
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(kBlock, BANET_GATHER_WAVES) void ba_gather_kernel(c
       if (c < C) sAbs[w][c] = absd[ch][e];
     }
   __syncthreads();
-  float* __restrict__ part = a.partials + ((size_t)b * a.G + g) * (kGHdr + C);
+  float* __restrict__ part = a.partials + ((size_t)vb * a.G + g) * (kGHdr + C);
   if (tid < 4 * 28) {
     const int ww = tid / 28, i = tid - ww * 28;
     float s = 0.f;
@@ -453,7 +454,8 @@ int plan_gather(const banet_level_t* lv, GatherPlan* pl) {
   // workgroups takes as long as the first), so the grid is what the chip holds at once, split
   // across the windows.
   const int resident = kCUs * (pl->c128 ? kC128BlocksPerCU : kGenericBlocksPerCU);
-  int target = (resident + lv->B - 1) / lv->B;
+  const int VB = lv->B * npairs(lv);   // virtual windows
+  int target = (resident + VB - 1) / VB;
   int G = pl->groups;
   if (G > target) G = target;
   if (G < 1) G = 1;
@@ -463,20 +465,20 @@ int plan_gather(const banet_level_t* lv, GatherPlan* pl) {
   pl->pstride = kGHdr + lv->C;
   pl->rows = pl->c128 ? pl->tiles : G;
   pl->frows = pl->rows > kFoldRows ? (pl->rows + kFoldRows - 1) / kFoldRows : pl->rows;
-  const size_t row_bytes = (size_t)lv->B * pl->pstride * sizeof(float);
+  const size_t row_bytes = (size_t)VB * pl->pstride * sizeof(float);
   pl->off_fold = align_up(row_bytes * pl->rows, 256);
   pl->off_queue = pl->off_fold + (pl->frows != pl->rows ? align_up(row_bytes * pl->frows, 256) : 0);
-  pl->partial_bytes = pl->off_queue + align_up((size_t)lv->B * 8 * sizeof(int), 256);
-  pl->rec_bytes = lv->K > 0 ? align_up((size_t)lv->B * lv->N * 8 * sizeof(float), 256) : 0;
+  pl->partial_bytes = pl->off_queue + align_up((size_t)VB * 8 * sizeof(int), 256);
+  pl->rec_bytes = lv->K > 0 ? align_up((size_t)VB * lv->N * 8 * sizeof(float), 256) : 0;
   return BANET_OK;
 }
 
 // sum kFoldRows consecutive partial rows (fixed order) -> one row
 __global__ __launch_bounds__(256) void ba_fold_kernel(const float* __restrict__ in, int rows, int stride,
                                                       float* __restrict__ out, int frows, const int32_t* active,
-                                                      int active_stride) {
-  const int b = blockIdx.y, c = blockIdx.x, e = threadIdx.x;
-  if (active != nullptr && active[(size_t)b * active_stride] == 0) return;
+                                                      int active_stride, int pairs) {
+  const int b = blockIdx.y, c = blockIdx.x, e = threadIdx.x;   // b = virtual window
+  if (active != nullptr && active[(size_t)(b / pairs) * active_stride] == 0) return;
   if (e >= stride) return;
   const int r0 = c * kFoldRows, r1 = min(rows, r0 + kFoldRows);
   const float* p = in + ((size_t)b * rows + r0) * stride + e;
@@ -494,21 +496,21 @@ __global__ __launch_bounds__(256) void ba_fold_kernel(const float* __restrict__ 
 }
 
 void prepare_gather(const banet_level_t* lv, const GatherPlan& pl, float* partials, hipStream_t s) {
-  if (pl.c128) (void)hipMemsetAsync(reinterpret_cast<char*>(partials) + pl.off_queue, 0, (size_t)lv->B * 8 * sizeof(int), s);
+  if (pl.c128) (void)hipMemsetAsync(reinterpret_cast<char*>(partials) + pl.off_queue, 0, (size_t)lv->B * npairs(lv) * 8 * sizeof(int), s);
 }
 
 const float* finish_gather(const banet_level_t* lv, const GatherPlan& pl, const int32_t* active, int active_stride,
                            float* partials, hipStream_t s) {
   if (pl.frows == pl.rows) return partials;
   float* out = reinterpret_cast<float*>(reinterpret_cast<char*>(partials) + pl.off_fold);
-  hipLaunchKernelGGL(ba_fold_kernel, dim3(pl.frows, lv->B), dim3(256), 0, s, partials, pl.rows, pl.pstride, out, pl.frows,
-                     active, active_stride);
+  hipLaunchKernelGGL(ba_fold_kernel, dim3(pl.frows, lv->B * npairs(lv)), dim3(256), 0, s, partials, pl.rows, pl.pstride, out,
+                     pl.frows, active, active_stride, npairs(lv));
   return out;
 }
 
 template <int VEC, int CH, bool GRAD>
 static int launch_k(const GatherArgs& a, int K, hipStream_t s) {
-  dim3 grid(a.G, a.lv.B), block(kBlock);
+  dim3 grid(a.G, a.lv.B * a.pairs), block(kBlock);
   const bool keven = (K & 1) == 0;
   if (K == 0)
     hipLaunchKernelGGL((ba_gather_kernel<VEC, CH, GRAD, 1, 0>), grid, block, 0, s, a);
@@ -553,6 +555,7 @@ int launch_gather(const banet_level_t* lv, const GatherPlan& pl, const float* R,
   a.groups = pl.groups;
   a.queue = reinterpret_cast<int*>(reinterpret_cast<char*>(partials) + pl.off_queue);
   a.nbands = pl.nbands;
+  a.pairs = npairs(lv);
   int rc;
   if (pl.c128)
     rc = launch_gather128(a, lv->K, s);

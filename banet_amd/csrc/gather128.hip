@@ -58,19 +58,20 @@ __global__ __launch_bounds__(kBlock, BANET_G128_WAVES) void ba_gather128_kernel(
   __shared__ __attribute__((aligned(16))) float sQ[kNumWaves][64][8];
   __shared__ float sAbs[kNumWaves][kC128];
   const banet_level_t& lv = a.lv;
-  const int b = blockIdx.y, g = blockIdx.x;
+  const int vb = blockIdx.y, g = blockIdx.x;   // vb = (window, pair): a multi-frame window is `pairs` virtual windows
+  const int b = vb / a.pairs;                  // that share the key frame's source map, depth, basis and Wc
   if (a.active != nullptr && a.active[(size_t)b * a.active_stride] == 0) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = wave_id();
   const int N = lv.N, K = lv.K, H = lv.H, W = lv.W;
   constexpr int C = kC128;
   const bool dense = lv.dense != 0;
-  const float* __restrict__ tgt_b = lv.tgt + (size_t)b * H * W * C;
+  const float* __restrict__ tgt_b = lv.tgt + (size_t)vb * H * W * C;
   const float* __restrict__ src_b = lv.src + (size_t)b * N * C;
   const float* __restrict__ dep_b = lv.depth + (size_t)b * N;
   const float* __restrict__ bas_b = KV4 ? lv.basis + (size_t)b * N * K : nullptr;
-  float* __restrict__ rec_b = KV4 ? a.rec + (size_t)b * N * 8 : nullptr;
-  float* __restrict__ part_b = a.partials + (size_t)b * a.tiles * (kGHdr + C);
+  float* __restrict__ rec_b = KV4 ? a.rec + (size_t)vb * N * 8 : nullptr;
+  float* __restrict__ part_b = a.partials + (size_t)vb * a.tiles * (kGHdr + C);
   const int grp = lane >> 4, sub = lane & 15;
   const int half = lane >> 5, li = lane & 31;
 
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(kBlock, BANET_G128_WAVES) void ba_gather128_kernel(
 
   // ---- tile queue: band x = tiles [tiles x / nb, tiles (x+1) / nb); home band = this workgroup's XCD
   const int nb = a.nbands;
-  int* __restrict__ queue = a.queue + b * 8;
+  int* __restrict__ queue = a.queue + vb * 8;
   int band = nb > 1 ? (g & 7) : 0, left = nb;
   auto band_lo = [&](int x) { return (int)(((long long)a.tiles * x) / nb); };
   auto pop = [&](int x) {  // wave-uniform
@@ -196,8 +197,8 @@ __global__ __launch_bounds__(kBlock, BANET_G128_WAVES) void ba_gather128_kernel(
           oy = lv.oy[q];
         }
       }
-      const float* Rm = a.R + b * 9;
-      const float* Tv = a.T + b * 3;
+      const float* Rm = a.R + vb * 9;
+      const float* Tv = a.T + vb * 3;
       const float rx = Rm[0] * p0 + Rm[1] * p1 + Rm[2] * p2;
       const float ry = Rm[3] * p0 + Rm[4] * p1 + Rm[5] * p2;
       const float rz = Rm[6] * p0 + Rm[7] * p1 + Rm[8] * p2;
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(kBlock, BANET_G128_WAVES) void ba_gather128_kernel(
 }
 
 int launch_gather128(const GatherArgs& a, int K, hipStream_t s) {
-  dim3 grid(a.G, a.lv.B), block(kBlock);
+  dim3 grid(a.G, a.lv.B * a.pairs), block(kBlock);
   if (K == 0)
     hipLaunchKernelGGL((ba_gather128_kernel<0>), grid, block, 0, s, a);
   else if ((K & 3) == 0 && K <= 128)

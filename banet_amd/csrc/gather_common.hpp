@@ -17,6 +17,7 @@ struct GatherArgs {
   int G, tiles, tiles_x, tiles_y, groups;
   int* queue;       // [B][8] tile-queue heads (ba_gather128_kernel), zero at launch
   int nbands;
+  int pairs;        // target frames per window: blockIdx.y = window * pairs + pair
 };
 
 template <int VEC>

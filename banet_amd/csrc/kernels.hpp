@@ -7,6 +7,8 @@ namespace banet {
 constexpr int kGHdr = 32;       // gather partial header: 21 H_cc + 6 Atb_c + nvalid (+pad), then C x sum|d|
 constexpr int kUStrideS = 8;    // per-pixel record: u0..u5, s, r
 
+inline int npairs(const banet_level_t* lv) { return lv->pairs > 1 ? lv->pairs : 1; }
+
 // ---- gather.hip ------------------------------------------------------------------------
 struct GatherPlan {
   int G, tiles, tiles_x, tiles_y, groups, pstride;
@@ -33,12 +35,12 @@ struct SyrkPlan {
   int direct;   // 1: ba_syrk_direct_kernel (K = 64 / 128), 0: the LDS-tiled kernel
   size_t partial_bytes;
 };
-int plan_syrk(int B, int N, int K, SyrkPlan* pl);
-int launch_syrk(const float* basis, const float* rec, int B, int N, int K, const SyrkPlan& pl, const int32_t* active,
-                int active_stride, float* partials, hipStream_t s);
+int plan_syrk(int B, int N, int K, int pairs, SyrkPlan* pl);
+int launch_syrk(const float* basis, const float* rec, int B, int N, int K, int pairs, const SyrkPlan& pl,
+                const int32_t* active, int active_stride, float* partials, hipStream_t s);
 void launch_reduce2(const float* gpart, int Gg, int gstride, const float* spart, int Gs, int sstride,
-                    const int32_t* active, int active_stride, int B, int K, int C, float* AtA, float* Atb, float* absres,
-                    float* nvalid, hipStream_t s);
+                    const int32_t* active, int active_stride, int B, int K, int C, int pairs, float* AtA, float* Atb,
+                    float* absres, float* nvalid, hipStream_t s);
 
 // ---- assemble.hip: one assembly pass = gather + syrk + reduce ------------------------------
 struct AsmPlan {
@@ -80,7 +82,7 @@ struct LmCtl {  // per-window loop state of the legacy early-termination LM (dev
 static_assert(sizeof(LmCtl) == 80, "LmCtl layout");
 
 struct SolveArgs {
-  int B, N, C, K, P, variant;
+  int B, N, C, K, P, variant, pairs;
   float l2_base;
   int max_iters;  // only used with ctl
   banet_mlp_t mlp;

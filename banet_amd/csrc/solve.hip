@@ -558,7 +558,8 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve_update_kernel(const So
 
   STICK(tk0);
   const bool legacy = a.variant == BANET_LEGACY_LM || a.variant == BANET_LEGACY_FIXED;
-  const float Nf = (float)a.N;
+  const int pairs = a.pairs;
+  const float Nf = (float)a.N * (float)pairs;   // residual rows per window: N points x pairs target frames
   const float nval = a.nvalid[b];
   // ---- average residual -------------------------------------------------------------
   const float numvalid = Nf / nval;  // legacy/ba.py:257
@@ -642,12 +643,14 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve_update_kernel(const So
   STICK(tk3);
   // ---- update -------------------------------------------------------------------------
   for (int k = tid; k < P; k += kSolveThreads) a.st.delta[(size_t)b * P + k] = sX[k];
-  for (int k = tid; k < K; k += kSolveThreads) a.st.Wc[(size_t)b * K + k] += sX[6 + k];   // bundlenet.py:276
-  if (tid == 0) {
-    float w[3] = {sX[0], sX[1], sX[2]}, t[3] = {sX[3], sX[4], sX[5]};
+  for (int k = tid; k < K; k += kSolveThreads) a.st.Wc[(size_t)b * K + k] += sX[6 * pairs + k];   // bundlenet.py:276
+  if (tid < pairs) {   // one thread per target frame's pose
+    const int pb = b * pairs + tid;
+    const float* sx = sX + 6 * tid;
+    float w[3] = {sx[0], sx[1], sx[2]}, t[3] = {sx[3], sx[4], sx[5]};
     float Rw[9], V[9], Ro[9], To[3], Rn[9], Tn[3];
-    for (int i = 0; i < 9; ++i) Ro[i] = a.st.R[b * 9 + i];
-    for (int i = 0; i < 3; ++i) To[i] = a.st.T[b * 3 + i];
+    for (int i = 0; i < 9; ++i) Ro[i] = a.st.R[pb * 9 + i];
+    for (int i = 0; i < 3; ++i) To[i] = a.st.T[pb * 3 + i];
     rodrigues(w, !legacy, Rw, V);
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) Rn[i * 3 + j] = Rw[i * 3] * Ro[j] + Rw[i * 3 + 1] * Ro[3 + j] + Rw[i * 3 + 2] * Ro[6 + j];
@@ -666,11 +669,13 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve_update_kernel(const So
       ctl->ut = sqrtf(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
       ctl->pending = 1;
     }
-    for (int i = 0; i < 9; ++i) a.st.R[b * 9 + i] = Rn[i];
-    for (int i = 0; i < 3; ++i) a.st.T[b * 3 + i] = Tn[i];
-    a.st.iters[b] += 1;
-    a.st.ratio[b] = (a.variant == BANET_LEGACY_FIXED) ? nval / Nf : numvalid;   // ba.py:214 / :344
-    a.st.lambda_out[b] = lam;
+    for (int i = 0; i < 9; ++i) a.st.R[pb * 9 + i] = Rn[i];
+    for (int i = 0; i < 3; ++i) a.st.T[pb * 3 + i] = Tn[i];
+    if (tid == 0) {
+      a.st.iters[b] += 1;
+      a.st.ratio[b] = (a.variant == BANET_LEGACY_FIXED) ? nval / Nf : numvalid;   // ba.py:214 / :344
+      a.st.lambda_out[b] = lam;
+    }
   }
 #ifdef BANET_TIMING
   __syncthreads();

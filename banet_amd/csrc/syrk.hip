@@ -15,11 +15,13 @@ namespace banet {
 
 struct SyrkArgs {
   const float* basis;  // [B][N][K]
-  const float* rec;    // [B][N][8]
+  const float* rec;    // [B][pairs][N][8]
   const int32_t* active;
   int active_stride;
-  float* partials;     // [B][Gs][7K + K*K]
+  float* partials;     // [B][Gs][(6 pairs + 1) K + K*K]: H_cd rows (pair, c), the Atb_d row, H_dd
   int N, K, Gs, tiles, pstride;
+  int pairs;           // target frames per window (records of pair i: rec + ((b pairs + i) N) 8)
+  int pass;            // LDS-tiled kernel only: pass p adds H_cd of pair p; pass 0 also H_dd / Atb_d with s, r summed over pairs
 };
 
 template <int NB>
@@ -38,7 +40,7 @@ __global__ __launch_bounds__(kBlock, 2) void ba_syrk_kernel(const SyrkArgs a) {
   const int w = wave_id();
   const int N = a.N, K = a.K;
   const float* __restrict__ bas_b = a.basis + (size_t)b * N * K;
-  const float* __restrict__ rec_b = a.rec + (size_t)b * N * 8;
+  const float* __restrict__ rec_b = a.rec + ((size_t)b * a.pairs + a.pass) * N * 8;   // this pass's pair
   const bool k4 = (K & 3) == 0;
 
   float hcd[7][KV];
@@ -51,7 +53,7 @@ __global__ __launch_bounds__(kBlock, 2) void ba_syrk_kernel(const SyrkArgs a) {
   for (int q = 0; q < NSLOT; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
   constexpr int npairs = (NB + 1) / 2;
   const int i1 = w, i2 = NB - 1 - w;
-  const bool mf_on = w < npairs;
+  const bool mf_on = w < npairs && a.pass == 0;
   const int n1 = NB - i1;
   const int nslots = (i2 != i1) ? NB + 1 : n1;
 
@@ -88,7 +90,16 @@ __global__ __launch_bounds__(kBlock, 2) void ba_syrk_kernel(const SyrkArgs a) {
     {
       const int n = tid >> 1;
       const bool ok = tid < 2 * kTilePix && pt0 + n < N;
-      const float4 v = *reinterpret_cast<const float4*>(rec_b + (ok ? (size_t)(pt0 + n) * 8 + 4 * (tid & 1) : 0));
+      float4 v = *reinterpret_cast<const float4*>(rec_b + (ok ? (size_t)(pt0 + n) * 8 + 4 * (tid & 1) : 0));
+      if (a.pass > 0) {   // H_cd of this pair only: no s (MFMA phase is off), no r
+        if (tid & 1) v.w = 0.f;
+      } else if ((tid & 1) && ok) {   // pass 0 of a multi-frame window: s and r summed over the pairs
+        for (int i = 1; i < a.pairs; ++i) {
+          const float4 o = *reinterpret_cast<const float4*>(rec_b + ((size_t)i * N + pt0 + n) * 8 + 4);
+          v.z += o.z;
+          v.w += o.w;
+        }
+      }
       preu = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
@@ -179,11 +190,13 @@ __global__ __launch_bounds__(kBlock, 2) void ba_syrk_kernel(const SyrkArgs a) {
   __syncthreads();
   for (int e = tid; e < 7 * K; e += kBlock) {
     const int i = e / K, k = e - i * K;
-    part[e] = (sH[(0 * 8 + i) * KPAD + k] + sH[(1 * 8 + i) * KPAD + k]) +
-              (sH[(2 * 8 + i) * KPAD + k] + sH[(3 * 8 + i) * KPAD + k]);
+    if (i == 6 && a.pass > 0) continue;   // Atb_d comes from pass 0
+    const int row = i < 6 ? 6 * a.pass + i : 6 * a.pairs;
+    part[row * K + k] = (sH[(0 * 8 + i) * KPAD + k] + sH[(1 * 8 + i) * KPAD + k]) +
+                        (sH[(2 * 8 + i) * KPAD + k] + sH[(3 * 8 + i) * KPAD + k]);
   }
   if (mf_on) {
-    float* pd = part + 7 * K;
+    float* pd = part + (6 * a.pairs + 1) * K;
     const int col = lane & 15, rq = (lane >> 4) * 4;
 #pragma unroll
     for (int q = 0; q < NSLOT; ++q) {
@@ -216,26 +229,43 @@ __global__ __launch_bounds__(kBlock, 2) void ba_syrk_kernel(const SyrkArgs a) {
 // --------------------------------------------------------------------------------------
 constexpr int kSyrkBatch = 4;
 
-template <int KH>
+template <int KH, int PAIRS>
 __global__ __launch_bounds__(kBlock, 1) void ba_syrk_direct_kernel(const SyrkArgs a) {
   constexpr int NBV = 4 * KH, NPAIR = NBV * (NBV + 1) / 2, K = 64 * KH, NV = 4 * KH;
-  __shared__ float sAcc[NPAIR + NBV][4][64];
+  constexpr int NU = (PAIRS + 1) / 2;   // record block rows: rows 0..5 / 6..11 = u of pairs 2j / 2j+1; block row 0 rows 12+i = r_i
+  __shared__ float sAcc[NPAIR + NU * NBV][4][64];
   const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   if (a.active != nullptr && a.active[(size_t)b * a.active_stride] == 0) return;
   const int w = wave_id();
   const int N = a.N;
   const int m = lane & 15, kq = lane >> 4;
   const float* __restrict__ bas_b = a.basis + (size_t)b * N * K;
-  const float* __restrict__ rec_b = a.rec + (size_t)b * N * 8;
-  // record word this lane feeds to the H_cd / Atb_d block row: rows 0..5 = u0..u5, row 6 = r
-  const int uword = m < 6 ? m : 7;
+  const float* __restrict__ rec_b = a.rec + (size_t)b * PAIRS * N * 8;
+  // record word this lane feeds to block row j: (pair, word) or none
+  size_t uoff[NU];
+  bool uon[NU];
+#pragma unroll
+  for (int j = 0; j < NU; ++j) {
+    int pair = -1, word = 0;
+    if (m < 12) {
+      pair = 2 * j + m / 6;
+      word = m % 6;
+    } else if (j == 0) {
+      pair = m - 12;
+      word = 7;
+    }
+    uon[j] = pair >= 0 && pair < PAIRS;
+    uoff[j] = uon[j] ? (size_t)pair * N * 8 + word : 0;
+  }
 
-  f32x4 acc[NPAIR];   // H_dd, upper triangle of virtual blocks
-  f32x4 acu[NBV];     // rows 0..6: H_cd (6) and Atb_d (1) against every virtual block column
+  f32x4 acc[NPAIR];      // H_dd, upper triangle of virtual blocks
+  f32x4 acu[NU][NBV];    // record block rows against every virtual block column
 #pragma unroll
   for (int q = 0; q < NPAIR; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int q = 0; q < NBV; ++q) acu[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < NU; ++j)
+#pragma unroll
+    for (int q = 0; q < NBV; ++q) acu[j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // this wave's run of quads
   const int nq = (N + 3) >> 2, nwaves = a.Gs * kNumWaves, gw = g * kNumWaves + w;
@@ -246,7 +276,7 @@ __global__ __launch_bounds__(kBlock, 1) void ba_syrk_direct_kernel(const SyrkArg
   // (kSyrkBatch x 44 x 32 cycles) to arrive
   struct Batch {
     f32x4 pb[kSyrkBatch][KH];
-    float ps[kSyrkBatch], pu[kSyrkBatch];
+    float ps[kSyrkBatch][PAIRS], pu[kSyrkBatch][NU];
   };
   auto issue = [&](Batch& B_, int q) __attribute__((always_inline)) {
 #pragma unroll
@@ -256,16 +286,20 @@ __global__ __launch_bounds__(kBlock, 1) void ba_syrk_direct_kernel(const SyrkArg
 #pragma unroll
       for (int h = 0; h < KH; ++h)
         B_.pb[d][h] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(bas_b + p * K + 64 * h + 4 * m));
-      B_.ps[d] = rec_b[p * 8 + 6];
-      B_.pu[d] = rec_b[p * 8 + uword];
+#pragma unroll
+      for (int i = 0; i < PAIRS; ++i) B_.ps[d][i] = rec_b[((size_t)i * N + p) * 8 + 6];
+#pragma unroll
+      for (int j = 0; j < NU; ++j) B_.pu[d][j] = rec_b[p * 8 + uoff[j]];
     }
   };
   auto consume = [&](const Batch& B_, int q) __attribute__((always_inline)) {
 #pragma unroll
     for (int d = 0; d < kSyrkBatch; ++d) {
       const bool ok = q + d < q1 && 4 * (q + d) + kq < N;
-      const float sv = ok ? B_.ps[d] : 0.f;                 // zero records switch the pixel off
-      const float uv = (ok && m < 7) ? B_.pu[d] : 0.f;
+      float ssum = B_.ps[d][0];
+#pragma unroll
+      for (int i = 1; i < PAIRS; ++i) ssum += B_.ps[d][i];
+      const float sv = ok ? ssum : 0.f;                     // zero records switch the pixel off
       float bv[NV], av[NV];
 #pragma unroll
       for (int h = 0; h < KH; ++h)
@@ -283,7 +317,11 @@ __global__ __launch_bounds__(kBlock, 1) void ba_syrk_direct_kernel(const SyrkArg
           ++idx;
         }
 #pragma unroll
-      for (int bj = 0; bj < NBV; ++bj) acu[bj] = __builtin_amdgcn_mfma_f32_16x16x4f32(uv, bv[bj], acu[bj], 0, 0, 0);
+      for (int j = 0; j < NU; ++j) {
+        const float uv = (ok && uon[j]) ? B_.pu[d][j] : 0.f;
+#pragma unroll
+        for (int bj = 0; bj < NBV; ++bj) acu[j][bj] = __builtin_amdgcn_mfma_f32_16x16x4f32(uv, bv[bj], acu[j][bj], 0, 0, 0);
+      }
     }
   };
 #ifdef BANET_TIMING
@@ -302,11 +340,11 @@ __global__ __launch_bounds__(kBlock, 1) void ba_syrk_direct_kernel(const SyrkArg
     consume(R1, q + kSyrkBatch);
     __builtin_amdgcn_sched_barrier(0);
   }
-
 #ifdef BANET_TIMING
   unsigned long long tm1, tr1;
   asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm1), "=s"(tr1)::"memory");
 #endif
+
   // ---- epilogue: add the 4 waves in fixed order through LDS, un-permute, publish ---------------
   for (int ww = 0; ww < kNumWaves; ++ww) {
     if (w == ww) {
@@ -315,29 +353,48 @@ __global__ __launch_bounds__(kBlock, 1) void ba_syrk_direct_kernel(const SyrkArg
 #pragma unroll
         for (int r = 0; r < 4; ++r) sAcc[q][r][lane] = (ww == 0 ? 0.f : sAcc[q][r][lane]) + acc[q][r];
 #pragma unroll
-      for (int q = 0; q < NBV; ++q)
+      for (int j = 0; j < NU; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sAcc[NPAIR + q][r][lane] = (ww == 0 ? 0.f : sAcc[NPAIR + q][r][lane]) + acu[q][r];
+        for (int q = 0; q < NBV; ++q)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* c = &sAcc[NPAIR + j * NBV + q][r][lane];
+            *c = (ww == 0 ? 0.f : *c) + acu[j][q][r];
+          }
     }
     __syncthreads();
   }
   float* __restrict__ part = a.partials + ((size_t)b * a.Gs + g) * a.pstride;
   // thread (w, lane) publishes accumulator register r = w of every block: row 4 kq + r, column m
   const int r = w, brow = 4 * kq + r;
-  if (brow < 7) {
 #pragma unroll
-    for (int bj = 0; bj < NBV; ++bj) part[brow * K + 64 * (bj >> 2) + 4 * m + (bj & 3)] = sAcc[NPAIR + bj][r][lane];
+  for (int j = 0; j < NU; ++j) {
+    const int pair = 2 * j + brow / 6;
+    if (brow < 12 && pair < PAIRS) {
+#pragma unroll
+      for (int bj = 0; bj < NBV; ++bj)
+        part[(6 * pair + brow % 6) * K + 64 * (bj >> 2) + 4 * m + (bj & 3)] = sAcc[NPAIR + j * NBV + bj][r][lane];
+    }
+  }
+  if (brow == 12) {   // Atb_d: rows 12 + i of block row 0 hold r_i; add the pairs in order (kq = 3, register i)
+#pragma unroll
+    for (int bj = 0; bj < NBV; ++bj) {
+      float v = sAcc[NPAIR + bj][0][lane];
+#pragma unroll
+      for (int i = 1; i < PAIRS; ++i) v += sAcc[NPAIR + bj][i][lane];
+      part[6 * PAIRS * K + 64 * (bj >> 2) + 4 * m + (bj & 3)] = v;
+    }
   }
 #ifdef BANET_TIMING
   __syncthreads();
-  if (tid == 0) {   // development aid (tools/time_syrk.py): overwrites 4 words of the partial
+  if (tid == 0) {   // development aid (tools/time_syrk.py): overwrites 3 words of the partial
     part[0] = (float)(tm1 - tm0);
     part[1] = (float)(tr1 - tr0);
     part[2] = (float)(q1 - q0);
   }
   return;
 #endif
-  float* pd = part + 7 * K;
+  float* pd = part + (6 * PAIRS + 1) * K;
   {
     int idx = 0;
     for (int bi = 0; bi < NBV; ++bi)
@@ -359,60 +416,75 @@ __global__ __launch_bounds__(kBlock, 1) void ba_syrk_direct_kernel(const SyrkArg
 // --------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ba_reduce2_kernel(const float* __restrict__ gpart, int Gg, int gstride,
                                                          const float* __restrict__ spart, int Gs, int sstride,
-                                                         const int32_t* active, int active_stride, int K, int C,
+                                                         const int32_t* active, int active_stride, int K, int C, int pairs,
                                                          float* __restrict__ AtA, float* __restrict__ Atb,
                                                          float* __restrict__ absres, float* __restrict__ nvalid) {
+  // Parameter order [pose_1 .. pose_pairs | depth]; the gather partials of pair i are the rows of
+  // virtual window b pairs + i.  Pose blocks of different pairs do not couple: exact zeros.
   const int b = blockIdx.y;
   if (active != nullptr && active[(size_t)b * active_stride] == 0) return;
-  const int P = 6 + K;
+  const int P6 = 6 * pairs, P = P6 + K;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const int total = P * P + P + C + 1;
   if (e >= total) return;
-  // which partial set / offset / sign?
-  int off;
-  bool from_s = false;
+  int off = 0, pair = -1;      // pair >= 0: one pair's gather rows; -2: gather rows of all pairs; -1: syrk rows
+  bool zero = false;
   float sign = 1.f;
   if (e < P * P) {
     const int i = e / P, j = e - i * P;
-    if (i < 6 && j < 6) {
-      const int lo = i < j ? i : j, hi = i < j ? j : i;
-      off = 6 * lo - lo * (lo - 1) / 2 + (hi - lo);
-    } else if (i < 6 || j < 6) {     // H_cd: bundle sign (J = [-Jc | jd b], bundlenet.py:60)
-      const int c = i < 6 ? i : j, k = (i < 6 ? j : i) - 6;
+    if (i < P6 && j < P6) {
+      if (i / 6 != j / 6) {
+        zero = true;
+      } else {
+        pair = i / 6;
+        const int ii = i % 6, jj = j % 6;
+        const int lo = ii < jj ? ii : jj, hi = ii < jj ? jj : ii;
+        off = 6 * lo - lo * (lo - 1) / 2 + (hi - lo);
+      }
+    } else if (i < P6 || j < P6) {   // H_cd: bundle sign (J = [-Jc | jd b], bundlenet.py:60)
+      const int c = i < P6 ? i : j, k = (i < P6 ? j : i) - P6;
       off = c * K + k;
-      from_s = true;
       sign = -1.f;
     } else {
-      off = 7 * K + (i - 6) * K + (j - 6);
-      from_s = true;
+      off = (P6 + 1) * K + (i - P6) * K + (j - P6);
     }
   } else if (e < P * P + P) {
     const int i = e - P * P;
-    if (i < 6) {
-      off = 21 + i;
+    if (i < P6) {
+      pair = i / 6;
+      off = 21 + i % 6;
     } else {                         // Atb_d: d = F1 - F2w (bundlenet.py:234)
-      off = 6 * K + (i - 6);
-      from_s = true;
+      off = P6 * K + (i - P6);
       sign = -1.f;
     }
   } else if (e < P * P + P + C) {
+    pair = -2;
     off = kGHdr + (e - P * P - P);
   } else {
+    pair = -2;
     off = 27;
   }
-  const float* p = from_s ? spart + (size_t)b * Gs * sstride + off : gpart + (size_t)b * Gg * gstride + off;
-  const int n = from_s ? Gs : Gg;
-  const size_t st = from_s ? sstride : gstride;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int i = 0;
-  for (; i + 3 < n; i += 4) {
-    s0 += p[(size_t)(i + 0) * st];
-    s1 += p[(size_t)(i + 1) * st];
-    s2 += p[(size_t)(i + 2) * st];
-    s3 += p[(size_t)(i + 3) * st];
+  float v = 0.f;
+  if (!zero) {
+    const bool from_s = pair == -1;
+    const int p0 = pair == -2 ? 0 : pair, p1 = pair == -2 ? pairs : pair + 1;
+    for (int pp = p0; pp < (from_s ? p0 + 1 : p1); ++pp) {   // fixed order: pairs, then rows
+      const float* p = from_s ? spart + (size_t)b * Gs * sstride + off : gpart + ((size_t)b * pairs + pp) * Gg * gstride + off;
+      const int n = from_s ? Gs : Gg;
+      const size_t st = from_s ? sstride : gstride;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      int i = 0;
+      for (; i + 3 < n; i += 4) {
+        s0 += p[(size_t)(i + 0) * st];
+        s1 += p[(size_t)(i + 1) * st];
+        s2 += p[(size_t)(i + 2) * st];
+        s3 += p[(size_t)(i + 3) * st];
+      }
+      for (; i < n; ++i) s0 += p[(size_t)i * st];
+      v += (s0 + s1) + (s2 + s3);
+    }
+    v *= sign;
   }
-  for (; i < n; ++i) s0 += p[(size_t)i * st];
-  const float v = sign * ((s0 + s1) + (s2 + s3));
   if (e < P * P)
     AtA[(size_t)b * P * P + e] = v;
   else if (e < P * P + P)
@@ -435,7 +507,7 @@ static int nb_for_k(int K) {
   return -1;
 }
 
-int plan_syrk(int B, int N, int K, SyrkPlan* pl) {
+int plan_syrk(int B, int N, int K, int pairs, SyrkPlan* pl) {
   pl->nb = nb_for_k(K);
   if (pl->nb < 0) return BANET_ERR_UNSUPPORTED;
   if (K == 0) {
@@ -446,13 +518,13 @@ int plan_syrk(int B, int N, int K, SyrkPlan* pl) {
     return BANET_OK;
   }
   pl->tiles = (N + kTilePix - 1) / kTilePix;
-  pl->direct = (K == 64 || K == 128) ? 1 : 0;   // ba_syrk_direct_kernel: one wave per SIMD, 256 workgroups in all
+  pl->direct = ((K == 64 || K == 128) && pairs <= 4) ? 1 : 0;   // ba_syrk_direct_kernel: one wave per SIMD, 256 workgroups in all
   int target = ((pl->direct ? 256 : 512) + B - 1) / B;   // LDS kernel: 2 resident workgroups per CU
   int G = pl->direct ? (N + 4 * 4 * 16 - 1) / (4 * 4 * 16) : pl->tiles / 4;   // direct: >= 16 quads per wave
   if (G > target) G = target;
   if (G < 1) G = 1;
   pl->Gs = G;
-  pl->pstride = (int)align_up((size_t)7 * K + (size_t)K * K, 4);
+  pl->pstride = (int)align_up((size_t)(6 * pairs + 1) * K + (size_t)K * K, 4);
   pl->partial_bytes = align_up((size_t)B * G * pl->pstride * sizeof(float), 256);
   return BANET_OK;
 }
@@ -469,32 +541,46 @@ static void launch_syrk_nb(const SyrkArgs& a, int B, hipStream_t s) {
   hipLaunchKernelGGL(k, dim3(a.Gs, B), dim3(kBlock), lds, s, a);
 }
 
-int launch_syrk(const float* basis, const float* rec, int B, int N, int K, const SyrkPlan& pl, const int32_t* active,
-                int active_stride, float* partials, hipStream_t s) {
-  SyrkArgs a{basis, rec, active, active_stride, partials, N, K, pl.Gs, pl.tiles, pl.pstride};
+template <int KH>
+static void launch_direct(const SyrkArgs& a, int B, hipStream_t s) {
+  const dim3 grid(a.Gs, B), block(kBlock);
+  switch (a.pairs) {
+    case 1: hipLaunchKernelGGL((ba_syrk_direct_kernel<KH, 1>), grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((ba_syrk_direct_kernel<KH, 2>), grid, block, 0, s, a); break;
+    case 3: hipLaunchKernelGGL((ba_syrk_direct_kernel<KH, 3>), grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL((ba_syrk_direct_kernel<KH, 4>), grid, block, 0, s, a); break;
+  }
+}
+
+int launch_syrk(const float* basis, const float* rec, int B, int N, int K, int pairs, const SyrkPlan& pl,
+                const int32_t* active, int active_stride, float* partials, hipStream_t s) {
+  SyrkArgs a{basis, rec, active, active_stride, partials, N, K, pl.Gs, pl.tiles, pl.pstride, pairs, 0};
   if (pl.direct) {
     if (K == 128)
-      hipLaunchKernelGGL(ba_syrk_direct_kernel<2>, dim3(a.Gs, B), dim3(kBlock), 0, s, a);
+      launch_direct<2>(a, B, s);
     else
-      hipLaunchKernelGGL(ba_syrk_direct_kernel<1>, dim3(a.Gs, B), dim3(kBlock), 0, s, a);
+      launch_direct<1>(a, B, s);
     return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;
   }
-  switch (pl.nb) {
-    case 1: launch_syrk_nb<1>(a, B, s); break;
-    case 2: launch_syrk_nb<2>(a, B, s); break;
-    case 4: launch_syrk_nb<4>(a, B, s); break;
-    case 8: launch_syrk_nb<8>(a, B, s); break;
-    default: return BANET_ERR_UNSUPPORTED;
+  for (int pass = 0; pass < pairs; ++pass) {   // LDS-tiled kernel: one pass per pair (H_dd / Atb_d in pass 0)
+    a.pass = pass;
+    switch (pl.nb) {
+      case 1: launch_syrk_nb<1>(a, B, s); break;
+      case 2: launch_syrk_nb<2>(a, B, s); break;
+      case 4: launch_syrk_nb<4>(a, B, s); break;
+      case 8: launch_syrk_nb<8>(a, B, s); break;
+      default: return BANET_ERR_UNSUPPORTED;
+    }
   }
   return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;
 }
 
 void launch_reduce2(const float* gpart, int Gg, int gstride, const float* spart, int Gs, int sstride,
-                    const int32_t* active, int active_stride, int B, int K, int C, float* AtA, float* Atb, float* absres,
-                    float* nvalid, hipStream_t s) {
-  const int P = 6 + K, total = P * P + P + C + 1;
+                    const int32_t* active, int active_stride, int B, int K, int C, int pairs, float* AtA, float* Atb,
+                    float* absres, float* nvalid, hipStream_t s) {
+  const int P = 6 * pairs + K, total = P * P + P + C + 1;
   hipLaunchKernelGGL(ba_reduce2_kernel, dim3((total + 255) / 256, B), dim3(256), 0, s, gpart, Gg, gstride, spart, Gs,
-                     sstride, active, active_stride, K, C, AtA, Atb, absres, nvalid);
+                     sstride, active, active_stride, K, C, pairs, AtA, Atb, absres, nvalid);
 }
 
 }  // namespace banet

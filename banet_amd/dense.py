@@ -14,9 +14,12 @@ from . import ops
 
 class DenseLevel:
     def __init__(self, scale, src, tgt, depth, basis=None):
+        """tgt [B,H,W,C] (2-frame) or [B,pairs,H,W,C] (multi-frame window: `pairs` target frames that
+        share the key frame's src / depth / basis -- SURVEY.md 8(d))"""
         self.scale = float(scale)
         self.src, self.tgt, self.depth, self.basis = src, tgt, depth, basis
-        self.B, self.H, self.W, self.C = tgt.shape
+        self.pairs = tgt.shape[1] if tgt.dim() == 5 else 1
+        self.B, self.H, self.W, self.C = tgt.shape[0], tgt.shape[-3], tgt.shape[-2], tgt.shape[-1]
 
 
 class DenseBA:
@@ -34,9 +37,10 @@ class DenseBA:
             basis = lv.basis.reshape(B, H * W, -1) if (variant == "bundle") else None
             self.problems.append(ops.LevelProblem(variant, lv.src, lv.tgt, lv.depth.reshape(B, H * W), H, W, C,
                                                   basis=basis, intr=self.intr, scale=lv.scale, dense=True,
-                                                  tgt_has_grad=False, normalize_rays=not legacy))
+                                                  tgt_has_grad=False, normalize_rays=not legacy, pairs=lv.pairs))
             self.mlps.append(None if variant == "legacy_fixed" else ops.MlpWeights(lw, dev))
         self.K = self.problems[0].K
+        self.pairs = self.problems[0].pairs
         nb = max(ops.lm_level_workspace_bytes(p) for p in self.problems)
         if nb == 0:
             raise ops.capi.BanetError("DenseBA: unsupported level shape")
@@ -46,11 +50,13 @@ class DenseBA:
     def new_state(self, R=None, T=None, Wc=None):
         dev = self.intr.device
         B, K = self.B, self.K
-        R = torch.eye(3, device=dev).repeat(B, 1, 1) if R is None else R
-        T = torch.zeros(B, 3, 1, device=dev) if T is None else T
+        R = torch.eye(3, device=dev).repeat(B * self.pairs, 1, 1) if R is None else R
+        T = torch.zeros(B * self.pairs, 3, 1, device=dev) if T is None else T
         if K > 0 and Wc is None:
             Wc = torch.zeros(B, K, 1, device=dev)
-        return ops.LmState(R, T, Wc if K > 0 else None, P=6 + K)
+        R = R.reshape(B, -1, 3, 3) if self.pairs > 1 else R
+        T = T.reshape(B, -1, 3, 1) if self.pairs > 1 else T
+        return ops.LmState(R, T, Wc if K > 0 else None, P=6 * self.pairs + K, pairs=self.pairs)
 
     def solve(self, iters_per_level, state=None, early_termination=False):
         """Enqueue the full schedule; returns the state (R,T,Wc updated in place) and the list
@@ -63,6 +69,6 @@ class DenseBA:
         return st, counts
 
     def algorithmic_bytes_per_iteration(self, level_index):
-        """4*N_l*(C*F + K + 1) per window-iteration (F = 2 frames)."""
+        """4*N_l*(C*F + K + 1) per window-iteration (F = 1 + pairs frames)."""
         p = self.problems[level_index]
-        return 4 * p.N * (p.C * 2 + p.K + 1)
+        return 4 * p.N * (p.C * (1 + p.pairs) + p.K + 1)

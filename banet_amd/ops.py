@@ -92,13 +92,15 @@ class MlpWeights:
 
 
 class LmState:
-    """Per-window LM state (banet_state_t): R [B,3,3], T [B,3,1], Wc [B,K,1] + diagnostics."""
+    """Per-window LM state (banet_state_t): R [B,3,3], T [B,3,1], Wc [B,K,1] + diagnostics.
+    Multi-frame windows (pairs > 1): R [B,pairs,3,3], T [B,pairs,3,1]."""
 
-    def __init__(self, R, T, Wc=None, P=6):
+    def __init__(self, R, T, Wc=None, P=6, pairs=1):
         dev = R.device
         B = R.shape[0]
-        self.R = capi.f32c(R).clone().reshape(B, 3, 3)
-        self.T = capi.f32c(T).clone().reshape(B, 3, 1)
+        shape = (B,) if pairs == 1 else (B, pairs)
+        self.R = capi.f32c(R).clone().reshape(*shape, 3, 3)
+        self.T = capi.f32c(T).clone().reshape(*shape, 3, 1)
         self.Wc = capi.f32c(Wc).clone() if Wc is not None else None
         self.iters = torch.zeros(B, dtype=torch.int32, device=dev)
         self.ratio = torch.zeros(B, dtype=torch.float32, device=dev)
@@ -118,7 +120,8 @@ class LevelProblem:
     """One banet_level_t plus the tensors it points at (kept alive here)."""
 
     def __init__(self, variant, src, tgt, depth, H, W, C, basis=None, rays=None, fx=None, fy=None, ox=None, oy=None,
-                 intr=None, scale=1.0, dense=False, tgt_has_grad=True, normalize_rays=False):
+                 intr=None, scale=1.0, dense=False, tgt_has_grad=True, normalize_rays=False, pairs=1):
+        """pairs > 1: multi-frame window, tgt [B,pairs,H,W,C(3C)] (banet_level_t.pairs)"""
         v = _VARIANT_OF[variant] if isinstance(variant, str) else int(variant)
         keep = [capi.f32c(x) if x is not None else None for x in (src, tgt, depth, basis, rays, fx, fy, ox, oy, intr)]
         src, tgt, depth, basis, rays, fx, fy, ox, oy, intr = keep
@@ -130,16 +133,17 @@ class LevelProblem:
         lv.B, lv.N, lv.C, lv.K, lv.H, lv.W = B, N, C, K, H, W
         lv.variant, lv.dense, lv.tgt_has_grad = v, int(dense), int(tgt_has_grad)
         lv.normalize_rays, lv.scale = int(normalize_rays), float(scale)
+        lv.pairs = int(pairs)
         for name, t in (("src", src), ("tgt", tgt), ("depth", depth), ("basis", basis), ("rays", rays), ("fx", fx),
                         ("fy", fy), ("ox", ox), ("oy", oy), ("intr", intr)):
             setattr(lv, name, None if t is None else t.data_ptr())
             if t is not None and not t.is_cuda:
                 raise capi.BanetError("banet_amd runs on the GPU only (%s is on %s)" % (name, t.device))
-        expect_tgt = B * H * W * C * (3 if tgt_has_grad else 1)
+        expect_tgt = B * int(pairs) * H * W * C * (3 if tgt_has_grad else 1)
         if tgt.numel() != expect_tgt or src.numel() != B * N * C:
             raise capi.BanetError("level tensors have inconsistent sizes")
         self.c = lv
-        self.B, self.N, self.C, self.K, self.P = B, N, C, K, 6 + K
+        self.B, self.N, self.C, self.K, self.P, self.pairs = B, N, C, K, 6 * int(pairs) + K, int(pairs)
         self.device = tgt.device
 
 

@@ -31,7 +31,7 @@ extern "C" {
 typedef void* banet_stream_t; /* a hipStream_t (NULL = default stream) */
 #endif
 
-#define BANET_VERSION 100 /* 0.1.0 */
+#define BANET_VERSION 110 /* 0.1.1: banet_level_t.pairs */
 
 enum {
   BANET_OK = 0,
@@ -97,9 +97,15 @@ typedef struct banet_level {
                               the kernel from the map (same arithmetic as grad_fixed)      */
   int32_t normalize_rays; /* dense only: 1 = bundlenet.py:119, 0 = legacy/ba.py:33-34     */
   float scale;          /* dense only: level scale s (points, intrinsics = full-res / s)  */
-  int32_t reserved_;
+  int32_t pairs;        /* target frames per window (F - 1); 0 or 1 = the reference's 2-frame
+                           case.  pairs > 1 (bundle variants only) is the multi-frame window
+                           of SURVEY.md 8(d): the key frame carries depth / basis / Wc, every
+                           other frame its own pose; P = 6 pairs + K, parameter order
+                           [pose_1 .. pose_pairs, depth]                                     */
+  int32_t reserved_;    /* must be 0 (development switches)                               */
+  int32_t pad_;         /* must be 0                                                      */
   const float* src;     /* dense: source map [B,H,W,C];  sparse: conv1 [B,N,C]            */
-  const float* tgt;     /* target map [B,H,W,C] or [B,H,W,3C]                             */
+  const float* tgt;     /* target maps [B,pairs,H,W,C] or [B,pairs,H,W,3C]                */
   const float* depth;   /* D  [B,N]   (legacy: z-depth; bundle: range along the ray)      */
   const float* basis;   /* Bs [B,N,K] or NULL when K == 0                                 */
   const float* rays;    /* sparse: p [B,3,N] (bundlenet.py:115-119); dense: NULL          */
@@ -118,7 +124,7 @@ typedef struct banet_mlp {
 } banet_mlp_t;
 
 /* Per-window LM state carried across iterations and levels (device memory, caller-owned).
- *   R [B,9]  T [B,3]  Wc [B,K]      current estimate (input and output)
+ *   R [B,pairs,9]  T [B,pairs,3]  Wc [B,K]   current estimate (input and output)
  *   iters [B] int32                 iterations executed at the current level
  *   ratio [B]                       legacy "keep ratio" (legacy/ba.py:214 / :344)
  *   lambda_out [B]                  last lambda (diagnostic)
@@ -136,7 +142,8 @@ typedef struct banet_state {
 /* (3) one fused assembly pass: warp -> sample -> residual/gradient -> Jacobians -> normal
  *     equations, for all B windows at the pose (R,T,Wc) -- replaces the TF graph of
  *     bundlenet.py:206-263 / legacy/ba.py:238-283 plus the EquationConstruction op.
- *       AtA [B,P,P], Atb [B,P]  (P = 6 + K), absres [B,C] = sum_n |d_nc|, nvalid [B]    */
+ *       AtA [B,P,P], Atb [B,P]  (P = 6 pairs + K), absres [B,C] = sum over pairs and n of
+ *       |d_nc|, nvalid [B] = sum over pairs of the in-image point counts                 */
 size_t banet_ba_assemble_workspace_bytes(const banet_level_t* lv);
 int banet_ba_assemble_f32(const banet_level_t* lv, const float* R, const float* T,
                           const float* Wc, float* AtA, float* Atb, float* absres,

@@ -569,6 +569,54 @@ def bundle_iteration(conv1, conv2, fx, fy, ox, oy, p, D, Bs, R, T, W, mlp, l2_ba
     return Rn, Tn, Wn, dict(AtA=AtA0, Atb=Atb, lam=lam, avg=avg, solution=sol, mask=mask)
 
 
+def bundle_window_iteration(conv1, conv2s, fx, fy, ox, oy, p, D, Bs, Rs, Ts, W, mlp, l2_base=None, eq=None):
+    """Multi-frame window (F = 1 + len(conv2s) frames): NOT in the reference -- the definition fixed
+    by SURVEY.md par. 8(d): keyframe 0 carries D0, the basis and W; every other frame i has its own
+    (R_i, T_i) and contributes an independent BundleIteration term (bundlenet.py:206-263, the same
+    functions as bundle_iteration above, unchanged); P = 6 (F-1) + K, parameter order
+    [pose_1 .. pose_{F-1}, depth]; the rows of all pairs go through ONE EquationConstruction, so
+    AtA is block-arrowhead (pose blocks on the diagonal, shared depth block summed).  lambda:
+    bundlenet.py:241-253 with the residual averaged over all pairs; damping, solve and updates as
+    bundlenet.py:264-276 (last coefficient undamped).  With one pair this IS bundle_iteration.
+    conv2s: list of target maps [B,H,W,3C]; Rs [pairs][B,3,3]; Ts [pairs][B,3,1]."""
+    eq = eq or equation_construction
+    dt = conv1.dtype.type
+    pairs = len(conv2s)
+    K = Bs.shape[-1]
+    Pn = 6 * pairs + K
+    Dn = D + np.matmul(Bs, W)
+    Js, Gs, ds, avgs, masks = [], [], [], [], []
+    for i in range(pairs):
+        w = warp(Rs[i], Ts[i], p, Dn, fx, fy, ox, oy)
+        diff, grad, mask = _bundle_residuals(conv1, conv2s[i], w)
+        avgs.append(np.mean(np.abs(diff[..., 0]), axis=1, keepdims=True))
+        Jc = camera_jacobian(w["x"], w["y"], w["Z"], fx, fy, -1)
+        jd = depth_jacobian(w["rx"], w["ry"], w["rz"], w["x"], w["y"], w["Z"], fx, fy)
+        Jd = np.matmul(jd[..., None], Bs[:, :, None, :])
+        J = np.zeros(Jc.shape[:3] + (Pn,), conv1.dtype)
+        J[..., 6 * i:6 * i + 6] = Jc
+        J[..., 6 * pairs:] = Jd
+        Js.append(J)
+        Gs.append(grad)
+        ds.append(diff)
+        masks.append(mask)
+    avg = sum(avgs) / dt(pairs)
+    y = lambda_mlp(avg, mlp)
+    lam = np.sqrt(np.sum(avg * avg, axis=-1, keepdims=True)) ** (dt(2.0) + y)
+    if l2_base is not None:
+        lam = dt(l2_base) * lam
+    AtA0, Atb = eq(np.concatenate(Js, axis=1), np.concatenate(Gs, axis=1), np.concatenate(ds, axis=1))
+    AtA = damp(AtA0, lam, undamped_last=True)
+    sol = solve_lu(AtA, Atb)
+    Rn, Tn = [], []
+    for i in range(pairs):
+        r, t = _se3_update(sol[:, 6 * i:6 * i + 6], Rs[i], Ts[i])
+        Rn.append(r)
+        Tn.append(t)
+    Wn = W + sol[:, 6 * pairs:]
+    return Rn, Tn, Wn, dict(AtA=AtA0, Atb=Atb, lam=lam, avg=avg, solution=sol, mask=masks)
+
+
 def _crop_intrinsics(intrisic, N):
     """bundlenet.py:298-302 / :354-357 (crop 4 px, rescale to 320x256)."""
     dt = intrisic.dtype.type

@@ -101,3 +101,30 @@ def solve_legacy(intr, levels, mlps, iters, early_termination=True, dtype=np.flo
         Ts.append(T[0])
         ratios.append(float(np.squeeze(ratio)))
     return np.stack(Rs), np.stack(Ts), np.array(ratios), counts
+
+
+def batch_window_scene(scenes):
+    """stack oracle/synth.make_window_scene dicts: tgt becomes [B,pairs,H,W,C]"""
+    return batch_scene(scenes)
+
+
+def solve_bundle_window(intr, levels, mlps, iters, l2_base=1000.0, dtype=np.float32, R0=None, T0=None):
+    """Fixed-count dense multi-frame window BA (banet_oracle.bundle_window_iteration).  levels[i]["tgt"] is
+    [B,pairs,H,W,C].  Returns (Rs [pairs][B,3,3], Ts [pairs][B,3,1], W, hist)."""
+    B, pairs = levels[0]["tgt"].shape[:2]
+    K = levels[0]["basis"].shape[-1]
+    Rs = [np.tile(np.eye(3, dtype=dtype)[None], (B, 1, 1)) if R0 is None else R0[:, i].astype(dtype) for i in range(pairs)]
+    Ts = [np.zeros((B, 3, 1), dtype) if T0 is None else T0[:, i].astype(dtype) for i in range(pairs)]
+    W = np.zeros((B, K, 1), dtype)
+    hist = []
+    for li, (lv, n_it) in enumerate(zip(levels, iters)):
+        one = dict(lv)
+        one["tgt"] = lv["tgt"][:, 0]
+        a = level_inputs(intr, one, True, dtype)
+        conv2s = [orc.target_map(lv["tgt"][:, i].astype(dtype)) for i in range(pairs)]
+        for _ in range(n_it):
+            Rs, Ts, W, dbg = orc.bundle_window_iteration(a["conv1"], conv2s, a["fx"], a["fy"], a["ox"], a["oy"], a["p"],
+                                                         a["D"], a["Bs"], Rs, Ts, W, mlps[li], l2_base)
+            hist.append(dict(level=li, delta=dbg["solution"][:, :, 0], lam=dbg["lam"], AtA=dbg["AtA"], Atb=dbg["Atb"],
+                             avg=dbg["avg"]))
+    return Rs, Ts, W, hist

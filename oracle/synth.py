@@ -98,3 +98,54 @@ def make_pair_scene(H, W, C, K, levels, seed, normalize_rays, w_gt=None, t_gt=No
                                D0=D0.astype(dtype), basis=basis.astype(dtype)))
     return dict(intr=np.array([fx, fy, ox, oy], dtype), R_gt=R, T_gt=T, W_gt=Wc_gt, levels=out_levels,
                 H=H, W=W, C=C, K=K)
+
+
+def make_window_scene(H, W, C, K, levels, seed, pairs, normalize_rays=True, rot_mag=0.012, trans_mag=0.03,
+                      Wc_gt=None, noise=0.0, dtype=np.float32):
+    """Dense multi-frame window (not in the reference): ONE key frame with depth
+    D0 + basis.W_gt and `pairs` target frames with their own GT poses.  Key-frame features are the
+    analytic field on the pixel grid; target frame i shows the same field moved by its pose:
+    F2_i(u') = field(warp_i^-1(u')), with the inverse warp found by fixed-point iteration (the
+    warps are near-identity, so it contracts by ~0.05 per step).
+    Returns dict(intr, R_gt [pairs,3,3], T_gt [pairs,3], W_gt, levels=[dict(scale,H,W,src,tgt[pairs],D0,basis)])."""
+    rng = np.random.RandomState(seed)
+    field = make_field(C, seed + 17)
+    fx = fy = 0.8 * W
+    ox, oy = W / 2.0, H / 2.0
+    w_gt = rng.uniform(-1, 1, (pairs, 3)) * rot_mag
+    t_gt = rng.uniform(-1, 1, (pairs, 3)) * trans_mag
+    if Wc_gt is None:
+        Wc_gt = rng.standard_normal(max(K, 1)) * 0.08 / np.sqrt(max(K, 1))
+    Wc_gt = np.asarray(Wc_gt, np.float64)[:K]
+    Rs = [rodrigues(w_gt[i]) for i in range(pairs)]
+
+    def warp(i, u, v):  # key-frame pixel (full-res coordinates) -> target-frame pixel
+        basis = dct_basis(u, v, W, H, K) if K > 0 else None
+        Dgt = depth0(u, v, W, H) + (basis @ Wc_gt if K > 0 else 0.0)
+        ray = np.stack([(u - ox) / fx, (v - oy) / fy, np.ones_like(u)], axis=-1)
+        if normalize_rays:
+            ray = ray / np.linalg.norm(ray, axis=-1, keepdims=True)
+        X = (ray * Dgt[..., None]) @ Rs[i].T + t_gt[i]
+        return fx * X[..., 0] / X[..., 2] + ox, fy * X[..., 1] / X[..., 2] + oy
+
+    out_levels = []
+    for s in levels:
+        Hl, Wl = H // s, W // s
+        vv, uu = np.meshgrid(np.arange(Hl, dtype=np.float64) * s, np.arange(Wl, dtype=np.float64) * s, indexing="ij")
+        basis = dct_basis(uu, vv, W, H, K) if K > 0 else np.zeros(uu.shape + (0,))
+        D0 = depth0(uu, vv, W, H)
+        src = eval_field(field, uu, vv)
+        tgts = []
+        for i in range(pairs):
+            u, v = uu.copy(), vv.copy()
+            for _ in range(14):
+                pu, pv = warp(i, u, v)
+                u, v = u + (uu - pu), v + (vv - pv)
+            t = eval_field(field, u, v)
+            if noise > 0:
+                t = t + rng.standard_normal(t.shape) * noise
+            tgts.append(t.astype(dtype))
+        out_levels.append(dict(scale=s, H=Hl, W=Wl, src=src.astype(dtype), tgt=np.stack(tgts), D0=D0.astype(dtype),
+                               basis=basis.astype(dtype)))
+    return dict(intr=np.array([fx, fy, ox, oy], dtype), R_gt=np.stack(Rs), T_gt=t_gt, W_gt=Wc_gt, levels=out_levels,
+                H=H, W=W, C=C, K=K, pairs=pairs)

@@ -40,7 +40,7 @@ def test_every_declared_symbol_is_exported(capi):
 
 def test_version_and_error_strings(capi):
     L = capi.lib()
-    assert L.banet_version() == 100
+    assert L.banet_version() == 110
     assert L.banet_error_string(0) == b"ok"
     assert b"workspace" in L.banet_error_string(-2)
 
@@ -49,15 +49,15 @@ def test_struct_layouts_match_the_header(capi, tmp_path):
     """compile a tiny C program against the header and compare sizeof/offsetof with ctypes"""
     prog = tmp_path / "layout.c"
     prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "banet_hip.h"\n'
-                    'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(banet_level_t), '
+                    'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(banet_level_t), '
                     'offsetof(banet_level_t, scale), offsetof(banet_level_t, src), offsetof(banet_level_t, intr), '
                     'sizeof(banet_mlp_t), sizeof(banet_state_t), offsetof(banet_state_t, iters), '
-                    'offsetof(banet_level_t, variant));return 0;}\n')
+                    'offsetof(banet_level_t, variant), offsetof(banet_level_t, pairs));return 0;}\n')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     want = [ctypes.sizeof(capi.Level), capi.Level.scale.offset, capi.Level.src.offset, capi.Level.intr.offset,
-            ctypes.sizeof(capi.Mlp), ctypes.sizeof(capi.State), capi.State.iters.offset, capi.Level.variant.offset]
+            ctypes.sizeof(capi.Mlp), ctypes.sizeof(capi.State), capi.State.iters.offset, capi.Level.variant.offset, capi.Level.pairs.offset]
     assert got == want
 
 

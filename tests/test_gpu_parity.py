@@ -325,6 +325,99 @@ def test_dense_pose_only_variant_matches_oracle():
     assert relerr(n(st.R), R) < 1e-4 and relerr(n(st.T), T) < 1e-4, (relerr(n(st.R), R), relerr(n(st.T), T))
 
 
+# ======================================================================================
+# (3b) multi-frame windows (SURVEY.md 8(d) definition; BASELINE configs[2..3] are 5-frame windows)
+# ======================================================================================
+def _window_scenes(B, H, W, C, K, scales, seed, pairs):
+    return [synth.make_window_scene(H, W, C, K, scales, seed + b, pairs, rot_mag=0.012 * (1 + 0.3 * b),
+                                    trans_mag=0.04 * (1 + 0.3 * b)) for b in range(B)]
+
+
+@pytest.mark.parametrize("H,W,C,K,pairs", [(40, 56, 128, 128, 4),    # cfg-3/4 shape class: 5 frames, C = K = 128 (direct SYRK, 2 record block rows)
+                                           (40, 56, 128, 64, 2),     # 3 frames, K = 64 (direct SYRK, 1 block row)
+                                           (37, 53, 12, 16, 3),      # generic gather + LDS-tiled SYRK passes
+                                           (40, 56, 128, 32, 5)])    # 6 frames: more pairs than the direct kernel takes
+def test_window_assembly_and_iteration_match_oracle(H, W, C, K, pairs):
+    from banet_amd import dense as bdense, ops
+    B = 2
+    scenes = _window_scenes(B, H, W, C, K, [1], 77, pairs)
+    intr, levels = odense.batch_window_scene(scenes)
+    lv = levels[0]
+    rng = np.random.RandomState(4)
+    R = np.stack([[synth.rodrigues(rng.uniform(-1, 1, 3) * 0.004) for _ in range(pairs)] for _ in range(B)]).astype(np.float32)
+    T = (np.stack([s["T_gt"] for s in scenes]) * 0.8).reshape(B, pairs, 3, 1).astype(np.float32)
+    Wc = (rng.standard_normal((B, K, 1)) * 0.01).astype(np.float32)
+    mlps = [orc.he_normal_mlp_weights(C, 9)]
+    ba = bdense.DenseBA(t(intr), _torch_levels(levels), mlps, "bundle", 1000.0)
+    assert ba.pairs == pairs and ba.problems[0].P == 6 * pairs + K
+    AtA, Atb, absres, nvalid = ops.ba_assemble(ba.problems[0], t(R), t(T), t(Wc))
+    one = dict(lv)
+    one["tgt"] = lv["tgt"][:, 0]
+    a = odense.level_inputs(intr, one, True, np.float64)
+    conv2s = [orc.target_map(lv["tgt"][:, i].astype(np.float64)) for i in range(pairs)]
+    Rn, Tn, Wn, dbg = orc.bundle_window_iteration(a["conv1"], conv2s, a["fx"], a["fy"], a["ox"], a["oy"], a["p"], a["D"],
+                                                  a["Bs"], [R[:, i].astype(np.float64) for i in range(pairs)],
+                                                  [T[:, i].astype(np.float64) for i in range(pairs)],
+                                                  Wc.astype(np.float64), mlps[0], 1000.0)
+    nv = sum(m.sum(axis=(1, 2)) for m in dbg["mask"])
+    assert np.abs(n(nvalid) - nv).max() <= 1, (n(nvalid), nv)
+    assert relerr(n(absres) / (H * W * pairs), dbg["avg"][:, 0]) < 1e-5
+    got = n(AtA)
+    assert relerr(got, dbg["AtA"]) < 3e-5, relerr(got, dbg["AtA"])
+    assert relerr(n(Atb)[..., None], dbg["Atb"]) < 3e-5
+    np.testing.assert_array_equal(got, np.swapaxes(got, 1, 2))
+    for i in range(pairs):                              # block arrowhead: poses of different frames do not couple
+        for j in range(pairs):
+            if i != j:
+                assert not got[:, 6 * i:6 * i + 6, 6 * j:6 * j + 6].any()
+    st = ba.new_state(t(R.reshape(B * pairs, 3, 3)), t(T.reshape(B * pairs, 3, 1)), t(Wc))
+    ops.ba_solve_update(ba.problems[0], ba.mlps[0], 1000.0, AtA, Atb, absres, nvalid, st)
+    sol = dbg["solution"][:, :, 0]
+    assert relerr(n(st.lambda_out), dbg["lam"].reshape(-1)) < 1e-4
+    assert relerr(n(st.delta)[:, :6 * pairs], sol[:, :6 * pairs]) < 1e-4
+    assert relerr(n(st.delta)[:, 6 * pairs:], sol[:, 6 * pairs:]) < 1e-4
+    assert relerr(n(st.R), np.stack(Rn, 1)) < 1e-5 and relerr(n(st.T), np.stack(Tn, 1)) < 1e-4 and relerr(n(st.Wc), Wn) < 1e-4
+
+
+def test_window_multilevel_solve_matches_oracle_and_converges():
+    """5-frame window (4 target frames), 3 levels, fp32 oracle from the same start."""
+    from banet_amd import dense as bdense
+    B, H, W, C, K, pairs = 2, 48, 64, 16, 8, 4
+    scenes = _window_scenes(B, H, W, C, K, [4, 2, 1], 91, pairs)
+    intr, levels = odense.batch_window_scene(scenes)
+    mlps = [orc.he_normal_mlp_weights(C, 5 + i) for i in range(3)]
+    T0 = (np.stack([s["T_gt"] for s in scenes]) * 0.7).reshape(B, pairs, 3, 1).astype(np.float32)
+    iters = [3, 3, 2]
+    Rs, Ts, Wo, hist = odense.solve_bundle_window(intr, levels, mlps, iters, T0=T0)
+    ba = bdense.DenseBA(t(intr), _torch_levels(levels), mlps, "bundle", 1000.0)
+    st, counts = ba.solve(iters, ba.new_state(T=t(T0.reshape(B * pairs, 3, 1))))
+    assert [int(c[0]) for c in counts] == iters
+    eR, eT, eW = relerr(n(st.R), np.stack(Rs, 1)), relerr(n(st.T), np.stack(Ts, 1)), relerr(n(st.Wc), Wo)
+    assert eR < 1e-4 and eT < 1e-4 and eW < 2e-4, (eR, eT, eW)
+    for b in range(B):
+        for i in range(pairs):
+            assert np.abs(n(st.T)[b, i, :, 0] - scenes[b]["T_gt"][i]).max() < np.abs(T0[b, i, :, 0] - scenes[b]["T_gt"][i]).max()
+
+
+def test_window_with_one_pair_is_the_two_frame_path_bit_for_bit():
+    from banet_amd import dense as bdense, ops
+    H, W, C, K = 40, 56, 128, 128
+    scenes = _window_scenes(2, H, W, C, K, [1], 13, 1)
+    intr, levels = odense.batch_window_scene(scenes)
+    mlps = [orc.he_normal_mlp_weights(C, 9)]
+    T = (np.stack([s["T_gt"] for s in scenes]) * 0.8).reshape(2, 3, 1).astype(np.float32)
+    R = np.tile(np.eye(3, dtype=np.float32)[None], (2, 1, 1))
+    Wc = np.zeros((2, K, 1), np.float32)
+    outs = []
+    for five_d in (True, False):
+        lv = [bdense.DenseLevel(l["scale"], t(l["src"]), t(l["tgt"] if five_d else l["tgt"][:, 0]), t(l["D0"]), t(l["basis"]))
+              for l in levels]
+        ba = bdense.DenseBA(t(intr), lv, mlps, "bundle", 1000.0)
+        outs.append([n(x) for x in ops.ba_assemble(ba.problems[0], t(R), t(T), t(Wc))])
+    for x, y in zip(*outs):
+        np.testing.assert_array_equal(x, y)
+
+
 def test_dense_legacy_lm_iteration_counts_identical():
     """legacy/ba.py early-terminated LM, three windows with different motions (so that the
     per-window loops stop at different iterations), device-side loop control."""

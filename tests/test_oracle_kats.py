@@ -114,3 +114,48 @@ def test_float32_and_float64_oracles_agree_and_converge():
     np.testing.assert_allclose(out[np.float32][1], out[np.float64][1], rtol=2e-4, atol=1e-6)
     np.testing.assert_allclose(out[np.float32][2], out[np.float64][2], rtol=2e-3, atol=2e-5)
     assert np.abs(out[np.float64][1][0, :, 0] - sc["T_gt"]).max() < 0.3 * np.abs(np.asarray(sc["T_gt"])).max() * 0.3 + 5e-3
+
+
+def test_window_iteration_extends_bundle_iteration():
+    """The multi-frame window (not in the reference) reuses the reference's per-pair functions:
+    with one pair it IS bundle_iteration (bit for bit); with several the normal matrix is block-arrowhead
+    and equals the sum of the per-pair normal equations embedded at their pose slots."""
+    from oracle import dense as od, synth
+    sc = [synth.make_window_scene(24, 32, 8, 4, [1], 9 + i, 3) for i in range(2)]
+    intr, levels = od.batch_window_scene(sc)
+    lv = levels[0]
+    one = dict(lv)
+    one["tgt"] = lv["tgt"][:, 0]
+    a = od.level_inputs(intr, one, True)
+    mlp = orc.he_normal_mlp_weights(8, 3)
+    B, pairs, K = 2, 3, 4
+    R = [np.tile(np.eye(3, dtype=np.float32)[None], (B, 1, 1)) for _ in range(pairs)]
+    T = [(np.stack([s["T_gt"][i] for s in sc]) * 0.7).astype(np.float32).reshape(B, 3, 1) for i in range(pairs)]
+    W = np.zeros((B, K, 1), np.float32)
+    conv2s = [orc.target_map(lv["tgt"][:, i]) for i in range(pairs)]
+    r1 = orc.bundle_iteration(a["conv1"], conv2s[0], a["fx"], a["fy"], a["ox"], a["oy"], a["p"], a["D"], a["Bs"], R[0], T[0], W, mlp, 1000.0)
+    rw = orc.bundle_window_iteration(a["conv1"], conv2s[:1], a["fx"], a["fy"], a["ox"], a["oy"], a["p"], a["D"], a["Bs"], R[:1], T[:1], W, mlp, 1000.0)
+    np.testing.assert_array_equal(r1[0], rw[0][0])
+    np.testing.assert_array_equal(r1[1], rw[1][0])
+    np.testing.assert_array_equal(r1[2], rw[2])
+    full = orc.bundle_window_iteration(a["conv1"], conv2s, a["fx"], a["fy"], a["ox"], a["oy"], a["p"], a["D"], a["Bs"], R, T, W, mlp, 1000.0)[3]
+    A = full["AtA"].astype(np.float64)
+    want = np.zeros_like(A)
+    rhs = np.zeros(full["Atb"].shape, np.float64)
+    P6 = 6 * pairs
+    for i in range(pairs):
+        d = orc.bundle_iteration(a["conv1"], conv2s[i], a["fx"], a["fy"], a["ox"], a["oy"], a["p"], a["D"], a["Bs"], R[i], T[i], W, mlp, 1000.0)[3]
+        Ai, bi = d["AtA"].astype(np.float64), d["Atb"].astype(np.float64)
+        sl = slice(6 * i, 6 * i + 6)
+        want[:, sl, sl] += Ai[:, :6, :6]
+        want[:, sl, P6:] += Ai[:, :6, 6:]
+        want[:, P6:, sl] += Ai[:, 6:, :6]
+        want[:, P6:, P6:] += Ai[:, 6:, 6:]
+        rhs[:, sl] += bi[:, :6]
+        rhs[:, P6:] += bi[:, 6:]
+    assert np.abs(A - want).max() / np.abs(want).max() < 1e-5
+    assert np.abs(full["Atb"] - rhs).max() / np.abs(rhs).max() < 1e-5
+    for i in range(pairs):
+        for j in range(pairs):
+            if i != j:
+                assert not A[:, 6 * i:6 * i + 6, 6 * j:6 * j + 6].any()
