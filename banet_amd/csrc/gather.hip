@@ -456,14 +456,18 @@ int plan_gather(const banet_level_t* lv, GatherPlan* pl) {
   const int resident = kCUs * (pl->c128 ? kC128BlocksPerCU : kGenericBlocksPerCU);
   const int VB = lv->B * npairs(lv);   // virtual windows
   int target = (resident + VB - 1) / VB;
-  int G = pl->groups;
+  // quarter-tile work items pay (measured: 40x30 x 8 windows 94 -> 50 us) only while they still leave the chip
+  // mostly empty -- at most one item per SIMD; beyond that the redone depth dot / geometry costs more than
+  // the shorter step chain saves (80x60 x 8: 101 -> 132 us).  reserved_ bit 4: off (A/B).
+  pl->qshift = (pl->c128 && (long long)pl->tiles * VB * 4 <= (long long)kCUs * 4 && !(lv->reserved_ & 16)) ? 2 : 0;
+  int G = pl->c128 ? ((pl->tiles << pl->qshift) + 3) / 4 : pl->groups;
   if (G > target) G = target;
   if (G < 1) G = 1;
   if (G >= 8) G &= ~7;
   pl->G = G;
   pl->nbands = (G & 7) == 0 ? 8 : 1;
   pl->pstride = kGHdr + lv->C;
-  pl->rows = pl->c128 ? pl->tiles : G;
+  pl->rows = pl->c128 ? (pl->tiles << pl->qshift) : G;
   pl->frows = pl->rows > kFoldRows ? (pl->rows + kFoldRows - 1) / kFoldRows : pl->rows;
   const size_t row_bytes = (size_t)VB * pl->pstride * sizeof(float);
   pl->off_fold = align_up(row_bytes * pl->rows, 256);
@@ -556,6 +560,7 @@ int launch_gather(const banet_level_t* lv, const GatherPlan& pl, const float* R,
   a.queue = reinterpret_cast<int*>(reinterpret_cast<char*>(partials) + pl.off_queue);
   a.nbands = pl.nbands;
   a.pairs = npairs(lv);
+  a.qshift = pl.qshift;
   int rc;
   if (pl.c128)
     rc = launch_gather128(a, lv->K, s);

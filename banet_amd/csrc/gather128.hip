@@ -71,7 +71,9 @@ __global__ __launch_bounds__(kBlock, BANET_G128_WAVES) void ba_gather128_kernel(
   const float* __restrict__ dep_b = lv.depth + (size_t)b * N;
   const float* __restrict__ bas_b = KV4 ? lv.basis + (size_t)b * N * K : nullptr;
   float* __restrict__ rec_b = KV4 ? a.rec + (size_t)vb * N * 8 : nullptr;
-  float* __restrict__ part_b = a.partials + (size_t)vb * a.tiles * (kGHdr + C);
+  const int qshift = a.qshift;                       // 2: a work item is one quarter (16 pixels, 4 steps) of a tile
+  const int nitems = a.tiles << qshift;
+  float* __restrict__ part_b = a.partials + (size_t)vb * nitems * (kGHdr + C);
   const int grp = lane >> 4, sub = lane & 15;
   const int half = lane >> 5, li = lane & 31;
 
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(kBlock, BANET_G128_WAVES) void ba_gather128_kernel(
   const int nb = a.nbands;
   int* __restrict__ queue = a.queue + vb * 8;
   int band = nb > 1 ? (g & 7) : 0, left = nb;
-  auto band_lo = [&](int x) { return (int)(((long long)a.tiles * x) / nb); };
+  auto band_lo = [&](int x) { return (int)(((long long)nitems * x) / nb); };
   auto pop = [&](int x) {  // wave-uniform
     int v = 0;
     if (lane == 0) v = atomicAdd(&queue[x], 1);
@@ -99,12 +101,18 @@ __global__ __launch_bounds__(kBlock, BANET_G128_WAVES) void ba_gather128_kernel(
   int t_next = pop(band);
 
   while (true) {
-    int t = t_next;
-    while (t >= band_lo(band + 1)) {  // this band is drained: move on (a drained band stays drained)
+    int wi = t_next;
+    while (wi >= band_lo(band + 1)) {  // this band is drained: move on (a drained band stays drained)
       if (--left == 0) return;
       band = band + 1 == nb ? 0 : band + 1;
-      t = pop(band);
+      wi = pop(band);
     }
+    // Small levels (fewer tiles than resident waves) are latency-bound: there a tile is split into 4
+    // work items that each redo the tile's (cheap) depth dot and geometry but gather only their own
+    // 16 pixels -- 4x the waves, a quarter of the serial step chain.
+    const int t = wi >> qshift;
+    const int s_lo = qshift ? 4 * (wi & 3) : 0, s_hi = qshift ? s_lo + 4 : 16;
+    const bool mine = (lane >> 2) >= s_lo && (lane >> 2) < s_hi;   // lane = pixel: pixels 4 s .. 4 s + 3 belong to step s
     t_next = pop(band);  // issued now, consumed after this tile: the atomic's latency is hidden
     BANET_TICK(tb0);
     int tx = 0, ty = 0;
@@ -258,7 +266,7 @@ __global__ __launch_bounds__(kBlock, BANET_G128_WAVES) void ba_gather128_kernel(
     BANET_TICK(tb2);
     // ---- 3. gather: 16 steps x 4 pixels; lane = (pixel group, 8-channel slice) --------------
     const int rowC = W * C;
-    for (int s = 0; s < 16; ++s) {
+    for (int s = s_lo; s < s_hi; ++s) {
       const int j = 4 * s + grp;
       const float4 pa = *reinterpret_cast<const float4*>(&sPar[w][j][0]);
       const float4 pb = *reinterpret_cast<const float4*>(&sPar[w][j][4]);
@@ -339,7 +347,7 @@ __global__ __launch_bounds__(kBlock, BANET_G128_WAVES) void ba_gather128_kernel(
     }
     {
       // patch the pixels whose stencil touches the image rim (rare): generic slow routine
-      unsigned long long slow = __ballot((gflags & 4) != 0);
+      unsigned long long slow = __ballot((gflags & 4) != 0 && mine);
       while (slow) {  // wave-uniform
         const int j = __builtin_ctzll(slow);
         slow &= slow - 1;
@@ -363,7 +371,11 @@ __global__ __launch_bounds__(kBlock, BANET_G128_WAVES) void ba_gather128_kernel(
     BANET_TICK(tb3);
 
     // ---- 4. per-pixel 6x6 algebra (lane = pixel), then the tile's 28 pose sums --------------
-    float* __restrict__ part = part_b + (size_t)t * (kGHdr + C);
+    float* __restrict__ part = part_b + (size_t)wi * (kGHdr + C);
+    if (!mine) {   // pixels of the other quarters: exact zeros (sQ holds stale sums for them)
+      q = Q5{0.f, 0.f, 0.f, 0.f, 0.f};
+      gflags = 0;
+    }
     {
       float mj[12];
 #pragma unroll
@@ -393,7 +405,7 @@ __global__ __launch_bounds__(kBlock, BANET_G128_WAVES) void ba_gather128_kernel(
       if ((lane & 1) == 0 && leaf < 28) part[leaf] = tot;
 
       if constexpr (KV4 > 0) {
-        if (valid) {
+        if (valid && mine) {
           const float md0 = q.m11 * jd0 + q.m12 * jd1, md1 = q.m12 * jd0 + q.m22 * jd1;
           float4 ua, ub;
           ua.x = jc[0] * md0 + jc[6] * md1;

@@ -18,21 +18,23 @@ def shard_range(total, rank, world):
 
 
 def pack_results(R, T, Wc, iters_per_level):
-    """-> [B_local, 12 + K + L] float32 record"""
+    """-> [B_local, 12 pairs + K + L] float32 record (R [B,(pairs,)3,3], T [B,(pairs,)3,1])"""
     B = R.shape[0]
-    parts = [R.reshape(B, 9), T.reshape(B, 3)]
+    parts = [R.reshape(B, -1), T.reshape(B, -1)]
     if Wc is not None:
         parts.append(Wc.reshape(B, -1))
     parts.append(torch.stack([c.to(torch.float32) for c in iters_per_level], dim=1))
     return torch.cat(parts, dim=1).contiguous()
 
 
-def unpack_results(rec, K, L):
+def unpack_results(rec, K, L, pairs=1):
     B = rec.shape[0]
-    R = rec[:, 0:9].reshape(B, 3, 3)
-    T = rec[:, 9:12].reshape(B, 3, 1)
-    Wc = rec[:, 12:12 + K].reshape(B, K, 1) if K > 0 else None
-    iters = rec[:, 12 + K:12 + K + L].to(torch.int32)
+    shape = (B,) if pairs == 1 else (B, pairs)
+    R = rec[:, 0:9 * pairs].reshape(*shape, 3, 3)
+    T = rec[:, 9 * pairs:12 * pairs].reshape(*shape, 3, 1)
+    o = 12 * pairs
+    Wc = rec[:, o:o + K].reshape(B, K, 1) if K > 0 else None
+    iters = rec[:, o + K:o + K + L].to(torch.int32)
     return R, T, Wc, iters
 
 

@@ -54,8 +54,13 @@ def _rodrigues(w):
 
 
 def make_dense_windows(B, H, W, C, K, scales, seed, device, normalize_rays=True, rot_mag=0.012, trans_mag=0.03,
-                       noise=0.01):
-    """B independent 2-frame windows.  Returns (intr [B,4], levels [DenseLevel coarse->fine], gt dict)."""
+                       noise=0.01, pairs=1):
+    """B independent windows.  pairs = 1: 2-frame windows, returns (intr [B,4], levels [DenseLevel
+    coarse->fine], gt dict).  pairs > 1: multi-frame windows (one key frame + `pairs` target frames, see
+    make_multiframe_windows)."""
+    if pairs > 1:
+        return make_multiframe_windows(B, H, W, C, K, scales, seed, device, pairs, normalize_rays, rot_mag, trans_mag,
+                                       noise)
     g = torch.Generator().manual_seed(seed)
     fx = fy = 0.8 * W
     ox, oy = W / 2.0, H / 2.0
@@ -87,6 +92,52 @@ def make_dense_windows(B, H, W, C, K, scales, seed, device, normalize_rays=True,
             if noise > 0:
                 tgt[b] += torch.randn(Hl, Wl, C, generator=g).to(device) * noise if Hl * Wl * C < (1 << 22) else \
                     torch.randn(Hl, Wl, C, device=device) * noise
+        depth = D0[None].repeat(B, 1, 1).contiguous()
+        basis = basis1[None].repeat(B, 1, 1, 1).contiguous() if K > 0 else None
+        levels.append(DenseLevel(s, src, tgt, depth, basis))
+    return intr, levels, dict(R=R_gt, T=t_gt, W=Wc_gt)
+
+
+def make_multiframe_windows(B, H, W, C, K, scales, seed, device, pairs, normalize_rays=True, rot_mag=0.012,
+                            trans_mag=0.03, noise=0.01):
+    """Same construction as oracle/synth.make_window_scene: key-frame features = the analytic field on
+    the grid, target frame i = the field at the inverse GT warp (fixed-point iteration), tgt [B,pairs,H,W,C].
+    gt: R [B,pairs,3,3], T [B,pairs,3], W [B,K]."""
+    g = torch.Generator().manual_seed(seed)
+    fx = fy = 0.8 * W
+    ox, oy = W / 2.0, H / 2.0
+    intr = torch.tensor([fx, fy, ox, oy], dtype=torch.float32).repeat(B, 1).to(device)
+    w_gt = (torch.rand(B, pairs, 3, generator=g) * 2 - 1) * rot_mag
+    t_gt = (torch.rand(B, pairs, 3, generator=g) * 2 - 1) * trans_mag
+    Wc_gt = torch.randn(B, max(K, 1), generator=g)[:, :K] * 0.08 / math.sqrt(max(K, 1))
+    R_gt = torch.stack([torch.stack([_rodrigues(w_gt[b, i]) for i in range(pairs)]) for b in range(B)])
+    levels = []
+    for s in scales:
+        Hl, Wl = H // s, W // s
+        vv, uu = torch.meshgrid(torch.arange(Hl, dtype=torch.float32, device=device) * s,
+                                torch.arange(Wl, dtype=torch.float32, device=device) * s, indexing="ij")
+        basis1 = _dct_basis(uu, vv, W, H, K) if K > 0 else None
+        D0 = _depth0(uu, vv, W, H)
+        src = torch.empty(B, Hl, Wl, C, dtype=torch.float32, device=device)
+        tgt = torch.empty(B, pairs, Hl, Wl, C, dtype=torch.float32, device=device)
+        for b in range(B):
+            fld = _field_params(C, seed * 1000 + 17 + b, device)
+            src[b] = _eval_field(fld, uu, vv)
+            wb = Wc_gt[b].to(device)
+            for i in range(pairs):
+                Rm, tv = R_gt[b, i].to(device), t_gt[b, i].to(device)
+                u, v = uu.clone(), vv.clone()
+                for _ in range(8):
+                    Dg = _depth0(u, v, W, H) + (_dct_basis(u, v, W, H, K) @ wb if K > 0 else 0.0)
+                    ray = torch.stack([(u - ox) / fx, (v - oy) / fy, torch.ones_like(u)], dim=-1)
+                    if normalize_rays:
+                        ray = ray / torch.linalg.norm(ray, dim=-1, keepdim=True)
+                    X = (ray * Dg[..., None]) @ Rm.T + tv
+                    u = u + (uu - (fx * X[..., 0] / X[..., 2] + ox))
+                    v = v + (vv - (fy * X[..., 1] / X[..., 2] + oy))
+                tgt[b, i] = _eval_field(fld, u, v)
+                if noise > 0:
+                    tgt[b, i] += torch.randn(Hl, Wl, C, device=device) * noise
         depth = D0[None].repeat(B, 1, 1).contiguous()
         basis = basis1[None].repeat(B, 1, 1, 1).contiguous() if K > 0 else None
         levels.append(DenseLevel(s, src, tgt, depth, basis))

@@ -69,7 +69,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--windows", type=int, default=WINDOWS_PER_GPU, help="windows per GPU")
+    ap.add_argument("--windows", type=int, default=None, help="windows per GPU (default: 8 for cfg-2, 32 for cfg-3)")
+    ap.add_argument("--frames", type=int, default=2, help="frames per window: 2 = cfg-2 (the default, BASELINE's metric "
+                    "workload); 5 = cfg-3/4, the 5-frame sliding window (key frame + 4 target frames, SURVEY 8(d))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -89,13 +91,15 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL over xGMI
 
-    B = args.windows
+    pairs = args.frames - 1
+    assert 1 <= pairs <= 4, "--frames 2..5"
+    B = args.windows if args.windows is not None else (WINDOWS_PER_GPU if pairs == 1 else 32)
     total_windows = B * world
     torch.manual_seed(1234 + rank)
-    intr, levels, gt = bsynth.make_dense_windows(B, H, W, C, K, SCALES, 1234 + 2 + rank, dev, trans_mag=0.06)
+    intr, levels, gt = bsynth.make_dense_windows(B, H, W, C, K, SCALES, 1234 + 2 + rank, dev, trans_mag=0.06, pairs=pairs)
     mlps = [he_normal_lambda_weights(C, 100 + i) for i in range(len(SCALES))]
     ba = bdense.DenseBA(intr, levels, mlps, "bundle", 1000.0)
-    T0 = (gt["T"] * 0.7).reshape(B, 3, 1).to(dev)          # translation prior: depth is unobservable from T = 0
+    T0 = (gt["T"] * 0.7).reshape(B * pairs, 3, 1).to(dev)   # translation prior: depth is unobservable from T = 0
 
     def step():
         st = ba.new_state(T=T0)
@@ -147,19 +151,23 @@ def main():
         achieved = alg_bytes / max(kern_ms, 1e-9) / 1e6            # GB/s
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and pairs == 1:   # the PMC pass was taken on cfg-2
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
-            "metric": "LM iterations/sec (2-frame 640x480 5-level dense BA, 128-coeff depth basis)",
+            "metric": "LM iterations/sec (%d-frame 640x480 5-level dense BA, 128-coeff depth basis)" % args.frames,
             "value": round(value, 2), "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "ms_per_solve": round(1e3 * elapsed / args.steps / B, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "cfg-2: 2-frame 640x480 5-level pyramid, C=128, K=128 basis, 10 LM iters/level, "
-                                   "batch %d windows per GPU, BundleIteration (bundlenet.py:193-278), dense points" % B,
+            "config": {"workload": ("cfg-2: 2-frame 640x480 5-level pyramid, C=128, K=128 basis, 10 LM iters/level, "
+                                    "batch %d windows per GPU, BundleIteration (bundlenet.py:193-278), dense points" % B)
+                       if pairs == 1 else
+                       ("cfg-3: %d-frame sliding window (key frame + %d target frames sharing depth/basis, P = %d), "
+                        "640x480 5-level pyramid, C=128, K=128, 10 LM iters/level, batch %d windows per GPU, dense points"
+                        % (args.frames, pairs, 6 * pairs + K, B)),
                        "windows_total": total_windows, "iters_per_level": ITERS, "scales": SCALES,
                        "parallelism": "windows sharded, dp%d" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -173,7 +181,7 @@ def main():
                          "pipeline_GBps": round(alg_bytes / max(kern_ms + syrk_ms, 1e-9) / 1e6, 1),
                          "per_level": per_level},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and pairs == 1:
             out["cpu_baseline"] = cpu_baseline(intr, levels, gt, mlps)
         print(json.dumps(out), flush=True)
     if world > 1:
