@@ -84,29 +84,9 @@ def DepthJacobianMatrix(rx, ry, rz, x, y, Z, fx, fy, name=None):
 
 
 def resampler(data, warp):
-    """tf.contrib.resampler.resampler restated for torch tensors: bilinear, zero padding.
-    data [B,H,W,C], warp [B,N,2] (x,y) -> [B,N,C].  Used by the per-level preparation
-    (bundlenet.py:290,320,343-344,385) -- not part of the per-iteration hot path."""
-    B, H, W, C = data.shape
-    x, y = warp[..., 0], warp[..., 1]
-    ok = (x > -1.0) & (y > -1.0) & (x < W) & (y < H)
-    xs = torch.where(ok, x, torch.zeros_like(x))
-    ys = torch.where(ok, y, torch.zeros_like(y))
-    fx_, fy_ = torch.floor(xs), torch.floor(ys)
-    cx, cy = fx_ + 1, fy_ + 1
-    dx, dy = cx - xs, cy - ys
-    flat = data.reshape(B, H * W, C)
-
-    def tap(xi, yi):
-        xi, yi = xi.long(), yi.long()
-        inside = (xi >= 0) & (yi >= 0) & (xi <= W - 1) & (yi <= H - 1)
-        idx = (yi.clamp(0, H - 1) * W + xi.clamp(0, W - 1)).unsqueeze(-1).expand(-1, -1, C)
-        v = torch.gather(flat, 1, idx)
-        return torch.where(inside.unsqueeze(-1), v, torch.zeros_like(v))
-
-    out = (dx * dy).unsqueeze(-1) * tap(fx_, fy_) + ((1 - dx) * (1 - dy)).unsqueeze(-1) * tap(cx, cy) \
-        + (dx * (1 - dy)).unsqueeze(-1) * tap(fx_, cy) + ((1 - dx) * dy).unsqueeze(-1) * tap(cx, fy_)
-    return torch.where(ok.unsqueeze(-1), out, torch.zeros_like(out))
+    """tf.contrib.resampler.resampler: bilinear, zero padding.  data [B,H,W,C], warp [B,N,2] (x,y)
+    -> [B,N,C] (bundlenet.py:290,320,343-344,385) -- HIP kernel ba_resample_kernel."""
+    return ops.resample(data, warp, clamp=False)
 
 
 def he_normal_lambda_weights(C, seed, device="cpu"):
@@ -135,11 +115,8 @@ class BundleNet:
     # -- small helpers kept for API parity --------------------------------------------
     def grad_fixed(self, input, name=None):
         """bundlenet.py:92-100"""
-        H, W = input.shape[1], input.shape[2]
-        p = torch.nn.functional.pad(input.permute(0, 3, 1, 2), (1, 1, 1, 1), mode="reflect").permute(0, 2, 3, 1)
-        gx = 0.5 * (p[:, 1:H + 1, 2:W + 2, :] - p[:, 1:H + 1, 0:W, :])
-        gy = 0.5 * (p[:, 2:H + 2, 1:W + 1, :] - p[:, 0:H, 1:W + 1, :])
-        return torch.cat([gx, gy], dim=-1)
+        C = input.shape[-1]
+        return ops.target_map(input)[..., C:]          # [gx | gy] of ba_target_map_kernel
 
     def conv1d(self, x, num_out_layers, name, activation=torch.nn.functional.elu):
         """bundlenet.py:102-110 (kernel width 1).  x [B,L,Cin]; weights looked up by name
@@ -223,8 +200,7 @@ class BundleNet:
         for level in range(0, 4):
             scale = 2 ** (3 - level)
             layer1 = resampler(layers[level], _points / scale)
-            layer2 = self._swap_halves(layers[level])
-            layer2 = torch.cat([layer2, self.grad_fixed(layer2)], dim=-1)
+            layer2 = ops.target_map(self._swap_halves(layers[level]))      # [f | gx | gy]
             R, T = self.CameraIteration(layer1, layer2, self.fx / scale, self.fy / scale, self.ox / scale,
                                         self.oy / scale, p, d, R, T, 1.0, str(level))
             rotations.append(R)
@@ -251,13 +227,12 @@ class BundleNet:
         for level in range(2, 4):
             scale = 2 ** (3 - level)
             layer1 = resampler(layers[level], _points / scale)
-            layer2 = self._swap_halves(layers[level])
-            layer2 = torch.cat([layer2, self.grad_fixed(layer2)], dim=-1)
+            layer2 = ops.target_map(self._swap_halves(layers[level]))      # [f | gx | gy]
             R, T, W = self.BundleIteration(layer1, layer2, self.fx / scale, self.fy / scale, self.ox / scale,
                                            self.oy / scale, p, d, b, R, T, W, 1000.0, str(level))
             out_R.append(R)
             out_T.append(T)
-            out_D.append(init_depth + torch.matmul(basis.reshape(nbatch, -1, nbasis), W).reshape(nbatch, Hh, Wh, 1))
+            out_D.append(ops.depth_output(init_depth, basis.reshape(nbatch, -1, nbasis), W))
         return out_R, out_T, out_D
 
     # -- losses (bundlenet.py:401-463) ---------------------------------------------------

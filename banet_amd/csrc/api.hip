@@ -210,6 +210,23 @@ int banet_lm_level_f32(const banet_level_t* lv, const banet_mlp_t* mlp, float l2
   return BANET_OK;
 }
 
+int banet_resample_f32(const float* data, const float* warp, float* out, int B, int N, int C, int H, int W, int mode,
+                       banet_stream_t stream) {
+  if (!data || !warp || !out) return BANET_ERR_INVALID_ARG;
+  return launch_resample(data, warp, out, B, N, C, H, W, mode, static_cast<hipStream_t>(stream));
+}
+
+int banet_target_map_f32(const float* img, float* out, int B, int H, int W, int C, banet_stream_t stream) {
+  if (!img || !out) return BANET_ERR_INVALID_ARG;
+  return launch_target_map(img, out, B, H, W, C, static_cast<hipStream_t>(stream));
+}
+
+int banet_depth_output_f32(const float* init_depth, const float* basis, const float* Wc, float* out, int B, int N, int K,
+                           banet_stream_t stream) {
+  if (!init_depth || !basis || !Wc || !out) return BANET_ERR_INVALID_ARG;
+  return launch_depth_output(init_depth, basis, Wc, out, B, N, K, static_cast<hipStream_t>(stream));
+}
+
 int banet_profile_begin(int max_launches) { return profile_begin(max_launches); }
 
 int banet_profile_end(int max_tags, int32_t* tag_points, int32_t* tag_launches, double* tag_ms, int32_t* ntags) {

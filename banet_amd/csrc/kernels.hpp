@@ -58,6 +58,13 @@ int launch_assemble(const banet_level_t* lv, const AsmPlan& pl, const float* R, 
 int profile_begin(int max_launches);
 int profile_end(int max_tags, int32_t* tag_points, int32_t* tag_launches, double* tag_ms, int32_t* ntags);
 
+// ---- prep.hip --------------------------------------------------------------------------
+int launch_resample(const float* data, const float* warp, float* out, int B, int N, int C, int H, int W, int mode,
+                    hipStream_t s);
+int launch_target_map(const float* img, float* out, int B, int H, int W, int C, hipStream_t s);
+int launch_depth_output(const float* init, const float* basis, const float* Wc, float* out, int B, int N, int K,
+                        hipStream_t s);
+
 // ---- eqcon.hip -------------------------------------------------------------------------
 void launch_reduce(const float* partials, int B, int G, int pstride, int P, float* AtA, float* Atb, hipStream_t s);
 struct EqPlan {

@@ -19,23 +19,9 @@ qr = True
 
 
 def interpolate2d2(imgs, p):
-    """legacy/utils_python.py:177-232: clamped bilinear, no mask.  imgs [B,H,W,C], p [B,N,2]."""
-    B, H, W, C = imgs.shape
-    x, y = p[..., 0], p[..., 1]
-    x0f, y0f = torch.floor(x), torch.floor(y)
-    dx, dy = x - x0f, y - y0f
-    x0, y0 = x0f.long(), y0f.long()
-    x1, y1 = x0 + 1, y0 + 1
-    x0, x1 = x0.clamp(0, W - 1), x1.clamp(0, W - 1)
-    y0, y1 = y0.clamp(0, H - 1), y1.clamp(0, H - 1)
-    flat = imgs.reshape(B, H * W, C)
-
-    def g(yy, xx):
-        return torch.gather(flat, 1, (yy * W + xx).unsqueeze(-1).expand(-1, -1, C))
-
-    w00, w01 = ((1 - dx) * (1 - dy)).unsqueeze(-1), (dx * (1 - dy)).unsqueeze(-1)
-    w10, w11 = ((1 - dx) * dy).unsqueeze(-1), (dx * dy).unsqueeze(-1)
-    return ((g(y0, x0) * w00 + g(y0, x1) * w01) + g(y1, x0) * w10) + g(y1, x1) * w11
+    """legacy/utils_python.py:177-232: clamped bilinear, no mask.  imgs [B,H,W,C], p [B,N,2]
+    -> [B,N,C] -- HIP kernel ba_resample_kernel (clamp mode)."""
+    return ops.resample(imgs, p, clamp=True)
 
 
 class Tracker:
@@ -54,11 +40,8 @@ class Tracker:
 
     def grad_fixed(self, input, name=None):
         """legacy/ba.py:17-25"""
-        H, W = input.shape[1], input.shape[2]
-        p = torch.nn.functional.pad(input.permute(0, 3, 1, 2), (1, 1, 1, 1), mode="reflect").permute(0, 2, 3, 1)
-        gx = 0.5 * (p[:, 1:H + 1, 2:W + 2, :] - p[:, 1:H + 1, 0:W, :])
-        gy = 0.5 * (p[:, 2:H + 2, 1:W + 1, :] - p[:, 0:H, 1:W + 1, :])
-        return torch.cat([gx, gy], dim=-1)
+        C = input.shape[-1]
+        return ops.target_map(input)[..., C:]          # [gx | gy] of ba_target_map_kernel
 
     def computeCoordinates(self, points2d, fx, fy, ox, oy):
         """legacy/ba.py:27-34 (rays NOT normalised)"""
@@ -106,8 +89,7 @@ class Tracker:
         for level in range(1, 4):
             scale = 2 ** (3 - level)
             layer1 = interpolate2d2(layers[level - 1][0:nb], points / scale)
-            layer2 = layers[level - 1][nb:2 * nb]
-            layer2 = torch.cat([layer2, self.grad_fixed(layer2)], dim=-1)
+            layer2 = ops.target_map(layers[level - 1][nb:2 * nb])          # [f | gx | gy], legacy/ba.py:116-118
             variant = "legacy_lm" if early_termination else "legacy_fixed"
             lv = self._level(variant, layer1, layer2, fx0 / scale, fy0 / scale, ox0 / scale, oy0 / scale, p, d)
             mlp = self._mlp(level, points.device) if early_termination else None

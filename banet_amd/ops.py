@@ -206,3 +206,42 @@ def profile_end(max_tags=16):
     nt = ctypes.c_int32(0)
     capi.check(capi.lib().banet_profile_end(max_tags, pts, cnt, ms, ctypes.byref(nt)))
     return {int(pts[i]): (int(cnt[i]), float(ms[i])) for i in range(nt.value)}
+
+
+# --------------------------------------------------------------------------------------
+# per-level preparation (banet_resample_f32 / banet_target_map_f32 / banet_depth_output_f32)
+# --------------------------------------------------------------------------------------
+def resample(data, warp, clamp=False):
+    """data [B,H,W,C], warp [B,N,2] -> [B,N,C].  clamp=False: tf.contrib.resampler.resampler
+    (bundlenet.py:290,320,343-344,385); clamp=True: interpolate2d2 (legacy/utils_python.py:177-232)."""
+    data, warp = capi.f32c(data), capi.f32c(warp)
+    B, H, W, C = data.shape
+    N = warp.shape[1]
+    if tuple(warp.shape) != (B, N, 2):
+        raise capi.BanetError("resample: expected data [B,H,W,C] and warp [B,N,2]; got %s %s" % (tuple(data.shape), tuple(warp.shape)))
+    out = torch.empty((B, N, C), dtype=torch.float32, device=data.device)
+    capi.check(capi.lib().banet_resample_f32(capi.ptr(data), capi.ptr(warp), capi.ptr(out), B, N, C, H, W,
+                                             1 if clamp else 0, capi.stream()))
+    return out
+
+
+def target_map(img):
+    """[B,H,W,C] -> [B,H,W,3C] = [f | gx | gy] (grad_fixed + concat: bundlenet.py:92-100,323-324; legacy/ba.py:116-118)."""
+    img = capi.f32c(img)
+    B, H, W, C = img.shape
+    out = torch.empty((B, H, W, 3 * C), dtype=torch.float32, device=img.device)
+    capi.check(capi.lib().banet_target_map_f32(capi.ptr(img), capi.ptr(out), B, H, W, C, capi.stream()))
+    return out
+
+
+def depth_output(init_depth, basis, Wc):
+    """init_depth [B,...] + basis [B,N,K] . Wc [B,K,1] -> same shape as init_depth (bundlenet.py:397)."""
+    init, basis, Wc = capi.f32c(init_depth), capi.f32c(basis), capi.f32c(Wc)
+    B, K = basis.shape[0], basis.shape[-1]
+    N = basis.numel() // (B * K)
+    if init.numel() != B * N or Wc.numel() != B * K:
+        raise capi.BanetError("depth_output: inconsistent shapes")
+    out = torch.empty_like(init)
+    capi.check(capi.lib().banet_depth_output_f32(capi.ptr(init), capi.ptr(basis), capi.ptr(Wc), capi.ptr(out), B, N, K,
+                                                 capi.stream()))
+    return out

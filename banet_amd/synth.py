@@ -100,7 +100,7 @@ def make_dense_windows(B, H, W, C, K, scales, seed, device, normalize_rays=True,
 
 def make_multiframe_windows(B, H, W, C, K, scales, seed, device, pairs, normalize_rays=True, rot_mag=0.012,
                             trans_mag=0.03, noise=0.01):
-    """Same construction as oracle/synth.make_window_scene: key-frame features = the analytic field on
+    """Same construction as make_window_scene in oracle/synth.py: key-frame features = the analytic field on
     the grid, target frame i = the field at the inverse GT warp (fixed-point iteration), tgt [B,pairs,H,W,C].
     gt: R [B,pairs,3,3], T [B,pairs,3], W [B,K]."""
     g = torch.Generator().manual_seed(seed)

@@ -166,7 +166,26 @@ int banet_lm_level_f32(const banet_level_t* lv, const banet_mlp_t* mlp, float l2
                        int max_iters, int early_termination, banet_state_t* st, void* ws,
                        size_t ws_bytes, banet_stream_t stream);
 
-/* (6) optional kernel timing, used by bench.py for the roofline figure.  Between
+/* (6) per-level preparation -- the step immediately before the LM loop.
+ *   banet_resample_f32   data [B,H,W,C], warp [B,N,2] (x,y) -> out [B,N,C]
+ *       mode BANET_RESAMPLE_ZERO_PAD : tf.contrib.resampler.resampler as called at
+ *            bundlenet.py:290,320,343-344,385 (bilinear, taps outside the image contribute 0,
+ *            points with x <= -1, y <= -1, x >= W or y >= H give 0)
+ *       mode BANET_RESAMPLE_CLAMP    : interpolate2d2, legacy/utils_python.py:177-232
+ *            (legacy/ba.py:115): weights from the unclamped floor, indices clamped
+ *   banet_target_map_f32 img [B,H,W,C] -> [B,H,W,3C] = [f | gx | gy], grad_fixed with REFLECT
+ *            padding (bundlenet.py:92-100,323-324; legacy/ba.py:17-25,116-118)
+ *   banet_depth_output_f32 out [B,N] = init_depth [B,N] + basis [B,N,K] . Wc [B,K]
+ *            (bundlenet.py:397)                                                            */
+enum { BANET_RESAMPLE_ZERO_PAD = 0, BANET_RESAMPLE_CLAMP = 1 };
+int banet_resample_f32(const float* data, const float* warp, float* out, int B, int N, int C,
+                       int H, int W, int mode, banet_stream_t stream);
+int banet_target_map_f32(const float* img, float* out, int B, int H, int W, int C,
+                         banet_stream_t stream);
+int banet_depth_output_f32(const float* init_depth, const float* basis, const float* Wc,
+                           float* out, int B, int N, int K, banet_stream_t stream);
+
+/* (7) optional kernel timing, used by bench.py for the roofline figure.  Between
  *     banet_profile_begin and banet_profile_end every launch of the fused assembly kernel
  *     (from banet_ba_assemble_f32 / banet_lm_level_f32) is bracketed by two hipEvents recorded
  *     on its stream.  banet_profile_end synchronises those events and returns, per distinct

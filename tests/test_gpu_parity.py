@@ -206,6 +206,48 @@ def test_resize_drivers_match_oracle():
 
 
 # ======================================================================================
+# (2b) per-level preparation kernels
+# ======================================================================================
+@pytest.mark.parametrize("B,H,W,C,N", [(2, 24, 32, 128, 500), (1, 17, 23, 7, 64), (3, 8, 8, 200, 33)])
+def test_resample_kernels_match_oracle(B, H, W, C, N):
+    from banet_amd import ops
+    rng = np.random.RandomState(B + H + C)
+    img = rng.standard_normal((B, H, W, C)).astype(np.float32)
+    warp = np.stack([rng.uniform(-3, W + 2, (B, N)), rng.uniform(-3, H + 2, (B, N))], -1).astype(np.float32)
+    warp[:, 0] = [0.0, 0.0]                      # exact corners / integer coordinates / borders of the zero-pad rule
+    warp[:, 1] = [W - 1.0, H - 1.0]
+    warp[:, 2] = [-1.0, 2.5]
+    warp[:, 3] = [W - 0.5, H - 0.25]
+    warp[:, 4] = [-0.5, -0.75]
+    warp[:, 5] = [float(W), 1.0]
+    got = n(ops.resample(t(img), t(warp), clamp=False))
+    want = orc.resampler(img, warp)
+    assert np.abs(got - want).max() < 2e-6 * max(1.0, np.abs(want).max())
+    assert not got[:, 2].any() and not got[:, 5].any()          # x <= -1 / x >= W: exactly zero
+    got2 = n(ops.resample(t(img), t(warp), clamp=True))
+    want2 = orc.interpolate2d2(img, warp)
+    assert np.abs(got2 - want2).max() < 2e-6 * max(1.0, np.abs(want2).max())
+    np.testing.assert_array_equal(got2[:, 0], img[:, 0, 0])      # integer coordinates: the texel itself
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 30, 40, 128), (1, 5, 7, 3), (1, 2, 2, 16)])
+def test_target_map_and_depth_output_match_oracle(B, H, W, C):
+    from banet_amd import ops
+    rng = np.random.RandomState(H * W + C)
+    img = rng.standard_normal((B, H, W, C)).astype(np.float32)
+    got = n(ops.target_map(t(img)))
+    np.testing.assert_array_equal(got, orc.target_map(img))     # differences and 0.5 scaling are exact in fp32
+    assert not got[:, 0, :, 2 * C:].any() and not got[:, :, 0, C:2 * C].any()   # REFLECT rim: zero gradient
+    K = 24
+    init = rng.uniform(1, 3, (B, H, W, 1)).astype(np.float32)
+    basis = rng.standard_normal((B, H * W, K)).astype(np.float32)
+    Wc = rng.standard_normal((B, K, 1)).astype(np.float32)
+    got = n(ops.depth_output(t(init), t(basis), t(Wc)))
+    want = init.astype(np.float64) + np.matmul(basis.astype(np.float64), Wc.astype(np.float64)).reshape(B, H, W, 1)
+    assert got.shape == init.shape and np.abs(got - want).max() < 1e-5
+
+
+# ======================================================================================
 # (3) dense fused path vs the oracle
 # ======================================================================================
 def _torch_levels(levels):
