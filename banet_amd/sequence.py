@@ -1,0 +1,93 @@
+"""Keyframe sequence driver: the caller of the legacy tracker, legacy/seq_example.py:72-83 (point
+selection) and :150-208 (keyframe loop), without file IO, OpenCV or the CNN -- frames arrive as
+feature pyramids (what `legacy/feat.py` would produce) plus, for key frames, the RGB image and the
+depth map used to pick the BA points.  Host logic in Python like the reference's; every tracking
+call goes to `Tracker.trackTF`, i.e. to libbanet_hip.so.
+"""
+import numpy as np
+import torch
+
+from . import legacy
+
+
+def sobel_x(image):
+    """cv2.Sobel(image, CV_32F, 1, 0, ksize=3) with OpenCV's default BORDER_REFLECT_101.  image [H,W,3]."""
+    p = np.pad(image.astype(np.float32), [(1, 1), (1, 1), (0, 0)], mode="reflect")
+    d = p[:, 2:] - p[:, :-2]
+    return d[:-2] + 2.0 * d[1:-1] + d[2:]
+
+
+def valid_point_and_depth(image, depth, num_points, thres, rng):
+    """legacy/seq_example.py:72-83: points with a strong image gradient and a valid depth, sampled with
+    replacement.  The reference computes the x-derivative twice (its `dy` is `Sobel(...,1,0)` too,
+    :73-74); reproduced.  -> points [1,num,2] (x,y) float32, depths [1,num,1]."""
+    H, W = depth.shape
+    dx = sobel_x(image)
+    dy = dx
+    dxy = np.sqrt(np.sum(np.square(dx), axis=-1) + np.sum(np.square(dy), axis=-1)).flatten()
+    d = depth.flatten()
+    x, y = np.meshgrid(np.linspace(0, W - 1, W), np.linspace(0, H - 1, H))
+    xy = np.stack((x.flatten(), y.flatten()), axis=-1).astype(np.float32)
+    index = np.logical_and(np.greater(dxy, thres), np.greater(d, 1e-5))
+    d, p = d[index], xy[index, :]
+    pick = rng.randint(0, p.shape[0], num_points)
+    return np.reshape(p[pick, :], (1, num_points, 2)), np.reshape(d[pick], (1, num_points, 1)).astype(np.float32)
+
+
+class KeyframeTracker:
+    """State machine of legacy/seq_example.py:150-208.  `track` returns the frame's global pose
+    (rotation, translation as the reference chains them), camera centre and whether the frame became
+    the new key frame (keep_ratio < 0.8 or more than 0.1 s since the key frame, :191)."""
+
+    def __init__(self, tracker, intrinsics, iters=(5, 8, 8), num_points=4096, thres=120.0, min_keep_ratio=0.8,
+                 max_gap=0.1, rng=None, device="cuda:0"):
+        self.tracker, self.iters = tracker, list(iters)
+        self.intrinsics = torch.as_tensor(intrinsics, dtype=torch.float32, device=device).reshape(1, 4, 1)
+        self.num_points, self.thres = num_points, thres
+        self.min_keep_ratio, self.max_gap = min_keep_ratio, max_gap
+        self.rng = rng if rng is not None else np.random.RandomState(0)
+        self.device = device
+        self.globalRotations, self.globalTranslations = [], []
+        self.keyframeIndex, self.frameIndex = 0, 0
+
+    def _reset_init(self):
+        self.initR = torch.eye(3, device=self.device).reshape(1, 3, 3)
+        self.initT = torch.zeros(1, 3, 1, device=self.device)
+
+    def _select(self, image, depth):
+        pts, d = valid_point_and_depth(image, depth, self.num_points, self.thres, self.rng)
+        self.points = torch.from_numpy(pts).to(self.device)
+        self.depths = torch.from_numpy(d).to(self.device)
+
+    def start(self, layers, image, depth, stamp):
+        """first frame = first key frame (seq_example.py:137-148)"""
+        self.key_layers, self.key_stamp = layers, float(stamp)
+        self._select(image, depth)
+        self._reset_init()
+        self.globalRotations = [torch.eye(3, device=self.device).reshape(1, 3, 3)]
+        self.globalTranslations = [torch.zeros(1, 3, 1, device=self.device)]
+        self.keyframeIndex, self.frameIndex = 0, 0
+
+    def track(self, layers, image, depth, stamp):
+        self.frameIndex += 1
+        both = [torch.cat([k, f], dim=0) for k, f in zip(self.key_layers, layers)]
+        rotation, translation, keep_ratio = self.tracker.trackTF(self.intrinsics, both, self.points, self.depths,
+                                                                 self.initR, self.initT, self.iters)
+        rotation, translation = rotation.clone(), translation.clone()
+        keep_ratio = float(keep_ratio.reshape(-1)[0])
+        gR = torch.matmul(rotation, self.globalRotations[self.keyframeIndex])                       # :168
+        gT = torch.matmul(rotation, translation) + self.globalTranslations[self.keyframeIndex]      # :169 (as written)
+        self.globalRotations.append(gR)
+        self.globalTranslations.append(gT)
+        camera = -torch.matmul(gR.transpose(1, 2).double(), gT.double()).flatten()                   # :174-175
+        switched = keep_ratio < self.min_keep_ratio or (float(stamp) - self.key_stamp) > self.max_gap   # :191
+        if switched:
+            self.keyframeIndex = self.frameIndex
+            self.key_layers, self.key_stamp = layers, float(stamp)
+            self._select(image, depth)
+            self._reset_init()
+        else:
+            self.initR, self.initT = rotation, translation
+        return dict(rotation=rotation, translation=translation, keep_ratio=keep_ratio, globalRotation=gR,
+                    globalTranslation=gT, camera=camera, new_keyframe=switched, iters=[int(c[0]) for c in
+                                                                                         self.tracker.level_iters_run])

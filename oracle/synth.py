@@ -149,3 +149,38 @@ def make_window_scene(H, W, C, K, levels, seed, pairs, normalize_rays=True, rot_
                                basis=basis.astype(dtype)))
     return dict(intr=np.array([fx, fy, ox, oy], dtype), R_gt=np.stack(Rs), T_gt=t_gt, W_gt=Wc_gt, levels=out_levels,
                 H=H, W=W, C=C, K=K, pairs=pairs)
+
+
+def make_plane_sequence(H, W, C, poses, seed, levels=(4, 2, 1), plane_n=(0.05, -0.03, 1.0), plane_d=3.0, dtype=np.float32):
+    """A camera moving in front of a textured plane: every frame pair is exactly consistent, so any frame
+    can serve as key frame (what the sequence driver needs).  poses: list of (w [3], t [3]) mapping frame-0
+    coordinates to frame-i coordinates (frame 0 = identity).  Returns dict(intr [1,4,1], frames =
+    [pyramid per frame: list of [1,H_l,W_l,C]], depths = [z-depth map [H,W] per frame], images = [H,W,3])."""
+    field = make_field(C, seed + 17, wl_min=24.0, wl_max=160.0)
+    fx = fy = 0.8 * W
+    ox, oy = W / 2.0, H / 2.0
+    n = np.asarray(plane_n, np.float64)
+    n = n / np.linalg.norm(n)
+    frames, depths, images = [], [], []
+    for (w, t) in poses:
+        R, t = rodrigues(np.asarray(w, np.float64)), np.asarray(t, np.float64)
+        Rn = R @ n
+
+        def sample(u, v):
+            ray = np.stack([(u - ox) / fx, (v - oy) / fy, np.ones_like(u)], axis=-1)
+            lam = (plane_d + Rn @ t) / (ray @ Rn)
+            X0 = (ray * lam[..., None] - t) @ R          # R^T (X_i - t)
+            return fx * X0[..., 0] / X0[..., 2] + ox, fy * X0[..., 1] / X0[..., 2] + oy, lam
+
+        pyr = []
+        for s in levels:
+            vv, uu = np.meshgrid(np.arange(H // s, dtype=np.float64) * s, np.arange(W // s, dtype=np.float64) * s, indexing="ij")
+            pu, pv, _ = sample(uu, vv)
+            pyr.append(eval_field(field, pu, pv).astype(dtype)[None])
+        vv, uu = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+        pu, pv, lam = sample(uu, vv)
+        frames.append(pyr)
+        depths.append(lam.astype(dtype))
+        img = eval_field(field, pu, pv)[..., :3]
+        images.append((127.5 + 100.0 * img).astype(dtype))
+    return dict(intr=np.array([fx, fy, ox, oy], dtype).reshape(1, 4, 1), frames=frames, depths=depths, images=images)

@@ -582,3 +582,54 @@ def test_full_size_solve_reduces_residual_and_pose_error(full_size):
     e1 = (st.T[:, :, 0].cpu() - gt["T"]).abs().amax(1)
     assert (e1 < e0).all(), (e0, e1)
     assert torch.isfinite(st.Wc).all() and torch.isfinite(st.R).all()
+
+
+# ======================================================================================
+# (5) caller: the keyframe sequence driver (legacy/seq_example.py:150-208)
+# ======================================================================================
+def test_keyframe_sequence_driver_matches_oracle():
+    from banet_amd import legacy, sequence
+    from oracle import sequence as oseq
+    H, W, C, N = 96, 128, 8, 512
+    poses = [((0, 0, 0), (0, 0, 0))] + [((0.004 * i, -0.003 * i, 0.002 * i), (0.02 * i, -0.012 * i, 0.008 * i)) for i in range(1, 5)]
+    seq = synth.make_plane_sequence(H, W, C, poses, 3)
+    stamps = [0.0, 0.04, 0.08, 0.12, 0.16]                      # frame 3 is > 0.1 s after key frame 0: it becomes the key frame
+    mlps = {str(l): orc.he_normal_mlp_weights(C, 40 + l) for l in (1, 2, 3)}
+    iters = [5, 8, 8]
+    picks = {}
+
+    def select(i):                                            # same points for both sides (host logic, fixed seed per key frame)
+        if i not in picks:
+            picks[i] = sequence.valid_point_and_depth(seq["images"][i], seq["depths"][i], N, 5.0, np.random.RandomState(100 + i))
+        return picks[i]
+
+    want = oseq.run_sequence(seq["intr"], seq["frames"], stamps, select, mlps, iters)
+
+    class FixedRng:                                           # the driver draws its points through rng.randint
+        def __init__(self):
+            self.key = 0
+
+        def randint(self, lo, hi, num):
+            return np.random.RandomState(100 + self.key).randint(lo, hi, num)
+
+    legacy.early_termination = True
+    rng = FixedRng()
+    drv = sequence.KeyframeTracker(legacy.Tracker(lambda_weights=mlps, iters=iters), seq["intr"], iters=iters, num_points=N,
+                                   thres=5.0, rng=rng, device=DEV)
+    drv.start([t(l) for l in seq["frames"][0]], seq["images"][0], seq["depths"][0], stamps[0])
+    got = []
+    for i in range(1, 5):
+        rng.key = i
+        got.append(drv.track([t(l) for l in seq["frames"][i]], seq["images"][i], seq["depths"][i], stamps[i]))
+    assert [g["new_keyframe"] for g in got] == [w["new_keyframe"] for w in want] == [False, False, True, False]
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g["iters"] == w["iters"], (i, g["iters"], w["iters"])
+        assert relerr(n(g["rotation"]), w["rotation"]) < 1e-4 and relerr(n(g["translation"]), w["translation"]) < 1e-4
+        assert relerr(n(g["globalRotation"]), w["globalRotation"]) < 1e-4
+        assert relerr(n(g["globalTranslation"]), w["globalTranslation"]) < 1e-4
+        assert abs(g["keep_ratio"] - w["keep_ratio"]) < 1e-5
+        assert np.abs(n(g["camera"]) - w["camera"]).max() < 1e-4 * max(1.0, np.abs(w["camera"]).max())
+    # the tracker recovers the motion (frame 1 vs key frame 0; legacy z-depth convention)
+    R1 = synth.rodrigues(np.asarray(poses[1][0], np.float64))
+    assert np.abs(n(got[0]["rotation"])[0] - R1).max() < 2e-3
+    assert np.abs(n(got[0]["translation"])[0, :, 0] - np.asarray(poses[1][1])).max() < 5e-3
