@@ -1,0 +1,42 @@
+"""Host logic of the keyframe sequence driver and its oracle twin (no GPU needed)."""
+import numpy as np
+
+from oracle import banet_oracle as orc, sequence as oseq, synth
+
+
+def test_sobel_matches_scipy_and_point_selection_follows_the_reference_rule():
+    from scipy import ndimage
+    from banet_amd import sequence
+    rng = np.random.RandomState(0)
+    img = rng.uniform(0, 255, (20, 30, 3)).astype(np.float32)
+    want = np.stack([ndimage.sobel(img[..., c], axis=1, mode="mirror") for c in range(3)], -1)   # cv2 BORDER_REFLECT_101
+    np.testing.assert_allclose(sequence.sobel_x(img), want, rtol=0, atol=1e-3)
+    depth = rng.uniform(0.5, 3, (20, 30)).astype(np.float32)
+    depth[:, :5] = 0.0                                            # invalid depth: never selected
+    pts, d = sequence.valid_point_and_depth(img, depth, 200, 50.0, np.random.RandomState(1))
+    assert pts.shape == (1, 200, 2) and d.shape == (1, 200, 1) and (d > 1e-5).all() and (pts[..., 0] >= 5).all()
+    gx = sequence.sobel_x(img)
+    mag = np.sqrt(2.0 * np.sum(gx * gx, -1))                      # the reference takes the x-derivative twice
+    xi, yi = pts[0, :, 0].astype(int), pts[0, :, 1].astype(int)
+    assert (mag[yi, xi] > 50.0).all()
+    np.testing.assert_array_equal(d[0, :, 0], depth[yi, xi])
+
+
+def test_oracle_sequence_recovers_motion_and_switches_keyframes():
+    from banet_amd import sequence
+    H, W, C, N = 96, 128, 8, 512
+    poses = [((0, 0, 0), (0, 0, 0))] + [((0.004 * i, -0.003 * i, 0.002 * i), (0.02 * i, -0.012 * i, 0.008 * i)) for i in range(1, 5)]
+    seq = synth.make_plane_sequence(H, W, C, poses, 3)
+    mlps = {str(l): orc.he_normal_mlp_weights(C, 40 + l) for l in (1, 2, 3)}
+
+    def select(i):
+        return sequence.valid_point_and_depth(seq["images"][i], seq["depths"][i], N, 5.0, np.random.RandomState(100 + i))
+
+    out = oseq.run_sequence(seq["intr"], seq["frames"], [0.0, 0.04, 0.08, 0.12, 0.16], select, mlps, [5, 8, 8])
+    assert [o["new_keyframe"] for o in out] == [False, False, True, False]
+    for i in (0, 1, 2):                                           # tracked against key frame 0
+        assert np.abs(out[i]["translation"].ravel() - np.asarray(poses[i + 1][1])).max() < 2e-3
+        assert np.abs(out[i]["rotation"][0] - synth.rodrigues(np.asarray(poses[i + 1][0], float))).max() < 1e-3
+    # frame 4 is tracked against key frame 3: relative motion, chained into the global pose (seq_example.py:168-169)
+    np.testing.assert_allclose(out[3]["globalRotation"], np.matmul(out[3]["rotation"], out[2]["globalRotation"]), atol=1e-6)
+    assert all(1 <= c <= m for o in out for c, m in zip(o["iters"], [5, 8, 8]))
