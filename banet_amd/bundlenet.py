@@ -89,6 +89,32 @@ def resampler(data, warp):
     return ops.resample(data, warp, clamp=False)
 
 
+def _resampler_autograd(data, warp):
+    """tf.contrib.resampler.resampler as a differentiable torch expression (gradients w.r.t. the map
+    and, through the bilinear weights, w.r.t. the coordinates -- the TF op's gradient).  Only used by
+    the training graph below; the forward-only paths use ops.resample (HIP)."""
+    B, H, W, C = data.shape
+    x, y = warp[..., 0], warp[..., 1]
+    ok = (x > -1.0) & (y > -1.0) & (x < W) & (y < H)
+    xs = torch.where(ok, x, torch.zeros_like(x))
+    ys = torch.where(ok, y, torch.zeros_like(y))
+    fx_, fy_ = torch.floor(xs), torch.floor(ys)
+    cx, cy = fx_ + 1, fy_ + 1
+    dx, dy = cx - xs, cy - ys
+    flat = data.reshape(B, H * W, C)
+
+    def tap(xi, yi):
+        xi, yi = xi.long(), yi.long()
+        inside = (xi >= 0) & (yi >= 0) & (xi <= W - 1) & (yi <= H - 1)
+        idx = (yi.clamp(0, H - 1) * W + xi.clamp(0, W - 1)).unsqueeze(-1).expand(-1, -1, C)
+        v = torch.gather(flat, 1, idx)
+        return torch.where(inside.unsqueeze(-1), v, torch.zeros_like(v))
+
+    out = (dx * dy).unsqueeze(-1) * tap(fx_, fy_) + ((1 - dx) * (1 - dy)).unsqueeze(-1) * tap(cx, cy) \
+        + (dx * (1 - dy)).unsqueeze(-1) * tap(fx_, cy) + ((1 - dx) * dy).unsqueeze(-1) * tap(cx, fy_)
+    return torch.where(ok.unsqueeze(-1), out, torch.zeros_like(out))
+
+
 def he_normal_lambda_weights(C, seed, device="cpu"):
     """lambda_<level>_<i> weights as bundlenet.py:105-106 creates them (he_normal, zero bias)."""
     g = torch.Generator().manual_seed(seed)
@@ -111,6 +137,10 @@ class BundleNet:
         self.reuse_variables = reuse_variables
         self.lambda_weights = dict(lambda_weights or {})
         self._mlp_cache = {}
+        # training graph: True = exact gradients (the upstream dL/dAtA is symmetrised before the op's
+        # backward); False = the reference's registered gradient verbatim (inexact: matrix_solve's
+        # gradient w.r.t. AtA is not symmetric, utils.cu:648-657 assumes it is)
+        self.exact_gradients = True
 
     # -- small helpers kept for API parity --------------------------------------------
     def grad_fixed(self, input, name=None):
@@ -144,6 +174,11 @@ class BundleNet:
     # -- the two iteration bodies -------------------------------------------------------
     def CameraIteration(self, conv1, conv2, fx, fy, ox, oy, p, D, R, T, l2_regularizer_base=None, level=None):
         """bundlenet.py:122-191: one pose-only GN/LM step -> (updatedR, updatedT)."""
+        if torch.is_grad_enabled() and any(torch.is_tensor(x) and x.requires_grad
+                                           for x in (conv1, conv2, D, R, T) + self._lambda_tensors(level)):
+            R2, T2, _ = self._iteration_autograd(conv1, conv2, fx, fy, ox, oy, p, D, None, R, T, None, l2_regularizer_base,
+                                                 level)
+            return R2, T2
         B, H, W, C3 = conv2.shape
         C = conv1.shape[2]
         lv = ops.LevelProblem("bundle_camera", conv1, conv2, D, H, W, C, rays=p, fx=fx, fy=fy, ox=ox, oy=oy,
@@ -156,6 +191,9 @@ class BundleNet:
 
     def BundleIteration(self, conv1, conv2, fx, fy, ox, oy, p, D, B, R, T, W, l2_regularizer_base=None, level=None):
         """bundlenet.py:193-278: pose + depth-basis step -> (updatedR, updatedT, updatedW)."""
+        if torch.is_grad_enabled() and any(torch.is_tensor(x) and x.requires_grad
+                                           for x in (conv1, conv2, D, B, R, T, W) + self._lambda_tensors(level)):
+            return self._iteration_autograd(conv1, conv2, fx, fy, ox, oy, p, D, B, R, T, W, l2_regularizer_base, level)
         nb, H, Wd, C3 = conv2.shape
         C = conv1.shape[2]
         K = B.shape[-1]
@@ -167,6 +205,63 @@ class BundleNet:
         ops.ba_solve_update(lv, self._mlp(level, conv1.device), l2, AtA, Atb, absres, nvalid, st)
         self.last = dict(AtA=AtA, Atb=Atb, lam=st.lambda_out, delta=st.delta)
         return st.R, st.T, st.Wc
+
+    # -- the training graph -------------------------------------------------------------------
+    def _lambda_tensors(self, level):
+        lw = self.lambda_weights.get(str(level))
+        return tuple(t for pair in lw for t in pair if torch.is_tensor(t)) if lw else ()
+
+    def _iteration_autograd(self, conv1, conv2, fx, fy, ox, oy, p, D, B, R, T, W, l2_regularizer_base, level):
+        """The reference's differentiable graph, statement for statement (bundlenet.py:193-278, and
+        :122-191 when B is None): standard differentiable tensor ops + the custom op
+        `equation_construction`, whose backward is the HIP EquationConstructionGrad kernel
+        (bundlenet.py:79-82) -- exactly the reference's split between TF autodiff and utils.cu.
+        Taken automatically when an input or a lambda weight requires grad; the forward-only calls
+        use the fused kernels.  Same values as the fused path (tested at 1e-4)."""
+        nb, npix, C = conv1.shape
+        H, Wd = conv2.shape[1], conv2.shape[2]
+        bundle = B is not None
+        if bundle:
+            D = D + torch.matmul(B, W)                                                   # :207
+        Rp = torch.matmul(R, p)
+        rx, ry, rz = Rp[:, 0], Rp[:, 1], Rp[:, 2]
+        RPT = Rp * D.transpose(1, 2) + T                                                # :210-213
+        X, Y, Z = RPT[:, 0], RPT[:, 1], RPT[:, 2]
+        x, y = X / Z, Y / Z
+        px, py = fx * x + ox, fy * y + oy
+        samp = _resampler_autograd(conv2, torch.stack([px, py], dim=-1))                # :230
+        mask = (~((px < 0) | (px > float(Wd - 1)) | (py < 0) | (py > float(H - 1)))).to(conv1.dtype)[..., None, None]
+        diff = (conv1 - samp[:, :, 0:C]).unsqueeze(-1) * mask                           # :234,238
+        grad = torch.stack([samp[:, :, C:2 * C], samp[:, :, 2 * C:3 * C]], dim=-1) * mask
+        avg = diff.squeeze(-1).abs().mean(dim=1, keepdim=True)                          # :243
+        h = avg
+        lw = self.lambda_weights[str(level)]
+        for i, (w, b) in enumerate(lw):
+            z = torch.matmul(h, w.to(h.device)) + b.to(h.device)
+            h = torch.tanh(z) if i == 4 else torch.nn.functional.selu(z)
+        lam = torch.linalg.vector_norm(avg, dim=-1, keepdim=True) ** (2.0 + h)          # :249
+        if l2_regularizer_base is not None:
+            lam = l2_regularizer_base * lam
+        J = CameraJacobianMatrix(x, y, Z, fx, fy)                                       # :259
+        if bundle:
+            jd = DepthJacobianMatrix(rx.unsqueeze(1), ry.unsqueeze(1), rz.unsqueeze(1), x, y, Z, fx, fy)
+            J = torch.cat([J, jd.unsqueeze(-1) * B.unsqueeze(-2)], dim=-1)              # :260-261
+        AtA, Atb = ops.equation_construction(J, grad, diff, symmetric_grad=self.exact_gradients)   # :263 (HIP fwd + bwd)
+        diag = torch.diagonal(AtA, dim1=1, dim2=2)
+        if bundle:
+            damp = torch.cat([diag[:, :-1] + 1e-5, torch.zeros(nb, 1, device=diag.device)], dim=-1)   # :266
+        else:
+            damp = diag + 1e-5                                                          # :182
+        AtA = AtA + torch.diag_embed(damp * lam.squeeze(-1))
+        sol = torch.linalg.solve(AtA, Atb)                                              # :267
+        wx, wy, wz = sol[:, 0], sol[:, 1], sol[:, 2]
+        dr = AngleaAxisRotation(wx, wy, wz)
+        dv = VMatrix(wx.reshape(-1), wy.reshape(-1), wz.reshape(-1))
+        updatedR = torch.matmul(dr, R)
+        updatedT = torch.matmul(dv, sol[:, 3:6]) + torch.matmul(dr, T)
+        updatedW = W + sol[:, 6:] if bundle else None
+        self.last = dict(AtA=AtA, Atb=Atb, lam=lam.reshape(-1), delta=sol[..., 0])
+        return updatedR, updatedT, updatedW
 
     # -- level drivers ------------------------------------------------------------------
     @staticmethod

@@ -58,19 +58,26 @@ class _EquationConstruction(torch.autograd.Function):
     reference registers with @ops.RegisterGradient (bundlenet.py:79-82)."""
 
     @staticmethod
-    def forward(ctx, jacobian, gradient, difference):
+    def forward(ctx, jacobian, gradient, difference, symmetric_grad):
         ctx.save_for_backward(jacobian, gradient, difference)
+        ctx.symmetric_grad = bool(symmetric_grad)
         return equation_construction_forward(jacobian, gradient, difference)
 
     @staticmethod
     def backward(ctx, left_grad, right_grad):
         J, G, d = ctx.saved_tensors
-        return equation_construction_grad(J, G, d, left_grad, right_grad)
+        if ctx.symmetric_grad:
+            left_grad = 0.5 * (left_grad + left_grad.transpose(1, 2))
+        return equation_construction_grad(J, G, d, left_grad, right_grad) + (None,)
 
 
-def equation_construction(jacobian, gradient, difference):
-    """`util.equation_construction(jacobian=, gradient=, difference=)` -> (AtA [B,P,P], Atb [B,P,1])."""
-    return _EquationConstruction.apply(jacobian, gradient, difference)
+def equation_construction(jacobian, gradient, difference, symmetric_grad=False):
+    """`util.equation_construction(jacobian=, gradient=, difference=)` -> (AtA [B,P,P], Atb [B,P,1]).
+    The registered gradient is the reference's (utils.cu:648-657: dA = 2 A g0 + d g1^T), which is the
+    true gradient only for a symmetric upstream g0 = dL/dAtA.  symmetric_grad=True feeds it
+    (g0 + g0^T)/2 instead -- the exact gradient for any g0, identical to the reference's whenever the
+    reference's is exact."""
+    return _EquationConstruction.apply(jacobian, gradient, difference, symmetric_grad)
 
 
 # --------------------------------------------------------------------------------------

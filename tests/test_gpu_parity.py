@@ -633,3 +633,60 @@ def test_keyframe_sequence_driver_matches_oracle():
     R1 = synth.rodrigues(np.asarray(poses[1][0], np.float64))
     assert np.abs(n(got[0]["rotation"])[0] - R1).max() < 2e-3
     assert np.abs(n(got[0]["translation"])[0, :, 0] - np.asarray(poses[1][1])).max() < 5e-3
+
+
+# ======================================================================================
+# (6) the layer as a differentiable op (north_star: "differentiable BA layer"): training graph =
+#     differentiable tensor ops + equation_construction with its HIP backward, as in the reference
+# ======================================================================================
+def _sparse_case(seed, B=2, H=24, W=32, C=6, K=5, N=300):
+    rng = np.random.RandomState(seed)
+    sc = [synth.make_pair_scene(H, W, C, K, [1], seed + b, normalize_rays=True) for b in range(B)]
+    intr, levels = odense.batch_scene(sc)
+    lv = levels[0]
+    pts = np.stack([rng.uniform(2, W - 3, (B, N)), rng.uniform(2, H - 3, (B, N))], -1).astype(np.float32)
+    fx = np.repeat(intr[:, 0:1], N, 1); fy = np.repeat(intr[:, 1:2], N, 1)
+    ox = np.repeat(intr[:, 2:3], N, 1); oy = np.repeat(intr[:, 3:4], N, 1)
+    p = orc.compute_coordinates(pts, fx, fy, ox, oy, True)
+    conv1 = orc.resampler(lv["src"], pts)
+    conv2 = orc.target_map(lv["tgt"])
+    D = orc.resampler(lv["D0"][..., None], pts)
+    Bs = orc.resampler(lv["basis"], pts)
+    R = np.stack([synth.rodrigues(rng.uniform(-1, 1, 3) * 0.003) for _ in range(B)]).astype(np.float32)
+    T = np.stack([np.asarray(s["T_gt"]) * 0.8 for s in sc]).reshape(B, 3, 1).astype(np.float32)
+    Wc = (rng.standard_normal((B, K, 1)) * 0.01).astype(np.float32)
+    return dict(conv1=conv1, conv2=conv2, fx=fx, fy=fy, ox=ox, oy=oy, p=p, D=D, Bs=Bs, R=R, T=T, W=Wc,
+                mlp=orc.he_normal_mlp_weights(C, 7))
+
+
+def test_training_graph_matches_fused_forward_and_finite_difference_gradients():
+    from banet_amd.bundlenet import BundleNet
+    c = _sparse_case(17)
+    names = ["conv1", "conv2", "fx", "fy", "ox", "oy", "p", "D", "Bs", "R", "T", "W"]
+    net = BundleNet(lambda_weights={"2": [(t(w), t(b)) for w, b in c["mlp"]]})
+    args = {k: t(c[k]) for k in names}
+    with torch.no_grad():
+        Rf, Tf, Wf = net.BundleIteration(*[args[k] for k in names], 1000.0, "2")           # fused HIP path
+    leaves = {k: args[k].clone().requires_grad_(True) for k in ("conv1", "conv2", "D", "Bs", "T", "W")}
+    call = [leaves.get(k, args[k]) for k in names]
+    Ra, Ta, Wa = net.BundleIteration(*call, 1000.0, "2")                                  # autograd graph
+    assert relerr(n(Ra), n(Rf)) < 1e-5 and relerr(n(Ta), n(Tf)) < 1e-4 and relerr(n(Wa), n(Wf)) < 1e-4
+    rng = np.random.RandomState(5)
+    cR, cT, cW = [rng.standard_normal(x.shape) for x in (n(Ra), n(Ta), n(Wa))]
+    loss = (Ra * t(cR)).sum() + (Ta * t(cT)).sum() + (Wa * t(cW)).sum()
+    grads = torch.autograd.grad(loss, list(leaves.values()))
+    grads = dict(zip(leaves.keys(), [n(g).astype(np.float64) for g in grads]))
+
+    def oracle_loss(over):                                                            # float64 oracle forward
+        a = {k: (over[k] if k in over else c[k]).astype(np.float64) for k in names}
+        R2, T2, W2, _ = orc.bundle_iteration(a["conv1"], a["conv2"], a["fx"], a["fy"], a["ox"], a["oy"], a["p"], a["D"],
+                                             a["Bs"], a["R"], a["T"], a["W"], c["mlp"], 1000.0)
+        return float((R2 * cR).sum() + (T2 * cT).sum() + (W2 * cW).sum())
+
+    for k in ("conv1", "conv2", "D", "Bs", "T", "W"):
+        v = rng.standard_normal(c[k].shape)
+        v /= np.linalg.norm(v)
+        eps = 1e-4 if k in ("conv1", "conv2", "Bs") else 1e-5
+        fd = (oracle_loss({k: c[k].astype(np.float64) + eps * v}) - oracle_loss({k: c[k].astype(np.float64) - eps * v})) / (2 * eps)
+        ad = float((grads[k] * v).sum())
+        assert abs(ad - fd) <= 3e-2 * max(abs(fd), abs(ad)) + 1e-6, (k, ad, fd)
