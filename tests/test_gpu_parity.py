@@ -421,6 +421,50 @@ def test_window_assembly_and_iteration_match_oracle(H, W, C, K, pairs):
     assert relerr(n(st.R), np.stack(Rn, 1)) < 1e-5 and relerr(n(st.T), np.stack(Tn, 1)) < 1e-4 and relerr(n(st.Wc), Wn) < 1e-4
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_random_shape_sweep_assembly_matches_oracle(seed):
+    """seeded random shapes (ragged tiles, tiny / odd channel counts, K not a multiple of 4, 1-3 target frames,
+    both gather kernels, both SYRK kernels, pose-only and bundle) against the float64 oracle"""
+    from banet_amd import dense as bdense, ops
+    rng = np.random.RandomState(1000 + seed)
+    B = int(rng.randint(1, 4))
+    H, W = int(rng.randint(9, 41)), int(rng.randint(9, 61))
+    C = int(rng.choice([1, 2, 3, 5, 8, 13, 20, 128, 128]))
+    K = int(rng.choice([0, 1, 3, 4, 7, 16, 20, 32, 64]))
+    pairs = int(rng.randint(1, 4))
+    scenes = [synth.make_window_scene(H, W, C, K, [1], 500 + 10 * seed + b, pairs, rot_mag=0.02, trans_mag=0.08) for b in range(B)]
+    intr, levels = odense.batch_window_scene(scenes)
+    lv = levels[0]
+    R = np.stack([[synth.rodrigues(rng.uniform(-1, 1, 3) * 0.006) for _ in range(pairs)] for _ in range(B)]).astype(np.float32)
+    T = (np.stack([s["T_gt"] for s in scenes]) * 0.8).reshape(B, pairs, 3, 1).astype(np.float32)
+    Wc = (rng.standard_normal((B, K, 1)) * 0.01).astype(np.float32)
+    mlps = [orc.he_normal_mlp_weights(C, 9)]
+    ba = bdense.DenseBA(t(intr), _torch_levels(levels), mlps, "bundle" if K else "bundle_camera", 1000.0)
+    AtA, Atb, absres, nvalid = ops.ba_assemble(ba.problems[0], t(R), t(T), t(Wc) if K else None)
+    one = dict(lv)
+    one["tgt"] = lv["tgt"][:, 0]
+    a = odense.level_inputs(intr, one, True, np.float64)
+    R64 = [R[:, i].astype(np.float64) for i in range(pairs)]
+    T64 = [T[:, i].astype(np.float64) for i in range(pairs)]
+    if K:
+        conv2s = [orc.target_map(lv["tgt"][:, i].astype(np.float64)) for i in range(pairs)]
+        dbg = orc.bundle_window_iteration(a["conv1"], conv2s, a["fx"], a["fy"], a["ox"], a["oy"], a["p"], a["D"], a["Bs"],
+                                          R64, T64, Wc.astype(np.float64), mlps[0], 1000.0)[3]
+        want_A, want_b = dbg["AtA"], dbg["Atb"]
+    else:                                                         # pose only: independent 6x6 systems per target frame
+        P = 6 * pairs
+        want_A, want_b = np.zeros((B, P, P)), np.zeros((B, P, 1))
+        for i in range(pairs):
+            d = orc.bundle_camera_iteration(a["conv1"], orc.target_map(lv["tgt"][:, i].astype(np.float64)), a["fx"], a["fy"],
+                                            a["ox"], a["oy"], a["p"], a["D"], R64[i], T64[i], mlps[0], 1.0)[2]
+            want_A[:, 6 * i:6 * i + 6, 6 * i:6 * i + 6] = d["AtA"]
+            want_b[:, 6 * i:6 * i + 6] = d["Atb"]
+    cfg = (B, H, W, C, K, pairs)
+    assert relerr(n(AtA), want_A) < 5e-5, (cfg, relerr(n(AtA), want_A))
+    assert relerr(n(Atb)[..., None], want_b) < 5e-5, (cfg, relerr(n(Atb)[..., None], want_b))
+    np.testing.assert_array_equal(n(AtA), np.swapaxes(n(AtA), 1, 2))
+
+
 def test_window_multilevel_solve_matches_oracle_and_converges():
     """5-frame window (4 target frames), 3 levels, fp32 oracle from the same start."""
     from banet_amd import dense as bdense
