@@ -72,7 +72,7 @@ int profile_end(int max_tags, int32_t* tag_points, int32_t* tag_launches, double
 int plan_assemble(const banet_level_t* lv, AsmPlan* pl) {
   int rc = plan_gather(lv, &pl->g);
   if (rc != BANET_OK) return rc;
-  rc = plan_syrk(lv->B, lv->N, lv->K, npairs(lv), &pl->s);
+  rc = plan_syrk(lv->B, lv->N, lv->K, npairs(lv), lv->reserved_, &pl->s);
   if (rc != BANET_OK) return rc;
   pl->P = 6 * npairs(lv) + lv->K;
   pl->off_rec = pl->g.partial_bytes;

@@ -36,7 +36,7 @@ struct SyrkPlan {
   int direct;   // 1: ba_syrk_direct_kernel (K = 64 / 128), 0: the LDS-tiled kernel
   size_t partial_bytes;
 };
-int plan_syrk(int B, int N, int K, int pairs, SyrkPlan* pl);
+int plan_syrk(int B, int N, int K, int pairs, int dbg, SyrkPlan* pl);
 int launch_syrk(const float* basis, const float* rec, int B, int N, int K, int pairs, const SyrkPlan& pl,
                 const int32_t* active, int active_stride, float* partials, hipStream_t s);
 void launch_reduce2(const float* gpart, int Gg, int gstride, const float* spart, int Gs, int sstride,

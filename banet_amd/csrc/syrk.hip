@@ -411,6 +411,200 @@ __global__ __launch_bounds__(kBlock, 1) void ba_syrk_direct_kernel(const SyrkArg
 }
 
 // --------------------------------------------------------------------------------------
+// ba_syrk_bf16x6_kernel -- same sums as ba_syrk_direct_kernel, H_dd on the bf16 matrix pipe at fp32
+// accuracy.  s_n = jd^T M jd >= 0 (M is a Gram matrix), so H_dd = sum (sqrt(s_n) b_n)(sqrt(s_n) b_n)^T:
+// A and B operands are the SAME values v = sqrt(s) b.  Each fp32 v is split EXACTLY into three bf16
+// pieces (v = hi + mid + lo: 8 + 8 + 8 significand bits, by masking and exact subtractions), and
+//   v w  =  hi hi' + (hi mid' + mid hi') + (hi lo' + lo hi' + mid mid')  + O(2^-24 |v w|)
+// -- six v_mfma_f32_16x16x32_bf16 (products exact in fp32, fp32 accumulate) per 32 pixels and block,
+// 6 x 17 cycles against 8 x 32 cycles for v_mfma_f32_16x16x4_f32: 2.5x less matrix-pipe time, the
+// dropped terms are below fp32 rounding.  Lane (m, kq) loads, for the 8 pixels 8 kq .. 8 kq + 7 of a
+// 32-pixel step, the coefficients {4m..4m+3} + 64h (16-byte loads, 256 contiguous bytes per pixel and
+// 16 lanes); one register quad per virtual block and piece is then directly an MFMA operand (k = pixel).
+// H_cd / Atb_d stay on v_mfma_f32_16x16x4_f32 with the raw fp32 values (u is not non-negative).
+// --------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int KH, int PAIRS>
+__global__ __launch_bounds__(kBlock, 1) void ba_syrk_bf16x6_kernel(const SyrkArgs a) {
+  constexpr int NBV = 4 * KH, NPAIR = NBV * (NBV + 1) / 2, K = 64 * KH;
+  constexpr int NU = (PAIRS + 1) / 2;
+  __shared__ float sAcc[NPAIR + NU * NBV][4][64];
+  const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  if (a.active != nullptr && a.active[(size_t)b * a.active_stride] == 0) return;
+  const int w = wave_id();
+  const int N = a.N;
+  const int m = lane & 15, kq = lane >> 4;
+  const float* __restrict__ bas_b = a.basis + (size_t)b * N * K;
+  const float* __restrict__ rec_b = a.rec + (size_t)b * PAIRS * N * 8;
+  size_t uoff[NU];
+  bool uon[NU];
+#pragma unroll
+  for (int j = 0; j < NU; ++j) {
+    int pair = -1, word = 0;
+    if (m < 12) {
+      pair = 2 * j + m / 6;
+      word = m % 6;
+    } else if (j == 0) {
+      pair = m - 12;
+      word = 7;
+    }
+    uon[j] = pair >= 0 && pair < PAIRS;
+    uoff[j] = uon[j] ? (size_t)pair * N * 8 + word : 0;
+  }
+
+  f32x4 acc[NPAIR];
+  f32x4 acu[NU][NBV];
+#pragma unroll
+  for (int q = 0; q < NPAIR; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < NU; ++j)
+#pragma unroll
+    for (int q = 0; q < NBV; ++q) acu[j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // this wave's run of 32-pixel steps
+  const int ns = (N + 31) >> 5, nwaves = a.Gs * kNumWaves, gw = g * kNumWaves + w;
+  const int s0 = (int)(((long long)ns * gw) / nwaves), s1 = (int)(((long long)ns * (gw + 1)) / nwaves);
+
+  f32x4 pb[8][KH];
+  float ps[8][PAIRS], pu[8][NU];
+  auto issue = [&](int st) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int pix = 32 * st + 8 * kq + i;
+      const size_t p = (st < s1 && pix < N) ? (size_t)pix : 0;
+#pragma unroll
+      for (int h = 0; h < KH; ++h)
+        pb[i][h] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(bas_b + p * K + 64 * h + 4 * m));
+#pragma unroll
+      for (int pr = 0; pr < PAIRS; ++pr) ps[i][pr] = rec_b[((size_t)pr * N + p) * 8 + 6];
+#pragma unroll
+      for (int j = 0; j < NU; ++j) pu[i][j] = rec_b[p * 8 + uoff[j]];
+    }
+  };
+  issue(s0);
+  for (int st = s0; st < s1; ++st) {
+    // ---- H_cd / Atb_d: fp32 MFMAs on the raw values, pixel 8 kq + i as the k index of sub-step i
+    float sq[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const bool ok = 32 * st + 8 * kq + i < N;
+      float ssum = ps[i][0];
+#pragma unroll
+      for (int pr = 1; pr < PAIRS; ++pr) ssum += ps[i][pr];
+      sq[i] = ok ? sqrtf(fmaxf(ssum, 0.f)) : 0.f;          // zero switches the pixel off
+#pragma unroll
+      for (int j = 0; j < NU; ++j) {
+        const float uv = (ok && uon[j]) ? pu[i][j] : 0.f;
+#pragma unroll
+        for (int h = 0; h < KH; ++h)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acu[j][4 * h + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(uv, pb[i][h][e], acu[j][4 * h + e], 0, 0, 0);
+      }
+    }
+    // ---- exact 3-way bf16 split of v = sqrt(s) b; one register quad per (virtual block, piece)
+    u32x4 op[NBV][3];
+#pragma unroll
+    for (int h = 0; h < KH; ++h)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        unsigned pc[3][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float v = sq[i] * pb[i][h][e];
+          const unsigned hi = __float_as_uint(v) & 0xffff0000u;
+          const float r1 = v - __uint_as_float(hi);
+          const unsigned mid = __float_as_uint(r1) & 0xffff0000u;
+          const float r2 = r1 - __uint_as_float(mid);
+          pc[0][i] = hi;
+          pc[1][i] = mid;
+          pc[2][i] = __float_as_uint(r2) & 0xffff0000u;
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int d = 0; d < 4; ++d) op[4 * h + e][t][d] = (pc[t][2 * d] >> 16) | pc[t][2 * d + 1];   // k = 2d | 2d + 1
+      }
+    issue(st + 1);                                          // the raw registers are free again
+    __builtin_amdgcn_sched_barrier(0);                      // keep the prefetch ahead of the MFMA block
+    int idx = 0;
+#pragma unroll
+    for (int bi = 0; bi < NBV; ++bi)
+#pragma unroll
+      for (int bj = bi; bj < NBV; ++bj) {
+        f32x4 c = acc[idx];
+#define BANET_MM(ta, tb) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, op[bi][ta]), __builtin_bit_cast(bf16x8, op[bj][tb]), c, 0, 0, 0)
+        BANET_MM(2, 0);   // smallest terms first
+        BANET_MM(0, 2);
+        BANET_MM(1, 1);
+        BANET_MM(1, 0);
+        BANET_MM(0, 1);
+        BANET_MM(0, 0);
+#undef BANET_MM
+        acc[idx] = c;
+        ++idx;
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // ---- epilogue (as ba_syrk_direct_kernel) ------------------------------------------------------
+  for (int ww = 0; ww < kNumWaves; ++ww) {
+    if (w == ww) {
+#pragma unroll
+      for (int q = 0; q < NPAIR; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sAcc[q][r][lane] = (ww == 0 ? 0.f : sAcc[q][r][lane]) + acc[q][r];
+#pragma unroll
+      for (int j = 0; j < NU; ++j)
+#pragma unroll
+        for (int q = 0; q < NBV; ++q)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* c = &sAcc[NPAIR + j * NBV + q][r][lane];
+            *c = (ww == 0 ? 0.f : *c) + acu[j][q][r];
+          }
+    }
+    __syncthreads();
+  }
+  float* __restrict__ part = a.partials + ((size_t)b * a.Gs + g) * a.pstride;
+  const int r = w, brow = 4 * kq + r;
+#pragma unroll
+  for (int j = 0; j < NU; ++j) {
+    const int pair = 2 * j + brow / 6;
+    if (brow < 12 && pair < PAIRS) {
+#pragma unroll
+      for (int bj = 0; bj < NBV; ++bj)
+        part[(6 * pair + brow % 6) * K + 64 * (bj >> 2) + 4 * m + (bj & 3)] = sAcc[NPAIR + j * NBV + bj][r][lane];
+    }
+  }
+  if (brow == 12) {
+#pragma unroll
+    for (int bj = 0; bj < NBV; ++bj) {
+      float v = sAcc[NPAIR + bj][0][lane];
+#pragma unroll
+      for (int i = 1; i < PAIRS; ++i) v += sAcc[NPAIR + bj][i][lane];
+      part[6 * PAIRS * K + 64 * (bj >> 2) + 4 * m + (bj & 3)] = v;
+    }
+  }
+  float* pd = part + (6 * PAIRS + 1) * K;
+  {
+    int idx = 0;
+    for (int bi = 0; bi < NBV; ++bi)
+      for (int bj = bi; bj < NBV; ++bj) {
+        const int rr = 64 * (bi >> 2) + 4 * brow + (bi & 3), cc = 64 * (bj >> 2) + 4 * m + (bj & 3);
+        const float v = sAcc[idx][r][lane];
+        if (bj > bi || rr <= cc) {
+          pd[rr * K + cc] = v;
+          pd[cc * K + rr] = v;
+        }
+        ++idx;
+      }
+  }
+}
+
+// --------------------------------------------------------------------------------------
 // fixed-order reduction of the per-workgroup partials of both kernels into AtA / Atb / |r| / nvalid
 // (the deterministic counterpart of utils.cu:181-198 ColumnReduceSimpleKernel)
 // --------------------------------------------------------------------------------------
@@ -507,7 +701,7 @@ static int nb_for_k(int K) {
   return -1;
 }
 
-int plan_syrk(int B, int N, int K, int pairs, SyrkPlan* pl) {
+int plan_syrk(int B, int N, int K, int pairs, int dbg, SyrkPlan* pl) {
   pl->nb = nb_for_k(K);
   if (pl->nb < 0) return BANET_ERR_UNSUPPORTED;
   if (K == 0) {
@@ -518,7 +712,9 @@ int plan_syrk(int B, int N, int K, int pairs, SyrkPlan* pl) {
     return BANET_OK;
   }
   pl->tiles = (N + kTilePix - 1) / kTilePix;
-  pl->direct = ((K == 64 || K == 128) && pairs <= 4) ? 1 : 0;   // ba_syrk_direct_kernel: one wave per SIMD, 256 workgroups in all
+  // K = 64 / 128: barrier-free kernels, one wave per SIMD, 256 workgroups in all: 2 = ba_syrk_bf16x6_kernel
+  // (default), 1 = ba_syrk_direct_kernel (fp32 MFMA; reserved_ bit 8, A/B only)
+  pl->direct = ((K == 64 || K == 128) && pairs <= 4) ? ((dbg & 256) ? 1 : 2) : 0;
   int target = ((pl->direct ? 256 : 512) + B - 1) / B;   // LDS kernel: 2 resident workgroups per CU
   int G = pl->direct ? (N + 4 * 4 * 16 - 1) / (4 * 4 * 16) : pl->tiles / 4;   // direct: >= 16 quads per wave
   if (G > target) G = target;
@@ -542,6 +738,17 @@ static void launch_syrk_nb(const SyrkArgs& a, int B, hipStream_t s) {
 }
 
 template <int KH>
+static void launch_bf16x6(const SyrkArgs& a, int B, hipStream_t s) {
+  const dim3 grid(a.Gs, B), block(kBlock);
+  switch (a.pairs) {
+    case 1: hipLaunchKernelGGL((ba_syrk_bf16x6_kernel<KH, 1>), grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((ba_syrk_bf16x6_kernel<KH, 2>), grid, block, 0, s, a); break;
+    case 3: hipLaunchKernelGGL((ba_syrk_bf16x6_kernel<KH, 3>), grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL((ba_syrk_bf16x6_kernel<KH, 4>), grid, block, 0, s, a); break;
+  }
+}
+
+template <int KH>
 static void launch_direct(const SyrkArgs& a, int B, hipStream_t s) {
   const dim3 grid(a.Gs, B), block(kBlock);
   switch (a.pairs) {
@@ -555,6 +762,13 @@ static void launch_direct(const SyrkArgs& a, int B, hipStream_t s) {
 int launch_syrk(const float* basis, const float* rec, int B, int N, int K, int pairs, const SyrkPlan& pl,
                 const int32_t* active, int active_stride, float* partials, hipStream_t s) {
   SyrkArgs a{basis, rec, active, active_stride, partials, N, K, pl.Gs, pl.tiles, pl.pstride, pairs, 0};
+  if (pl.direct == 2) {
+    if (K == 128)
+      launch_bf16x6<2>(a, B, s);
+    else
+      launch_bf16x6<1>(a, B, s);
+    return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;
+  }
   if (pl.direct) {
     if (K == 128)
       launch_direct<2>(a, B, s);
