@@ -461,9 +461,13 @@ int plan_gather(const banet_level_t* lv, GatherPlan* pl) {
   // the shorter step chain saves (80x60 x 8: 101 -> 132 us).  reserved_ bit 4: off (A/B).
   pl->qshift = (pl->c128 && (long long)pl->tiles * VB * 4 <= (long long)kCUs * 4 && !(lv->reserved_ & 16)) ? 2 : 0;
   int G = pl->c128 ? ((pl->tiles << pl->qshift) + 3) / 4 : pl->groups;
-  if (G > target) G = target;
+  if (G > target) {
+    G = target >= 8 ? (target & ~7) : target;   // several work items per wave: one resident round, no more
+  } else if (G >= 8) {
+    G = (G + 7) & ~7;   // every item gets its own wave in ONE round (rounding down left a few items for a second
+                        // pass: 2x the latency of a level that is pure latency); surplus workgroups find nothing and exit
+  }
   if (G < 1) G = 1;
-  if (G >= 8) G &= ~7;
   pl->G = G;
   pl->nbands = (G & 7) == 0 ? 8 : 1;
   pl->pstride = kGHdr + lv->C;
