@@ -72,6 +72,8 @@ static SolveArgs make_solve_args(const banet_level_t* lv, const banet_mlp_t* mlp
   a.nvalid = nvalid;
   a.st = *st;
   a.ctl = nullptr;
+  a.queue = nullptr;
+  a.nqueue = 0;
   return a;
 }
 
@@ -200,8 +202,13 @@ int banet_lm_level_f32(const banet_level_t* lv, const banet_mlp_t* mlp, float l2
     }
   } else {
     launch_zero_iters(st->iters, lv->B, s);
+    // the tile queue is reset once here; afterwards every solve kernel leaves it zeroed for the next gather
+    a.queue = assemble_queue(pl, w.partials);
+    a.nqueue = 8 * npairs(lv);
+    if (a.queue) (void)hipMemsetAsync(a.queue, 0, (size_t)lv->B * a.nqueue * sizeof(int), s);
     for (int it = 0; it < max_iters; ++it) {
-      rc = launch_assemble(lv, pl, st->R, st->T, st->Wc, nullptr, 0, w.partials, w.AtA, w.Atb, w.absres, w.nvalid, s);
+      rc = launch_assemble(lv, pl, st->R, st->T, st->Wc, nullptr, 0, w.partials, w.AtA, w.Atb, w.absres, w.nvalid, s,
+                           a.queue == nullptr);
       if (rc != BANET_OK) return rc;
       rc = launch_solve(a, s);
       if (rc != BANET_OK) return rc;

@@ -81,16 +81,20 @@ int plan_assemble(const banet_level_t* lv, AsmPlan* pl) {
   return BANET_OK;
 }
 
+int* assemble_queue(const AsmPlan& pl, void* ws) {
+  return pl.g.c128 ? reinterpret_cast<int*>(static_cast<char*>(ws) + pl.g.off_queue) : nullptr;
+}
+
 // tags for the profiler: +N = gather kernel at a level with N points, -N = syrk kernel
 int launch_assemble(const banet_level_t* lv, const AsmPlan& pl, const float* R, const float* T, const float* Wc,
                     const int32_t* active, int active_stride, void* ws, float* AtA, float* Atb, float* absres,
-                    float* nvalid, hipStream_t s) {
+                    float* nvalid, hipStream_t s, bool reset_queue) {
   char* base = static_cast<char*>(ws);
   float* gpart = reinterpret_cast<float*>(base);
   float* rec = lv->K > 0 ? reinterpret_cast<float*>(base + pl.off_rec) : nullptr;
   float* spart = lv->K > 0 ? reinterpret_cast<float*>(base + pl.off_spart) : nullptr;
   int rc;
-  prepare_gather(lv, pl.g, gpart, s);
+  if (reset_queue) prepare_gather(lv, pl.g, gpart, s);
   {
     Timed t(s, lv->N);
     rc = launch_gather(lv, pl.g, R, T, Wc, active, active_stride, rec, gpart, s);

@@ -54,7 +54,8 @@ struct AsmPlan {
 int plan_assemble(const banet_level_t* lv, AsmPlan* pl);
 int launch_assemble(const banet_level_t* lv, const AsmPlan& pl, const float* R, const float* T, const float* Wc,
                     const int32_t* active, int active_stride, void* ws, float* AtA, float* Atb, float* absres,
-                    float* nvalid, hipStream_t s);
+                    float* nvalid, hipStream_t s, bool reset_queue = true);
+int* assemble_queue(const AsmPlan& pl, void* ws);   // the gather's tile-queue heads inside the workspace (or nullptr)
 int profile_begin(int max_launches);
 int profile_end(int max_tags, int32_t* tag_points, int32_t* tag_launches, double* tag_ms, int32_t* ntags);
 
@@ -101,6 +102,8 @@ struct SolveArgs {
   const float* nvalid;
   banet_state_t st;
   LmCtl* ctl;  // nullptr: fixed-count mode (every call performs one update)
+  int* queue;  // LM loop: the next gather's tile-queue heads, zeroed by this kernel (saves a memset per iteration)
+  int nqueue;  // words per window
 };
 int launch_solve(const SolveArgs& a, hipStream_t s);
 void launch_ctl_init(LmCtl* ctl, int32_t* iters, int B, hipStream_t s);

@@ -643,6 +643,7 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve_update_kernel(const So
   STICK(tk3);
   // ---- update -------------------------------------------------------------------------
   for (int k = tid; k < P; k += kSolveThreads) a.st.delta[(size_t)b * P + k] = sX[k];
+  if (a.queue != nullptr && tid < a.nqueue) a.queue[b * a.nqueue + tid] = 0;   // tile queue of the next gather
   for (int k = tid; k < K; k += kSolveThreads) a.st.Wc[(size_t)b * K + k] += sX[6 * pairs + k];   // bundlenet.py:276
   if (tid < pairs) {   // one thread per target frame's pose
     const int pb = b * pairs + tid;
