@@ -453,13 +453,19 @@ int plan_gather(const banet_level_t* lv, GatherPlan* pl) {
   // One resident round: the gather is latency-bound per wave (measured: a second, partial round of
   // workgroups takes as long as the first), so the grid is what the chip holds at once, split
   // across the windows.
-  const int resident = kCUs * (pl->c128 ? kC128BlocksPerCU : kGenericBlocksPerCU);
+  // Large dense levels (>= 4 tiles per resident wave): ba_gather128p_kernel -- wave-private LDS patches with a
+  // software-pipelined box prefetch, 2 workgroups per CU (measured 640x480 x 8: 138 -> 125 us/window, 320x240 x 8:
+  // 48 -> 38); smaller levels are latency-bound and keep the 3-per-CU direct kernel.  reserved_ bit 6: direct (A/B).
+  pl->patch = (pl->c128 && lv->dense && !(lv->reserved_ & 64) &&
+               ((long long)pl->tiles * lv->B * npairs(lv) >= 4LL * kCUs * BANET_G128P_WAVES * kNumWaves ||
+                (lv->reserved_ & 512))) ? 1 : 0;   // bit 9: force it at any size (parity tests)
+  const int resident = kCUs * (pl->patch ? BANET_G128P_WAVES : pl->c128 ? kC128BlocksPerCU : kGenericBlocksPerCU);
   const int VB = lv->B * npairs(lv);   // virtual windows
   int target = (resident + VB - 1) / VB;
   // quarter-tile work items pay (measured: 40x30 x 8 windows 94 -> 50 us) only while they still leave the chip
   // mostly empty -- at most one item per SIMD; beyond that the redone depth dot / geometry costs more than
   // the shorter step chain saves (80x60 x 8: 101 -> 132 us).  reserved_ bit 4: off (A/B).
-  pl->qshift = (pl->c128 && (long long)pl->tiles * VB * 4 <= (long long)kCUs * 4 && !(lv->reserved_ & 16)) ? 2 : 0;
+  pl->qshift = (pl->c128 && !pl->patch && (long long)pl->tiles * VB * 4 <= (long long)kCUs * 4 && !(lv->reserved_ & 16)) ? 2 : 0;
   int G = pl->c128 ? ((pl->tiles << pl->qshift) + 3) / 4 : pl->groups;
   if (G > target) {
     G = target >= 8 ? (target & ~7) : target;   // several work items per wave: one resident round, no more
@@ -567,7 +573,7 @@ int launch_gather(const banet_level_t* lv, const GatherPlan& pl, const float* R,
   a.qshift = pl.qshift;
   int rc;
   if (pl.c128)
-    rc = launch_gather128(a, lv->K, s);
+    rc = pl.patch ? launch_gather128p(a, lv->K, s) : launch_gather128(a, lv->K, s);
   else
     rc = lv->tgt_has_grad ? launch_c<true>(a, lv->C, lv->K, s) : launch_c<false>(a, lv->C, lv->K, s);
   if (rc != BANET_OK) return rc;

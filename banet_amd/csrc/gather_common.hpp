@@ -186,9 +186,13 @@ __device__ __noinline__ Q5 border_pixel_q5(int x0, int y0, float w00, float w01,
   return q;
 }
 
+#ifndef BANET_G128P_WAVES
+#define BANET_G128P_WAVES 2   // ba_gather128p_kernel: workgroups per CU (its prefetch registers need 256 VGPRs)
+#endif
 #ifndef BANET_G128_WAVES
 #define BANET_G128_WAVES 3   // ba_gather128_kernel: workgroups per CU (= waves per SIMD) of its launch bounds
 #endif
-int launch_gather128(const GatherArgs& a, int K, hipStream_t s);  // gather128.hip
+int launch_gather128(const GatherArgs& a, int K, hipStream_t s);
+int launch_gather128p(const GatherArgs& a, int K, hipStream_t s);   // gather128p.hip: wave-private LDS patches  // gather128.hip
 
 }  // namespace banet

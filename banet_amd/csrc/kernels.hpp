@@ -13,6 +13,7 @@ inline int npairs(const banet_level_t* lv) { return lv->pairs > 1 ? lv->pairs : 
 struct GatherPlan {
   int G, tiles, tiles_x, tiles_y, groups, pstride;
   int c128;     // 1: ba_gather128_kernel (dynamic tile queue, one partial row per tile)
+  int patch;    // 1: ba_gather128p_kernel (same interface; taps from wave-private LDS patches) for large levels
   int rows;     // partial rows per window written by the gather kernel (tiles or G)
   int frows;    // rows per window handed to ba_reduce2_kernel (after ba_fold_kernel when rows > kFoldRows)
   int nbands;   // tile-queue bands (8 = one per XCD)

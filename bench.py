@@ -172,7 +172,7 @@ def main():
                        "parallelism": "windows sharded, dp%d" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "ba_gather128_kernel<1>",
+                         "kernel": "ba_gather128p_kernel<1> (640x480 and 320x240 levels) + ba_gather128_kernel<1> (coarser levels)",
                          "launches": nlaunch, "avg_launch_us": round(1e3 * kern_ms / max(nlaunch, 1), 2),
                          "algorithmic_bytes_per_launch": round(alg_bytes / max(nlaunch, 1)),
                          "kernel_time_share": round(kern_ms / (1e3 * elapsed), 4),

@@ -465,6 +465,50 @@ def test_random_shape_sweep_assembly_matches_oracle(seed):
     np.testing.assert_array_equal(n(AtA), np.swapaxes(n(AtA), 1, 2))
 
 
+@pytest.mark.parametrize("H,W,K,big,pairs", [(48, 64, 128, False, 1), (40, 56, 16, True, 1), (37, 53, 0, True, 2), (64, 96, 64, False, 3)])
+def test_patch_gather_kernel_matches_oracle(H, W, K, big, pairs):
+    """ba_gather128p_kernel (the default on large levels) forced at oracle-sized inputs: staged step pairs, pairs that
+    fall back to direct loads (large motion), rim pixels, masked pixels, ragged tiles, several target frames."""
+    from banet_amd import dense as bdense, ops
+    B, C = 2, 128
+    scenes = [synth.make_window_scene(H, W, C, K, [1], 300 + b, pairs, rot_mag=0.012 * (6 if big else 1),
+                                      trans_mag=0.05 * (6 if big else 1)) for b in range(B)]
+    intr, levels = odense.batch_window_scene(scenes)
+    lv = levels[0]
+    rng = np.random.RandomState(8)
+    R = np.stack([[synth.rodrigues(rng.uniform(-1, 1, 3) * 0.004) for _ in range(pairs)] for _ in range(B)]).astype(np.float32)
+    T = (np.stack([s["T_gt"] for s in scenes]) * 0.8).reshape(B, pairs, 3, 1).astype(np.float32)
+    Wc = (rng.standard_normal((B, K, 1)) * 0.01).astype(np.float32)
+    mlps = [orc.he_normal_mlp_weights(C, 9)]
+    ba = bdense.DenseBA(t(intr), _torch_levels(levels), mlps, "bundle" if K else "bundle_camera", 1000.0)
+    outs = {}
+    for bits in (512, 64):                                       # patch kernel forced / direct kernel
+        ba.problems[0].c.reserved_ = bits
+        outs[bits] = [n(x) for x in ops.ba_assemble(ba.problems[0], t(R), t(T), t(Wc) if K else None)]
+    ba.problems[0].c.reserved_ = 0
+    for x, y in zip(outs[512], outs[64]):
+        assert relerr(x, y) < 2e-6, relerr(x, y)
+    one = dict(lv)
+    one["tgt"] = lv["tgt"][:, 0]
+    a = odense.level_inputs(intr, one, True, np.float64)
+    R64 = [R[:, i].astype(np.float64) for i in range(pairs)]
+    T64 = [T[:, i].astype(np.float64) for i in range(pairs)]
+    if K:
+        conv2s = [orc.target_map(lv["tgt"][:, i].astype(np.float64)) for i in range(pairs)]
+        dbg = orc.bundle_window_iteration(a["conv1"], conv2s, a["fx"], a["fy"], a["ox"], a["oy"], a["p"], a["D"], a["Bs"],
+                                          R64, T64, Wc.astype(np.float64), mlps[0], 1000.0)[3]
+        assert relerr(outs[512][0], dbg["AtA"]) < 3e-5 and relerr(outs[512][1][..., None], dbg["Atb"]) < 3e-5
+        nv = sum(m.sum(axis=(1, 2)) for m in dbg["mask"])
+        assert np.abs(outs[512][3] - nv).max() <= 1
+        if big:
+            assert (nv < H * W * pairs).all()                     # some pixels really leave the image
+    else:
+        for i in range(pairs):
+            d = orc.bundle_camera_iteration(a["conv1"], orc.target_map(lv["tgt"][:, i].astype(np.float64)), a["fx"], a["fy"],
+                                            a["ox"], a["oy"], a["p"], a["D"], R64[i], T64[i], mlps[0], 1.0)[2]
+            assert relerr(outs[512][0][:, 6 * i:6 * i + 6, 6 * i:6 * i + 6], d["AtA"]) < 3e-5
+
+
 def test_window_multilevel_solve_matches_oracle_and_converges():
     """5-frame window (4 target frames), 3 levels, fp32 oracle from the same start."""
     from banet_amd import dense as bdense
