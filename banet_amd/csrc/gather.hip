@@ -462,6 +462,11 @@ int plan_gather(const banet_level_t* lv, GatherPlan* pl) {
   const int resident = kCUs * (pl->patch ? BANET_G128P_WAVES : pl->c128 ? kC128BlocksPerCU : kGenericBlocksPerCU);
   const int VB = lv->B * npairs(lv);   // virtual windows
   int target = (resident + VB - 1) / VB;
+  // Mid-size levels (a few tiles per wave at most) start all their waves in the same phase: measured, ~1300 waves
+  // finish a tile in 67 us but 2560 need 169 us (160x120 x 8: one tile per wave 21.1 us/window, two per wave on half
+  // the waves 16.7).  Such levels run on at most 320 workgroups (1280 waves).
+  if (pl->c128 && !pl->patch && (long long)pl->tiles * VB < 4LL * kCUs * BANET_G128P_WAVES * kNumWaves)
+    target = min(target, (320 + VB - 1) / VB);
   // quarter-tile work items pay (measured: 40x30 x 8 windows 94 -> 50 us) only while they still leave the chip
   // mostly empty -- at most one item per SIMD; beyond that the redone depth dot / geometry costs more than
   // the shorter step chain saves (80x60 x 8: 101 -> 132 us).  reserved_ bit 4: off (A/B).
