@@ -10,8 +10,11 @@
 //   H_cc += Jc^T M Jc ; Atb_c += Jc^T g   utils.cu:344-380,393-414 restricted to the pose block
 //   record (u = Jc^T M jd, s = jd^T M jd, r = jd^T g) for the depth-basis blocks (syrk.hip)
 //
+// This file: the GENERIC kernel (any C <= 256, K <= 256, sparse points, the reference's precomputed [f|gx|gy]
+// target layout) plus the planning / dispatch of all gather kernels; the C = 128 dense fast paths live in
+// gather128.hip (direct loads) and gather128p.hip (wave-private LDS patches, large levels).
 // Design: NO workgroup barriers and no LDS in the main loop -- every wave is an independent
-// stream, so occupancy (4 waves/SIMD) hides the dependent chain basis-row -> depth -> projection
+// stream, so occupancy (3 waves/SIMD) hides the dependent chain basis-row -> depth -> projection
 // -> texel address -> 13 row loads.  A wave owns 64-pixel batches (8x8 patches):
 //   1. depth: the 64 basis rows are read as coalesced 512-B rows (64 loads in flight), each lane
 //      keeps its partial dot with W, and a 6-level transposing butterfly (one shuffle per value)
