@@ -119,19 +119,19 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
   int* __restrict__ queue = a.queue + vb * 8;
   int band = nb > 1 ? (g & 7) : 0, left = nb;
   auto band_lo = [&](int x) { return (int)(((long long)nitems * x) / nb); };
-  auto pop = [&](int x) {  // wave-uniform
+  auto pop_raw = [&](int x) {  // issues the atomic; the id is read (v_readfirstlane) only when it is needed
     int v = 0;
     if (lane == 0) v = atomicAdd(&queue[x], 1);
-    return rfl(v) + band_lo(x);
+    return v;
   };
-  int t_next = pop(band);
+  int raw_next = pop_raw(band);
 
   while (true) {
-    int wi = t_next;
+    int wi = rfl(raw_next) + band_lo(band);
     while (wi >= band_lo(band + 1)) {  // this band is drained: move on (a drained band stays drained)
       if (--left == 0) return;
       band = band + 1 == nb ? 0 : band + 1;
-      wi = pop(band);
+      wi = rfl(pop_raw(band)) + band_lo(band);
     }
     // Small levels (fewer tiles than resident waves) are latency-bound: there a tile is split into 4
     // work items that each redo the tile's (cheap) depth dot and geometry but gather only their own
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
     const int t = wi >> qshift;
     const int s_lo = qshift ? 4 * (wi & 3) : 0, s_hi = qshift ? s_lo + 4 : 16;
     const bool mine = (lane >> 2) >= s_lo && (lane >> 2) < s_hi;   // lane = pixel: pixels 4 s .. 4 s + 3 belong to step s
-    t_next = pop(band);  // issued now, consumed after this tile: the atomic's latency is hidden
+    raw_next = pop_raw(band);  // issued now, read at the top of the next tile: the atomic's latency is hidden
     int tx = 0, ty = 0;
     if (dense) tile_coords(t, a.tiles_x, a.tiles_y, tx, ty);
     auto point_of = [&](int n, bool& valid) -> int {
