@@ -103,7 +103,7 @@ __device__ void mlp_layer(const float* in, float* out, const float* __restrict__
       const int i0 = sl * chunk, i1 = min(nin, i0 + chunk);
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       const float* wp = Wt + 4 * q;
-#pragma unroll 8
+#pragma unroll 16
       for (int i = i0; i < i1; ++i) {
         const float4 w4 = *reinterpret_cast<const float4*>(wp + (size_t)i * nout);
         const float xv = in[i];
