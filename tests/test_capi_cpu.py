@@ -100,3 +100,26 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "oracle/" not in txt.replace(
                     "oracle/synth.py", ""), f
+
+
+def test_plain_c_program_links_against_the_library(tmp_path):
+    """the drop-in boundary is a C ABI: a C translation unit (no C++, no torch) includes the header, links
+    libbanet_hip.so and calls entry points that need no GPU"""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "t.c"
+    src.write_text('#include <stdio.h>\n#include <string.h>\n#include "banet_hip.h"\n'
+                   'int main(void){ banet_level_t lv; memset(&lv, 0, sizeof lv);\n'
+                   '  if (banet_version() != BANET_VERSION) return 1;\n'
+                   '  if (strcmp(banet_error_string(BANET_OK), "ok")) return 2;\n'
+                   '  if (banet_ba_assemble_f32(&lv, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0) != BANET_ERR_INVALID_ARG) return 3;\n'
+                   '  if (banet_resample_f32(0, 0, 0, 1, 1, 1, 1, 1, BANET_RESAMPLE_CLAMP, 0) != BANET_ERR_INVALID_ARG) return 4;\n'
+                   '  printf("c-abi ok %d\\n", banet_version()); return 0; }\n')
+    libdir = os.path.join(ROOT, "banet_amd", "lib")
+    exe = tmp_path / "t"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-lbanet_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.check_output([str(exe)]).decode()
+    assert out.startswith("c-abi ok 110")
