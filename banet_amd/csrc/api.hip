@@ -28,6 +28,7 @@ struct LevelWs {  // carve of the level workspace
   float* absres;
   float* nvalid;
   LmCtl* ctl;
+  float* bigA;
   size_t total;
 };
 
@@ -46,6 +47,8 @@ static LevelWs carve_level(const banet_level_t* lv, const AsmPlan& pl, void* ws)
   w.absres = reinterpret_cast<float*>(take((size_t)lv->B * lv->C * sizeof(float)));
   w.nvalid = reinterpret_cast<float*>(take((size_t)lv->B * sizeof(float)));
   w.ctl = reinterpret_cast<LmCtl*>(take((size_t)lv->B * sizeof(LmCtl)));
+  const size_t big = solve_big_bytes(lv->B, pl.P, lv->C);
+  w.bigA = big ? reinterpret_cast<float*>(take(big)) : nullptr;
   w.total = off;
   return w;
 }
@@ -74,6 +77,7 @@ static SolveArgs make_solve_args(const banet_level_t* lv, const banet_mlp_t* mlp
   a.ctl = nullptr;
   a.queue = nullptr;
   a.nqueue = 0;
+  a.bigA = nullptr;
   return a;
 }
 
@@ -186,6 +190,7 @@ int banet_lm_level_f32(const banet_level_t* lv, const banet_mlp_t* mlp, float l2
   hipStream_t s = static_cast<hipStream_t>(stream);
   SolveArgs a = make_solve_args(lv, mlp, l2_base, w.AtA, w.Atb, w.absres, w.nvalid, st);
   a.max_iters = max_iters;
+  a.bigA = w.bigA;
   const bool lm = early_termination && lv->variant == BANET_LEGACY_LM;
   if (lm) {
     // device-side loop control: max_iters + 1 evaluation rounds; the last one only runs the

@@ -103,10 +103,12 @@ struct SolveArgs {
   const float* nvalid;
   banet_state_t st;
   LmCtl* ctl;  // nullptr: fixed-count mode (every call performs one update)
+  float* bigA; // workspace for the normal matrix when it does not fit in LDS (solve_big_bytes), else nullptr
   int* queue;  // LM loop: the next gather's tile-queue heads, zeroed by this kernel (saves a memset per iteration)
   int nqueue;  // words per window
 };
 int launch_solve(const SolveArgs& a, hipStream_t s);
+size_t solve_big_bytes(int B, int P, int C);
 void launch_ctl_init(LmCtl* ctl, int32_t* iters, int B, hipStream_t s);
 void launch_zero_iters(int32_t* iters, int B, hipStream_t s);
 

@@ -313,12 +313,18 @@ __host__ __device__ inline int ldlt_ld(int n) {  // row stride: >= round16(n), o
   return ld;
 }
 __host__ __device__ inline int ldlt_ldw(int n) { return ((n + 1 + 3) & ~3) + 4; }   // W^T row stride
+__host__ __device__ inline int solve_scratch_floats(int P) {   // MLP partials (4096) or the LDL^T scratch, whichever is larger
+  const int need = P >= 32 ? kPanel * ldlt_ldw(P) + 288 : 0;
+  return need > 4096 ? ((need + 3) & ~3) : 4096;
+}
+__host__ __device__ inline size_t solve_big_floats(int P) { return (size_t)(P + 4) * ldlt_ld(P); }
 
 __device__ __forceinline__ float rdlane(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 
-__device__ void ldlt_solve_blocked(float* A, int ld, int n, float* x, float* scratch /* >= 16*ldw + 272 floats */) {
+__device__ __attribute__((always_inline)) void ldlt_solve_blocked(float* A, int ld, int n, float* x,
+                                                                  float* scratch /* >= 16*ldw + 272 floats */) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int m = n + 1;                 // rows including the right-hand side
   const int ldw = ldlt_ldw(n);
@@ -536,6 +542,9 @@ __device__ void rodrigues(const float w[3], bool clamp, float Rw[9], float V[9])
   for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.f : 0.f) + a * Kx[i] + bq * K2[i];
 }
 
+// BIG: the normal matrix lives in the caller's workspace instead of LDS (a separate instantiation, so that the
+// common LDS-resident kernel keeps its register allocation)
+template <bool BIG>
 __global__ __launch_bounds__(kSolveThreads) void ba_solve_update_kernel(const SolveArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -543,15 +552,19 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve_update_kernel(const So
   const bool blocked = P >= kGrid;                   // bundle variants: blocked LDL^T, rhs stored as row P
   const int ld = blocked ? ldlt_ld(P) : P + 2;
   const int arows = blocked ? P + 4 : P;
-  float* sA = smem;                 // [arows][ld] augmented
-  float* sX = sA + ((arows * ld + 3) & ~3);  // [P]  (every carve offset a multiple of 4 floats: float4 LDS accesses)
+  // P too large for an LDS-resident matrix (K = 256 windows: P up to 6*7 + 256): the matrix lives in the caller's
+  // workspace (L2-resident, 370 KB per window) and only the vectors / scratch stay in LDS.  Same code, global pointer.
+  constexpr bool big = BIG;
+  float* gA = big ? a.bigA + (size_t)b * solve_big_floats(P) : nullptr;
+  float* sA = smem;                 // [arows][ld] augmented (unused when big)
+  float* sX = sA + (big ? 0 : ((arows * ld + 3) & ~3));  // [P]  (every carve offset a multiple of 4 floats: float4 LDS accesses)
   float* sH0 = sX + ((P + 3) & ~3); // MLP ping
   float* sH1 = sH0 + 4 * C;         // MLP pong
   float* sAvg = sH1 + 4 * C;        // [C]
   float* sRed = sAvg + ((C + 3) & ~3);  // [8]
   float* sScal = sRed + 20;         // pivot reciprocal, -, flags
-  float* sPart = sRed + 24;         // [4096] MLP partial sums / solver scratch
-  int* sPerm = reinterpret_cast<int*>(sPart + 4096);  // [P]
+  float* sPart = sRed + 24;         // [solve_scratch_floats(P)] MLP partial sums / solver scratch
+  int* sPerm = reinterpret_cast<int*>(sPart + solve_scratch_floats(P));  // [P]
 
   LmCtl* ctl = a.ctl ? a.ctl + b : nullptr;
   if (ctl && ctl->active == 0) return;
@@ -615,13 +628,24 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve_update_kernel(const So
   }
   // ---- damping ------------------------------------------------------------------------
   const float* A_g = a.AtA + (size_t)b * P * P;
-  for (int e = tid; e < P * P; e += kSolveThreads) {
-    const int i = e / P, j = e - i * P;
-    float v = A_g[e];
-    if (i == j && !(a.variant == BANET_BUNDLE && i == P - 1)) v = v + (v + 1e-5f) * lam;
-    sA[i * ld + j] = v;
+  if (big) {
+    for (int e = tid; e < P * P; e += kSolveThreads) {
+      const int i = e / P, j = e - i * P;
+      float v = A_g[e];
+      if (i == j && !(a.variant == BANET_BUNDLE && i == P - 1)) v = v + (v + 1e-5f) * lam;
+      gA[i * ld + j] = v;
+    }
+    for (int i = tid; i < P; i += kSolveThreads) gA[P * ld + i] = a.Atb[(size_t)b * P + i];
+    __threadfence_block();
+  } else {
+    for (int e = tid; e < P * P; e += kSolveThreads) {
+      const int i = e / P, j = e - i * P;
+      float v = A_g[e];
+      if (i == j && !(a.variant == BANET_BUNDLE && i == P - 1)) v = v + (v + 1e-5f) * lam;
+      sA[i * ld + j] = v;
+    }
+    for (int i = tid; i < P; i += kSolveThreads) sA[blocked ? P * ld + i : i * ld + P] = a.Atb[(size_t)b * P + i];
   }
-  for (int i = tid; i < P; i += kSolveThreads) sA[blocked ? P * ld + i : i * ld + P] = a.Atb[(size_t)b * P + i];
   __syncthreads();
   STICK(tk2);
   // ---- solve --------------------------------------------------------------------------
@@ -636,8 +660,10 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve_update_kernel(const So
     float* sCol = sPart;                // the MLP scratch is free by now (4096 floats)
     if (P <= kGrid - 1) {               // pose-only variants: pivoted LU as tf.matrix_solve
       lu_solve_regs<1>(sA, ld, P, sX, sPerm, sCol, sCol + 2 * kGrid, reinterpret_cast<int*>(sCol + 3 * kGrid), sScal);
+    } else if constexpr (big) {
+      ldlt_solve_blocked(gA, ld, P, sX, sCol);    // matrix in global memory (workgroup-private, L2)
     } else {
-      ldlt_solve_blocked(sA, ld, P, sX, sCol);
+      ldlt_solve_blocked(smem, ld, P, sX, sCol);  // matrix in LDS
     }
   }
   STICK(tk3);
@@ -708,19 +734,34 @@ __global__ void zero_iters_kernel(int32_t* iters, int B) {
   if (b < B) iters[b] = 0;
 }
 
-size_t solve_lds_bytes(int P, int C) {
+size_t solve_lds_bytes(int P, int C, bool big) {
   const bool blocked = P >= kGrid;
   const int ld = blocked ? ldlt_ld(P) : P + 2, arows = blocked ? P + 4 : P;
-  const size_t fl = (size_t)((arows * ld + 3) & ~3) + ((P + 3) & ~3) + 8 * C + ((C + 3) & ~3) + 24 + 4096 + P + 8;
+  const size_t fl = (size_t)(big ? 0 : ((arows * ld + 3) & ~3)) + ((P + 3) & ~3) + 8 * C + ((C + 3) & ~3) + 24 +
+                    solve_scratch_floats(P) + P + 8;
   return fl * sizeof(float);
 }
 
+// bytes of caller workspace the solve needs for its matrix (0: it fits in LDS)
+size_t solve_big_bytes(int B, int P, int C) {
+  if (solve_lds_bytes(P, C, false) <= 160 * 1024) return 0;
+  return (size_t)B * solve_big_floats(P) * sizeof(float);
+}
+
 int launch_solve(const SolveArgs& a, hipStream_t s) {
-  const size_t lds = solve_lds_bytes(a.P, a.C);
+  const bool need_big = solve_lds_bytes(a.P, a.C, false) > 160 * 1024;
+  if (need_big && a.bigA == nullptr) return BANET_ERR_UNSUPPORTED;   // only banet_lm_level_f32 has a workspace for it
+  const size_t lds = solve_lds_bytes(a.P, a.C, need_big);
   if (lds > 160 * 1024) return BANET_ERR_UNSUPPORTED;
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)ba_solve_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(ba_solve_update_kernel, dim3(a.B), dim3(kSolveThreads), lds, s, a);
+  if (need_big) {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)ba_solve_update_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(ba_solve_update_kernel<true>, dim3(a.B), dim3(kSolveThreads), lds, s, a);
+  } else {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)ba_solve_update_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(ba_solve_update_kernel<false>, dim3(a.B), dim3(kSolveThreads), lds, s, a);
+  }
   return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;
 }
 

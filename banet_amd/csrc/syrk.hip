@@ -25,7 +25,8 @@ struct SyrkArgs {
 };
 
 template <int NB>
-__global__ __launch_bounds__(kBlock, 2) void ba_syrk_kernel(const SyrkArgs a) {
+__global__ __launch_bounds__(kBlock, NB > 8 ? 1 : 2) void ba_syrk_kernel(const SyrkArgs a) {
+  constexpr int PW = NB > 8 ? 2 : 1;    // block-row pairs per wave (NB = 16, K <= 256: rows {w, 15-w} and {w+4, 11-w})
   constexpr int KPAD = NB * 16;
   constexpr int KP = KPAD + 16;         // row stride: bank shift 16 per row -> conflict-free MFMA operand reads
   constexpr int KV = KPAD >= 64 ? KPAD / 64 : 1;
@@ -48,14 +49,13 @@ __global__ __launch_bounds__(kBlock, 2) void ba_syrk_kernel(const SyrkArgs a) {
   for (int i = 0; i < 7; ++i)
 #pragma unroll
     for (int e = 0; e < KV; ++e) hcd[i][e] = 0.f;
-  f32x4 acc[NSLOT];
+  f32x4 acc[PW][NSLOT];
 #pragma unroll
-  for (int q = 0; q < NSLOT; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int p = 0; p < PW; ++p)
+#pragma unroll
+    for (int q = 0; q < NSLOT; ++q) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
   constexpr int npairs = (NB + 1) / 2;
-  const int i1 = w, i2 = NB - 1 - w;
   const bool mf_on = w < npairs && a.pass == 0;
-  const int n1 = NB - i1;
-  const int nslots = (i2 != i1) ? NB + 1 : n1;
 
   float4 pre[QT];
   float4 preu = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -158,14 +158,21 @@ __global__ __launch_bounds__(kBlock, 2) void ba_syrk_kernel(const SyrkArgs a) {
         const int pix = 4 * kk + kq;
         const float* row = sB + pix * KP + col;
         const float sv = sU[pix * kUStrideS + 6];
-        const float a1 = sv * row[16 * i1];
-        const float a2 = sv * row[16 * i2];
 #pragma unroll
-        for (int q = 0; q < NSLOT; ++q) {
-          if (q < nslots) {  // wave-uniform
-            const bool first = q < n1;
-            const float bj = row[16 * (first ? i1 + q : i2 + q - n1)];
-            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(first ? a1 : a2, bj, acc[q], 0, 0, 0);
+        for (int p = 0; p < PW; ++p) {
+          const int i1 = w + 4 * p, i2 = NB - 1 - i1;
+          if (i1 > i2) continue;  // wave-uniform (odd NB / fewer pairs than waves)
+          const int n1 = NB - i1;
+          const int nslots = (i2 != i1) ? NB + 1 : n1;
+          const float a1 = sv * row[16 * i1];
+          const float a2 = sv * row[16 * i2];
+#pragma unroll
+          for (int q = 0; q < NSLOT; ++q) {
+            if (q < nslots) {  // wave-uniform
+              const bool first = q < n1;
+              const float bj = row[16 * (first ? i1 + q : i2 + q - n1)];
+              acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(first ? a1 : a2, bj, acc[p][q], 0, 0, 0);
+            }
           }
         }
       }
@@ -199,16 +206,23 @@ __global__ __launch_bounds__(kBlock, 2) void ba_syrk_kernel(const SyrkArgs a) {
     float* pd = part + (6 * a.pairs + 1) * K;
     const int col = lane & 15, rq = (lane >> 4) * 4;
 #pragma unroll
-    for (int q = 0; q < NSLOT; ++q) {
-      if (q < nslots) {
-        const bool first = q < n1;
-        const int bi = first ? i1 : i2, bj = first ? i1 + q : i2 + q - n1;
+    for (int p = 0; p < PW; ++p) {
+      const int i1 = w + 4 * p, i2 = NB - 1 - i1;
+      if (i1 > i2) continue;
+      const int n1 = NB - i1;
+      const int nslots = (i2 != i1) ? NB + 1 : n1;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int rr = 16 * bi + rq + r, cc = 16 * bj + col;
-          if (rr < K && cc < K && (bj > bi || rr <= cc)) {
-            pd[rr * K + cc] = acc[q][r];
-            pd[cc * K + rr] = acc[q][r];
+      for (int q = 0; q < NSLOT; ++q) {
+        if (q < nslots) {
+          const bool first = q < n1;
+          const int bi = first ? i1 : i2, bj = first ? i1 + q : i2 + q - n1;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int rr = 16 * bi + rq + r, cc = 16 * bj + col;
+            if (rr < K && cc < K && (bj > bi || rr <= cc)) {
+              pd[rr * K + cc] = acc[p][q][r];
+              pd[cc * K + rr] = acc[p][q][r];
+            }
           }
         }
       }
@@ -698,6 +712,7 @@ static int nb_for_k(int K) {
   if (K <= 32) return 2;
   if (K <= 64) return 4;
   if (K <= 128) return 8;
+  if (K <= 256) return 16;
   return -1;
 }
 
@@ -715,7 +730,7 @@ int plan_syrk(int B, int N, int K, int pairs, int dbg, SyrkPlan* pl) {
   // K = 64 / 128: barrier-free kernels, one wave per SIMD, 256 workgroups in all: 2 = ba_syrk_bf16x6_kernel
   // (default), 1 = ba_syrk_direct_kernel (fp32 MFMA; reserved_ bit 8, A/B only)
   pl->direct = ((K == 64 || K == 128) && pairs <= 4) ? ((dbg & 256) ? 1 : 2) : 0;
-  int target = ((pl->direct ? 256 : 512) + B - 1) / B;   // LDS kernel: 2 resident workgroups per CU
+  int target = (((pl->direct || pl->nb > 8) ? 256 : 512) + B - 1) / B;   // LDS kernel: 2 resident workgroups per CU (1 at K > 128)
   int G = pl->direct ? (N + 4 * 4 * 16 - 1) / (4 * 4 * 16) : pl->tiles / 4;   // direct: >= 16 quads per wave
   if (G > target) G = target;
   if (G < 1) G = 1;
@@ -783,6 +798,7 @@ int launch_syrk(const float* basis, const float* rec, int B, int N, int K, int p
       case 2: launch_syrk_nb<2>(a, B, s); break;
       case 4: launch_syrk_nb<4>(a, B, s); break;
       case 8: launch_syrk_nb<8>(a, B, s); break;
+      case 16: launch_syrk_nb<16>(a, B, s); break;
       default: return BANET_ERR_UNSUPPORTED;
     }
   }

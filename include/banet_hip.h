@@ -88,7 +88,10 @@ typedef struct banet_level {
   int32_t B;            /* windows                                                        */
   int32_t N;            /* points per window                                              */
   int32_t C;            /* feature channels (C <= 256)                                    */
-  int32_t K;            /* depth-basis coefficients; 0 for the pose-only variants; <= 128 */
+  int32_t K;            /* depth-basis coefficients; 0 for the pose-only variants; <= 256
+                           (P = 6 pairs + K > ~190: the solve keeps its matrix in the workspace
+                           of banet_lm_level_f32; banet_ba_solve_update_f32 alone then returns
+                           BANET_ERR_UNSUPPORTED)                                          */
   int32_t H, W;         /* target map height / width at this level                        */
   int32_t variant;      /* BANET_LEGACY_LM ... BANET_BUNDLE                               */
   int32_t dense;        /* 1: the N = H*W points are this level's own pixel grid          */

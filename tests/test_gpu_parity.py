@@ -509,6 +509,42 @@ def test_patch_gather_kernel_matches_oracle(H, W, K, big, pairs):
             assert relerr(outs[512][0][:, 6 * i:6 * i + 6, 6 * i:6 * i + 6], d["AtA"]) < 3e-5
 
 
+@pytest.mark.parametrize("C,K,pairs", [(128, 256, 7), (12, 200, 2), (128, 256, 1)])
+def test_large_basis_windows_match_oracle(C, K, pairs):
+    """BASELINE configs[4] class: K = 256 coefficients, up to 8 frames (P = 6*7 + 256 = 298).  The LDS-tiled SYRK runs
+    with 16 block rows, the solve keeps its matrix in the caller's workspace (it does not fit in LDS)."""
+    from banet_amd import dense as bdense, ops
+    B, H, W = 2, 32, 40
+    scenes = _window_scenes(B, H, W, C, K, [1], 55, pairs)
+    intr, levels = odense.batch_window_scene(scenes)
+    lv = levels[0]
+    mlps = [orc.he_normal_mlp_weights(C, 9)]
+    T0 = (np.stack([s["T_gt"] for s in scenes]) * 0.8).reshape(B, pairs, 3, 1).astype(np.float32)
+    ba = bdense.DenseBA(t(intr), _torch_levels(levels), mlps, "bundle", 1000.0)
+    assert ba.problems[0].P == 6 * pairs + K
+    R = np.tile(np.eye(3, dtype=np.float32)[None, None], (B, pairs, 1, 1))
+    Wc = np.zeros((B, K, 1), np.float32)
+    AtA, Atb, absres, nvalid = ops.ba_assemble(ba.problems[0], t(R), t(T0), t(Wc))
+    one = dict(lv)
+    one["tgt"] = lv["tgt"][:, 0]
+    a = odense.level_inputs(intr, one, True, np.float64)
+    conv2s = [orc.target_map(lv["tgt"][:, i].astype(np.float64)) for i in range(pairs)]
+    Rn, Tn, Wn, dbg = orc.bundle_window_iteration(a["conv1"], conv2s, a["fx"], a["fy"], a["ox"], a["oy"], a["p"], a["D"], a["Bs"],
+                                                  [R[:, i].astype(np.float64) for i in range(pairs)],
+                                                  [T0[:, i].astype(np.float64) for i in range(pairs)], Wc.astype(np.float64),
+                                                  mlps[0], 1000.0)
+    assert relerr(n(AtA), dbg["AtA"]) < 3e-5 and relerr(n(Atb)[..., None], dbg["Atb"]) < 3e-5
+    np.testing.assert_array_equal(n(AtA), np.swapaxes(n(AtA), 1, 2))
+    st, counts = ba.solve([1], ba.new_state(T=t(T0.reshape(B * pairs, 3, 1))))       # one full LM iteration through banet_lm_level_f32
+    sol = dbg["solution"][:, :, 0]
+    assert int(counts[0][0]) == 1
+    assert relerr(n(st.delta)[:, :6 * pairs], sol[:, :6 * pairs]) < 1e-4, relerr(n(st.delta)[:, :6 * pairs], sol[:, :6 * pairs])
+    assert relerr(n(st.delta)[:, 6 * pairs:], sol[:, 6 * pairs:]) < 1e-4, relerr(n(st.delta)[:, 6 * pairs:], sol[:, 6 * pairs:])
+    Rg = n(st.R).reshape(B, pairs, 3, 3)
+    Tg = n(st.T).reshape(B, pairs, 3, 1)
+    assert relerr(Rg, np.stack(Rn, 1)) < 1e-5 and relerr(Tg, np.stack(Tn, 1)) < 1e-4 and relerr(n(st.Wc), Wn) < 1e-4
+
+
 def test_window_multilevel_solve_matches_oracle_and_converges():
     """5-frame window (4 target frames), 3 levels, fp32 oracle from the same start."""
     from banet_amd import dense as bdense
