@@ -76,7 +76,9 @@ def test_argument_validation_without_gpu(capi):
     nb = L.banet_lm_level_workspace_bytes(ctypes.byref(lv))
     assert nb > 0 and nb % 256 == 0
     assert L.banet_ba_assemble_workspace_bytes(ctypes.byref(lv)) <= nb
-    lv.K = 129                                                                           # beyond the compiled set
+    lv.K = 200                                                                           # large bases: the solve's matrix moves
+    assert L.banet_lm_level_workspace_bytes(ctypes.byref(lv)) > nb                        # into the workspace
+    lv.K = 257                                                                           # beyond the compiled set
     assert L.banet_lm_level_workspace_bytes(ctypes.byref(lv)) == 0
     lv.K = 32
     assert L.banet_ba_assemble_f32(ctypes.byref(lv), None, None, None, None, None, None, None, None, 0, None) == -1
