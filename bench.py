@@ -72,6 +72,10 @@ def main():
     ap.add_argument("--windows", type=int, default=None, help="windows per GPU (default: 8 for cfg-2, 32 for cfg-3)")
     ap.add_argument("--frames", type=int, default=2, help="frames per window: 2 = cfg-2 (the default, BASELINE's metric "
                     "workload); 5 = cfg-3/4, the 5-frame sliding window (key frame + 4 target frames, SURVEY 8(d))")
+    ap.add_argument("--height", type=int, default=H)
+    ap.add_argument("--width", type=int, default=W)
+    ap.add_argument("--basis", type=int, default=K, help="depth-basis coefficients K")
+    ap.add_argument("--iters", type=int, default=ITERS[0], help="LM iterations per level")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -92,18 +96,21 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL over xGMI
 
     pairs = args.frames - 1
-    assert 1 <= pairs <= 4, "--frames 2..5"
+    assert 1 <= pairs <= 7, "--frames 2..8"
+    Hh, Ww, Kk = args.height, args.width, args.basis
+    iters = [args.iters] * len(SCALES)
+    default_shape = (Hh, Ww, Kk, args.iters) == (H, W, K, ITERS[0])
     B = args.windows if args.windows is not None else (WINDOWS_PER_GPU if pairs == 1 else 32)
     total_windows = B * world
     torch.manual_seed(1234 + rank)
-    intr, levels, gt = bsynth.make_dense_windows(B, H, W, C, K, SCALES, 1234 + 2 + rank, dev, trans_mag=0.06, pairs=pairs)
+    intr, levels, gt = bsynth.make_dense_windows(B, Hh, Ww, C, Kk, SCALES, 1234 + 2 + rank, dev, trans_mag=0.06, pairs=pairs)
     mlps = [he_normal_lambda_weights(C, 100 + i) for i in range(len(SCALES))]
     ba = bdense.DenseBA(intr, levels, mlps, "bundle", 1000.0)
     T0 = (gt["T"] * 0.7).reshape(B * pairs, 3, 1).to(dev)   # translation prior: depth is unobservable from T = 0
 
     def step():
         st = ba.new_state(T=T0)
-        st, counts = ba.solve(ITERS, st)
+        st, counts = ba.solve(iters, st)
         rec = parallel.pack_results(st.R, st.T, st.Wc, counts)
         return parallel.gather_results(rec, total_windows), st
 
@@ -116,7 +123,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    launches = 2 * args.steps * sum(ITERS) + 8
+    launches = 2 * args.steps * sum(iters) + 8
     ops.profile_begin(launches)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -131,7 +138,7 @@ def main():
     assert torch.isfinite(full).all(), "solve produced non-finite results"
 
     if rank == 0:
-        iters_per_step = sum(ITERS)
+        iters_per_step = sum(iters)
         value = total_windows * iters_per_step * args.steps / elapsed
         # roofline of the dominant kernel (ba_gather128_kernel): algorithmic bytes of the pass it streams
         # / its measured time, summed over every launch of the timed region (all levels)
@@ -151,24 +158,25 @@ def main():
         achieved = alg_bytes / max(kern_ms, 1e-9) / 1e6            # GB/s
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc) and pairs == 1:   # the PMC pass was taken on cfg-2
+        if os.path.exists(pmc) and pairs == 1 and default_shape:   # the PMC pass was taken on cfg-2
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
-            "metric": "LM iterations/sec (%d-frame 640x480 5-level dense BA, 128-coeff depth basis)" % args.frames,
+            "metric": "LM iterations/sec (%d-frame %dx%d 5-level dense BA, %d-coeff depth basis)" % (args.frames, Ww, Hh, Kk),
             "value": round(value, 2), "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "ms_per_solve": round(1e3 * elapsed / args.steps / B, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("cfg-2: 2-frame 640x480 5-level pyramid, C=128, K=128 basis, 10 LM iters/level, "
                                     "batch %d windows per GPU, BundleIteration (bundlenet.py:193-278), dense points" % B)
-                       if pairs == 1 else
-                       ("cfg-3: %d-frame sliding window (key frame + %d target frames sharing depth/basis, P = %d), "
-                        "640x480 5-level pyramid, C=128, K=128, 10 LM iters/level, batch %d windows per GPU, dense points"
-                        % (args.frames, pairs, 6 * pairs + K, B)),
-                       "windows_total": total_windows, "iters_per_level": ITERS, "scales": SCALES,
+                       if pairs == 1 and default_shape else
+                       ("%s: %d-frame window (key frame + %d target frames sharing depth/basis, P = %d), "
+                        "%dx%d 5-level pyramid, C=128, K=%d, %d LM iters/level, batch %d windows per GPU, dense points"
+                        % ("cfg-3" if default_shape else "custom", args.frames, pairs, 6 * pairs + Kk, Ww, Hh, Kk, args.iters, B)),
+                       "windows_total": total_windows, "iters_per_level": iters, "scales": SCALES,
+                       "shape": {"H": Hh, "W": Ww, "C": C, "K": Kk, "frames": args.frames},
                        "parallelism": "windows sharded, dp%d" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -181,7 +189,7 @@ def main():
                          "pipeline_GBps": round(alg_bytes / max(kern_ms + syrk_ms, 1e-9) / 1e6, 1),
                          "per_level": per_level},
         }
-        if world == 1 and not args.no_cpu_baseline and pairs == 1:
+        if world == 1 and not args.no_cpu_baseline and pairs == 1 and default_shape:
             out["cpu_baseline"] = cpu_baseline(intr, levels, gt, mlps)
         print(json.dumps(out), flush=True)
     if world > 1:
