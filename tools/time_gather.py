@@ -16,6 +16,7 @@ dev = torch.device("cuda:0")
 intr, levels, gt = bsynth.make_dense_windows(B, H, W, C, K, [1], 5, dev, trans_mag=0.06)
 ba = bdense.DenseBA(intr, levels, [he_normal_lambda_weights(C, 1)], "bundle" if K else "bundle_camera", 1000.0)
 p = ba.problems[0]
+p.c.reserved_ = 64   # the instrumented kernel is the direct ba_gather128_kernel (large levels default to the patch kernel)
 L = capi.lib()
 R = torch.eye(3, device=dev).repeat(B, 1, 1)
 T = (gt["T"] * 0.7).reshape(B, 3, 1).to(dev)

@@ -11,6 +11,7 @@ dev = torch.device("cuda:0")
 intr, levels, gt = bsynth.make_dense_windows(B, H, W, C, K, [1], 5, dev, trans_mag=0.06)
 ba = bdense.DenseBA(intr, levels, [he_normal_lambda_weights(C, 1)], "bundle", 1000.0)
 p = ba.problems[0]
+p.c.reserved_ = 256   # the instrumented kernel is the fp32-MFMA ba_syrk_direct_kernel (the default is the bf16x6 kernel)
 L = capi.lib()
 R = torch.eye(3, device=dev).repeat(B, 1, 1)
 T = (gt["T"] * 0.7).reshape(B, 3, 1).to(dev)
