@@ -210,7 +210,7 @@ int banet_lm_level_f32(const banet_level_t* lv, const banet_mlp_t* mlp, float l2
     // the tile queue is reset once here; afterwards every solve kernel leaves it zeroed for the next gather
     a.queue = assemble_queue(pl, w.partials);
     a.nqueue = 8 * npairs(lv);
-    if (a.queue) (void)hipMemsetAsync(a.queue, 0, (size_t)lv->B * a.nqueue * sizeof(int), s);
+    if (a.queue) launch_zero_iters(a.queue, lv->B * a.nqueue, s);   // a kernel, not hipMemsetAsync: see prepare_gather
     for (int it = 0; it < max_iters; ++it) {
       rc = launch_assemble(lv, pl, st->R, st->T, st->Wc, nullptr, 0, w.partials, w.AtA, w.Atb, w.absres, w.nvalid, s,
                            a.queue == nullptr);

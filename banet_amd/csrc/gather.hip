@@ -519,7 +519,9 @@ __global__ __launch_bounds__(256) void ba_fold_kernel(const float* __restrict__ 
 }
 
 void prepare_gather(const banet_level_t* lv, const GatherPlan& pl, float* partials, hipStream_t s) {
-  if (pl.c128) (void)hipMemsetAsync(reinterpret_cast<char*>(partials) + pl.off_queue, 0, (size_t)lv->B * npairs(lv) * 8 * sizeof(int), s);
+  // zeroed by a kernel, not hipMemsetAsync: a captured HIP graph holding the memset node faulted on its second replay
+  // (ROCm 7.2; tests/test_gpu_parity.py::test_solve_is_hip_graph_capturable)
+  if (pl.c128) launch_zero_iters(reinterpret_cast<int32_t*>(reinterpret_cast<char*>(partials) + pl.off_queue), lv->B * npairs(lv) * 8, s);
 }
 
 const float* finish_gather(const banet_level_t* lv, const GatherPlan& pl, const int32_t* active, int active_stride,

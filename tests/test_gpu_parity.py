@@ -814,3 +814,37 @@ def test_training_graph_matches_fused_forward_and_finite_difference_gradients():
         fd = (oracle_loss({k: c[k].astype(np.float64) + eps * v}) - oracle_loss({k: c[k].astype(np.float64) - eps * v})) / (2 * eps)
         ad = float((grads[k] * v).sum())
         assert abs(ad - fd) <= 3e-2 * max(abs(fd), abs(ad)) + 1e-6, (k, ad, fd)
+
+
+def test_solve_is_hip_graph_capturable():
+    """The data path makes no allocation / synchronisation / host round trip: a whole multi-level solve (gather, fold,
+    SYRK, reduce, solve kernels and the one queue memset per level) can be captured into a HIP graph and replayed."""
+    from banet_amd import dense as bdense
+    B, H, W, C, K = 2, 48, 64, 128, 64
+    scenes = _scenes(B, H, W, C, K, [2, 1], 71)
+    intr, levels = odense.batch_scene(scenes)
+    mlps = [orc.he_normal_mlp_weights(C, 5 + i) for i in range(2)]
+    T0 = t(np.stack([np.asarray(s["T_gt"]) * 0.7 for s in scenes]).reshape(B, 3, 1))
+    ba = bdense.DenseBA(t(intr), _torch_levels(levels), mlps, "bundle", 1000.0)
+    st_e, _ = ba.solve([3, 2], ba.new_state(T=T0))                       # eager reference (also warms up the kernels)
+    want = [n(st_e.R).copy(), n(st_e.T).copy(), n(st_e.Wc).copy()]
+    st = ba.new_state(T=T0)
+    R0, Tc0, W0 = st.R.clone(), st.T.clone(), st.Wc.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for prob, mlp, its in zip(ba.problems, ba.mlps, [3, 2]):         # warm-up on the capture stream
+            from banet_amd import ops
+            ops.lm_level(prob, mlp, ba.l2_base, its, False, st, ws=ba.ws)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    st.R.copy_(R0); st.T.copy_(Tc0); st.Wc.copy_(W0)
+    with torch.cuda.graph(graph):
+        for prob, mlp, its in zip(ba.problems, ba.mlps, [3, 2]):
+            ops.lm_level(prob, mlp, ba.l2_base, its, False, st, ws=ba.ws)
+    for _ in range(2):                                                    # replay twice from the same start
+        st.R.copy_(R0); st.T.copy_(Tc0); st.Wc.copy_(W0)
+        graph.replay()
+        torch.cuda.synchronize()
+        for got, w_ in zip((st.R, st.T, st.Wc), want):
+            np.testing.assert_array_equal(n(got), w_)                     # bit-identical to the eager run
