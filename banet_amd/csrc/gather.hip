@@ -474,7 +474,8 @@ int plan_gather(const banet_level_t* lv, GatherPlan* pl) {
   // mostly empty -- at most one item per SIMD; beyond that the redone depth dot / geometry costs more than
   // the shorter step chain saves (80x60 x 8: 101 -> 132 us).  reserved_ bit 4: off (A/B).
   pl->qshift = (pl->c128 && !pl->patch && pl->tiles <= 32 && (long long)pl->tiles * VB * 4 <= (long long)kCUs * 4 &&
-                !(lv->reserved_ & 16)) ? 2 : 0;   // (80x60 x 2 windows, also 640 items, LOSES 82 vs 51 us: coarsest levels only)
+                !(lv->reserved_ & 16)) ? 2 : 0;
+  if (pl->c128 && !pl->patch && (lv->reserved_ & 1024)) pl->qshift = 2;   // bit 10: force quarter tiles (A/B)   // (80x60 x 2 windows, also 640 items, LOSES 82 vs 51 us: coarsest levels only)
   int G = pl->c128 ? ((pl->tiles << pl->qshift) + 3) / 4 : pl->groups;
   if (G > target) {
     G = target >= 8 ? (target & ~7) : target;   // several work items per wave: one resident round, no more
