@@ -49,3 +49,12 @@ for bits, name in cfgs:
     ker = {k: round(min(r[1][k] for r in res[bits]), 1) for k in res[bits][0][1]}
     print("%dx%d K=%d B=%d %-6s %8.1f us/launch  %7.1f us/window  %7.1f GB/s   kernels (best of %d): %s" % (
         W, H, K, B, name, ms * 1e3, ms * 1e3 / B, byts / ms / 1e6, ROUNDS, ker))
+ref = None
+for bits, name in cfgs:      # the variants must agree to rounding
+    p.c.reserved_ = bits
+    out = [t.clone() for t in ops.ba_assemble(p, R, T, Wc if K else None)]
+    torch.cuda.synchronize()
+    if ref is None:
+        ref = out
+    else:
+        print("  %-28s max rel diff vs first: %s" % (name, ["%.1e" % float((a - b).abs().max() / b.abs().max()) for a, b in zip(out, ref)]))
