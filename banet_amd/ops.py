@@ -3,6 +3,7 @@
 thin call into libbanet_hip.so through its C ABI.  GPU only -- no CPU / eager fallback.
 """
 import ctypes
+from typing import Tuple
 
 import torch
 
@@ -78,6 +79,43 @@ def equation_construction(jacobian, gradient, difference, symmetric_grad=False):
     (g0 + g0^T)/2 instead -- the exact gradient for any g0, identical to the reference's whenever the
     reference's is exact."""
     return _EquationConstruction.apply(jacobian, gradient, difference, symmetric_grad)
+
+
+# torch.ops.banet.equation_construction / equation_construction_grad: the same two kernels registered with the
+# dispatcher (the counterpart of REGISTER_OP + @ops.RegisterGradient, utils.cu:150-171,420-428 and
+# bundlenet.py:79-82).  Device type "cuda" only (= HIP here): a CPU tensor raises NotImplementedError.
+@torch.library.custom_op("banet::equation_construction", mutates_args=(), device_types="cuda")
+def _eq_op(jacobian: torch.Tensor, gradient: torch.Tensor, difference: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    return equation_construction_forward(jacobian, gradient, difference)
+
+
+@_eq_op.register_fake
+def _eq_op_fake(jacobian, gradient, difference):
+    B, _, _, P = jacobian.shape
+    return jacobian.new_empty((B, P, P)), jacobian.new_empty((B, P, 1))
+
+
+@torch.library.custom_op("banet::equation_construction_grad", mutates_args=(), device_types="cuda")
+def _eq_grad_op(jacobian: torch.Tensor, gradient: torch.Tensor, difference: torch.Tensor, left_grad: torch.Tensor,
+                right_grad: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    return equation_construction_grad(jacobian, gradient, difference, left_grad, right_grad)
+
+
+@_eq_grad_op.register_fake
+def _eq_grad_op_fake(jacobian, gradient, difference, left_grad, right_grad):
+    return torch.empty_like(jacobian), torch.empty_like(gradient), torch.empty_like(difference)
+
+
+def _eq_op_setup(ctx, inputs, output):
+    ctx.save_for_backward(*inputs)
+
+
+def _eq_op_backward(ctx, left_grad, right_grad):
+    J, G, d = ctx.saved_tensors
+    return torch.ops.banet.equation_construction_grad(J, G, d, left_grad.contiguous(), right_grad.contiguous())
+
+
+_eq_op.register_autograd(_eq_op_backward, setup_context=_eq_op_setup)
 
 
 # --------------------------------------------------------------------------------------

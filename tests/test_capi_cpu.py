@@ -95,6 +95,19 @@ def test_gpu_only_no_fallback(capi):
         ops.equation_construction(J, G, d)
 
 
+def test_dispatcher_registration_is_hip_only():
+    """torch.ops.banet.equation_construction[_grad] exist, infer shapes on meta tensors, and have no CPU kernel"""
+    import torch
+    from banet_amd import ops  # noqa: F401  (registers the ops)
+    J, G, d = (torch.zeros(s, device="meta") for s in ((2, 8, 2, 38), (2, 8, 4, 2), (2, 8, 4, 1)))
+    AtA, Atb = torch.ops.banet.equation_construction(J, G, d)
+    assert tuple(AtA.shape) == (2, 38, 38) and tuple(Atb.shape) == (2, 38, 1)
+    gJ, gG, gd = torch.ops.banet.equation_construction_grad(J, G, d, AtA, Atb)
+    assert gJ.shape == J.shape and gG.shape == G.shape and gd.shape == d.shape
+    with pytest.raises(NotImplementedError):
+        torch.ops.banet.equation_construction(torch.zeros(1, 8, 2, 6), torch.zeros(1, 8, 4, 2), torch.zeros(1, 8, 4, 1))
+
+
 def test_product_never_imports_the_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "banet_amd")):
         for f in files:

@@ -105,6 +105,12 @@ def test_equation_construction_grad_matches_oracle(B, N, C, P):
     AtA, Atb = ops.equation_construction(Jt, Gt, dt_)
     ((AtA * t(g0)).sum() + (Atb * t(g1)).sum()).backward()
     assert relerr(n(Jt.grad), rJ) < 3e-5 and relerr(n(Gt.grad), rG) < 3e-5 and relerr(n(dt_.grad), rd) < 3e-5
+    # and the dispatcher registration (torch.ops.banet.*): same kernels, same autograd pairing
+    J2, G2, d2 = t(J).requires_grad_(), t(G).requires_grad_(), t(d).requires_grad_()
+    AtA2, Atb2 = torch.ops.banet.equation_construction(J2, G2, d2)
+    assert torch.equal(AtA2, AtA) and torch.equal(Atb2, Atb)
+    ((AtA2 * t(g0)).sum() + (Atb2 * t(g1)).sum()).backward()
+    assert torch.equal(J2.grad, Jt.grad) and torch.equal(G2.grad, Gt.grad) and torch.equal(d2.grad, dt_.grad)
 
 
 # ======================================================================================
