@@ -497,6 +497,10 @@ __global__ __launch_bounds__(kBlock, 1) void ba_syrk_bf16x6_kernel(const SyrkArg
       for (int j = 0; j < NU; ++j) pu[i][j] = rec_b[p * 8 + uoff[j]];
     }
   };
+#ifdef BANET_TIMING
+  unsigned long long tm0, tr0;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm0), "=s"(tr0)::"memory");
+#endif
   issue(s0);
   for (int st = s0; st < s1; ++st) {
     // ---- H_cd / Atb_d: fp32 MFMAs on the raw values, pixel 8 kq + i as the k index of sub-step i
@@ -562,6 +566,10 @@ __global__ __launch_bounds__(kBlock, 1) void ba_syrk_bf16x6_kernel(const SyrkArg
       }
     __builtin_amdgcn_sched_barrier(0);
   }
+#ifdef BANET_TIMING
+  unsigned long long tm1, tr1;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm1), "=s"(tr1)::"memory");
+#endif
 
   // ---- epilogue (as ba_syrk_direct_kernel) ------------------------------------------------------
   for (int ww = 0; ww < kNumWaves; ++ww) {
@@ -602,6 +610,15 @@ __global__ __launch_bounds__(kBlock, 1) void ba_syrk_bf16x6_kernel(const SyrkArg
       part[6 * PAIRS * K + 64 * (bj >> 2) + 4 * m + (bj & 3)] = v;
     }
   }
+#ifdef BANET_TIMING
+  __syncthreads();
+  if (tid == 0) {   // development aid (tools/time_syrk.py): overwrites 3 words of the partial
+    part[0] = (float)(tm1 - tm0);
+    part[1] = (float)(tr1 - tr0);
+    part[2] = (float)(s1 - s0);
+  }
+  return;
+#endif
   float* pd = part + (6 * PAIRS + 1) * K;
   {
     int idx = 0;

@@ -11,7 +11,8 @@ dev = torch.device("cuda:0")
 intr, levels, gt = bsynth.make_dense_windows(B, H, W, C, K, [1], 5, dev, trans_mag=0.06)
 ba = bdense.DenseBA(intr, levels, [he_normal_lambda_weights(C, 1)], "bundle", 1000.0)
 p = ba.problems[0]
-p.c.reserved_ = 256   # the instrumented kernel is the fp32-MFMA ba_syrk_direct_kernel (the default is the bf16x6 kernel)
+BF = os.environ.get("PBF", "1") == "1"   # 1: the default bf16x6 kernel, 0: the fp32-MFMA ba_syrk_direct_kernel
+p.c.reserved_ = 0 if BF else 256
 L = capi.lib()
 R = torch.eye(3, device=dev).repeat(B, 1, 1)
 T = (gt["T"] * 0.7).reshape(B, 3, 1).to(dev)
@@ -33,12 +34,13 @@ flat = ws.view(torch.float32)
 off = int(os.environ.get("POFF", "-1"))
 import numpy as np
 arr = flat.cpu().numpy()
-nq = (H * W // 4) // (Gs * 4)
+nq = (H * W // (32 if BF else 4)) // (Gs * 4)
 cand = np.where((arr[2:] >= nq - 1) & (arr[2:] <= nq + 1))[0]
 cand = [c for c in cand if arr[c] > 1e4 and arr[c + 1] > 1e2 and (c + pstride + 2 >= len(arr) or abs(arr[c + pstride + 2] - nq) <= 1)]
 base = cand[0]
 rows = np.stack([arr[base + i * pstride: base + i * pstride + 3] for i in range(B * Gs)])
 cyc, rt, q = rows[:, 0], rows[:, 1], rows[:, 2]
-print("workgroups %d  quads/wave %.0f  loop cycles %.0f (%.0f per quad; 44 MFMA x 32 = 1408 -> %.0f%% MFMA busy)" % (
-    len(rows), q.mean(), cyc.mean(), (cyc / q).mean(), 100 * 1408 / (cyc / q).mean()))
+mf = 216 * 16 + 64 * 32 if BF else 1408   # MFMA pipe cycles per unit (bf16x6: a 32-pixel step; fp32: a 4-pixel quad)
+print("workgroups %d  units/wave %.0f  loop cycles %.0f (%.0f per unit; MFMA pipe %d cycles -> %.0f%% busy)" % (
+    len(rows), q.mean(), cyc.mean(), (cyc / q).mean(), mf, 100 * mf / (cyc / q).mean()))
 print("loop wall time %.1f us  -> shader clock %.2f GHz" % (rt.mean() / 100.0, cyc.mean() / (rt.mean() * 10.0) ))
