@@ -464,7 +464,8 @@ int plan_gather(const banet_level_t* lv, GatherPlan* pl) {
                 (lv->reserved_ & 512))) ? 1 : 0;   // bit 9: force it at any size (parity tests)
   const int resident = kCUs * (pl->patch ? BANET_G128P_WAVES : pl->c128 ? kC128BlocksPerCU : kGenericBlocksPerCU);
   const int VB = lv->B * npairs(lv);   // virtual windows
-  int target = (resident + VB - 1) / VB;
+  const int gy = pl->patch ? lv->B : VB;   // the patch kernel loops over a window's target frames inside a tile: grid.y = windows
+  int target = (resident + gy - 1) / gy;
   // Mid-size levels (a few tiles per wave at most) start all their waves in the same phase: measured, ~1300 waves
   // finish a tile in 67 us but 2560 need 169 us (160x120 x 8: one tile per wave 21.1 us/window, two per wave on half
   // the waves 16.7).  Such levels run on at most 320 workgroups (1280 waves).

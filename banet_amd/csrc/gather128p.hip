@@ -84,22 +84,19 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
   __shared__ __attribute__((aligned(16))) float sPatch[kNumWaves][kPatchTexels * 64];   // one channel half of a step pair's box
   __shared__ int sGrp[kNumWaves][8][4];                                                  // per step pair: base offset, pw, staged
   const banet_level_t& lv = a.lv;
-  const int vb = blockIdx.y, g = blockIdx.x;   // vb = (window, pair): a multi-frame window is `pairs` virtual windows
-  const int b = vb / a.pairs;                  // that share the key frame's source map, depth, basis and Wc
+  const int b = blockIdx.y, g = blockIdx.x;    // a workgroup serves one window; a multi-frame window's target frames
+                                               // ("pairs") are looped over INSIDE a tile: the depth D0 + b.W is computed once
   if (a.active != nullptr && a.active[(size_t)b * a.active_stride] == 0) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = wave_id();
   const int N = lv.N, K = lv.K, H = lv.H, W = lv.W;
   constexpr int C = kC128p;
   const bool dense = lv.dense != 0;
-  const float* __restrict__ tgt_b = lv.tgt + (size_t)vb * H * W * C;
   const float* __restrict__ src_b = lv.src + (size_t)b * N * C;
   const float* __restrict__ dep_b = lv.depth + (size_t)b * N;
   const float* __restrict__ bas_b = KV4 ? lv.basis + (size_t)b * N * K : nullptr;
-  float* __restrict__ rec_b = KV4 ? a.rec + (size_t)vb * N * 8 : nullptr;
   const int qshift = a.qshift;                       // 2: a work item is one quarter (16 pixels, 4 steps) of a tile
   const int nitems = a.tiles << qshift;
-  float* __restrict__ part_b = a.partials + (size_t)vb * nitems * (kGHdr + C);
   const int grp = lane >> 4, sub = lane & 15;
   const int half = lane >> 5, li = lane & 31;
 
@@ -116,7 +113,7 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
 
   // ---- tile queue: band x = tiles [tiles x / nb, tiles (x+1) / nb); home band = this workgroup's XCD
   const int nb = a.nbands;
-  int* __restrict__ queue = a.queue + vb * 8;
+  int* __restrict__ queue = a.queue + b * 8;
   int band = nb > 1 ? (g & 7) : 0, left = nb;
   auto band_lo = [&](int x) { return (int)(((long long)nitems * x) / nb); };
   auto pop_raw = [&](int x) {  // issues the atomic; the id is read (v_readfirstlane) only when it is needed
@@ -156,10 +153,6 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
     };
     bool valid;
     const int pt = point_of(lane, valid);
-    float absd8[8];   // |d| of channels {4 sub + e, 64 + 4 sub + e} over this lane group's pixels
-#pragma unroll
-    for (int i = 0; i < 8; ++i) absd8[i] = 0.f;
-    float absd2[1][2] = {{0.f, 0.f}};  // rim pixels (generic routine: channels 2 lane, 2 lane + 1)
 
     // ---- 1. depth: D_j = D0_j + b_j . W.  A half wave reads one basis row per instruction
     // (16 B per lane); 32 row pairs go through a 5-level transposing butterfly inside each half,
@@ -188,6 +181,17 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
       for (int i = 0; i < 32; ++i) carry_push_p<5, 16>(pend, part[i], i);
       D += pend[5];
     }
+
+#pragma unroll 1
+    for (int pr = 0; pr < a.pairs; ++pr) {   // target frames of the window: same pixels, depth and source features
+    const int vb = b * a.pairs + pr;
+    const float* __restrict__ tgt_b = lv.tgt + (size_t)vb * H * W * C;
+    float* __restrict__ rec_b = KV4 ? a.rec + (size_t)vb * N * 8 : nullptr;
+    float* __restrict__ part_b = a.partials + (size_t)vb * nitems * (kGHdr + C);
+    float absd8[8];   // |d| of channels {4 sub + e, 64 + 4 sub + e} over this lane group's pixels
+#pragma unroll
+    for (int i = 0; i < 8; ++i) absd8[i] = 0.f;
+    float absd2[1][2] = {{0.f, 0.f}};  // rim pixels (generic routine: channels 2 lane, 2 lane + 1)
 
     // ---- 2. geometry, lane = pixel -------------------------------------------------------
     float gw00 = 0.f, gw01 = 0.f, gw10 = 0.f, gw11 = 0.f, jd0 = 0.f, jd1 = 0.f;
@@ -508,11 +512,12 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
     sAbs[w][2 * lane + 1] += absd2[0][1];
     part[kGHdr + lane] = sAbs[w][lane];
     part[kGHdr + 64 + lane] = sAbs[w][64 + lane];
+    }  // pairs
   }  // tiles
 }
 
 int launch_gather128p(const GatherArgs& a, int K, hipStream_t s) {
-  dim3 grid(a.G, a.lv.B * a.pairs), block(kBlock);
+  dim3 grid(a.G, a.lv.B), block(kBlock);
   if (K == 0)
     hipLaunchKernelGGL((ba_gather128p_kernel<0>), grid, block, 0, s, a);
   else if ((K & 3) == 0 && K <= 128)

@@ -14,13 +14,14 @@ B = int(os.environ.get("PB", "4"))
 H, W = int(os.environ.get("PH", "480")), int(os.environ.get("PW", "640"))
 C, K = 128, int(os.environ.get("PK", "128"))
 only = os.environ.get("PONLY")
+PP = int(os.environ.get("PP", "1"))   # target frames per window (pairs)
 dev = torch.device("cuda:0")
-intr, levels, gt = bsynth.make_dense_windows(B, H, W, C, K, [1], 5, dev, trans_mag=0.06)
+intr, levels, gt = bsynth.make_dense_windows(B, H, W, C, K, [1], 5, dev, trans_mag=0.06, pairs=PP)
 variant = "bundle" if K > 0 else "bundle_camera"
 ba = bdense.DenseBA(intr, levels, [he_normal_lambda_weights(C, 1)], variant, 1000.0)
 p = ba.problems[0]
-R = torch.eye(3, device=dev).repeat(B, 1, 1)
-T = (gt["T"] * 0.7).reshape(B, 3, 1).to(dev)
+R = torch.eye(3, device=dev).repeat(B, 1, 1) if PP == 1 else torch.eye(3, device=dev).repeat(B, PP, 1, 1)
+T = (gt["T"] * 0.7).reshape(B, 3, 1).to(dev) if PP == 1 else (gt["T"] * 0.7).reshape(B, PP, 3, 1).to(dev)
 Wc = torch.zeros(B, max(K, 1), 1, device=dev)[:, :K]
 byts = ba.algorithmic_bytes_per_iteration(0) * B
 ALL = ((0, "full"), (1024, "quarter tiles forced"), (512, "patch kernel forced"), (64, "direct gather kernel"), (128, "patch kernel, direct loads only"), (256, "fp32-MFMA syrk"), (16, "no quarter tiles"), (32, "generic kernel"), (1, "all taps -> texel(1,1)"), (4, "no depth dot"), (8, "no gather loop"), (12, "geometry only"))
@@ -47,8 +48,8 @@ for rnd in range(ROUNDS):                      # round-robin over the configurat
 for bits, name in cfgs:
     ms = min(r[0] for r in res[bits])
     ker = {k: round(min(r[1][k] for r in res[bits]), 1) for k in res[bits][0][1]}
-    print("%dx%d K=%d B=%d %-6s %8.1f us/launch  %7.1f us/window  %7.1f GB/s   kernels (best of %d): %s" % (
-        W, H, K, B, name, ms * 1e3, ms * 1e3 / B, byts / ms / 1e6, ROUNDS, ker))
+    print("%dx%d K=%d B=%d pairs=%d %-6s %8.1f us/launch  %7.1f us/window  %7.1f GB/s   kernels (best of %d): %s" % (
+        W, H, K, B, PP, name, ms * 1e3, ms * 1e3 / B, byts / ms / 1e6, ROUNDS, ker))
 ref = None
 for bits, name in cfgs:      # the variants must agree to rounding
     p.c.reserved_ = bits
