@@ -428,7 +428,7 @@ __global__ __launch_bounds__(kBlock, 1) void ba_syrk_direct_kernel(const SyrkArg
 // ba_syrk_bf16x6_kernel -- same sums as ba_syrk_direct_kernel, H_dd on the bf16 matrix pipe at fp32
 // accuracy.  s_n = jd^T M jd >= 0 (M is a Gram matrix), so H_dd = sum (sqrt(s_n) b_n)(sqrt(s_n) b_n)^T:
 // A and B operands are the SAME values v = sqrt(s) b.  Each fp32 v is split EXACTLY into three bf16
-// pieces (v = hi + mid + lo: 8 + 8 + 8 significand bits, by masking and exact subtractions), and
+// pieces (v = hi + mid + lo: 8 + 8 + 8 significand bits, v_cvt_pk_bf16_f32 and exact subtractions), and
 //   v w  =  hi hi' + (hi mid' + mid hi') + (hi lo' + lo hi' + mid mid')  + O(2^-24 |v w|)
 // -- six v_mfma_f32_16x16x32_bf16 (products exact in fp32, fp32 accumulate) per 32 pixels and block,
 // 6 x 17 cycles against 8 x 32 cycles for v_mfma_f32_16x16x4_f32: 2.5x less matrix-pipe time, the
@@ -439,6 +439,28 @@ __global__ __launch_bounds__(kBlock, 1) void ba_syrk_direct_kernel(const SyrkArg
 // --------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// exact 3-way bf16 split of 8 fp32 values, two at a time: v_cvt_pk_bf16_f32 (round to nearest even) gives the packed
+// MFMA operand dword directly; v - hi and (v - hi) - mid are exact in fp32, so hi + mid + lo = v up to 2^-25 |v|.
+// 9 VALU instructions per two values (cvt_pk, shift, and, pk_add, ... ) against ~19 for mask-and-subtract per value.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split8_bf16x3(const float (&x)[8], u32x4_t (&out)[3]) {
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    f32x2_t v = {x[2 * d], x[2 * d + 1]};          // k = 2d (low half), 2d + 1 (high half)
+    const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+    const f32x2_t hf = {__uint_as_float(hp << 16), __uint_as_float(hp & 0xffff0000u)};
+    const f32x2_t r1 = v - hf;
+    const unsigned mp = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2_t));
+    const f32x2_t mf = {__uint_as_float(mp << 16), __uint_as_float(mp & 0xffff0000u)};
+    const f32x2_t r2 = r1 - mf;
+    out[0][d] = hp;
+    out[1][d] = mp;
+    out[2][d] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2_t));
+  }
+}
 
 template <int KH, int PAIRS>
 __global__ __launch_bounds__(kBlock, 1) void ba_syrk_bf16x6_kernel(const SyrkArgs a) {
@@ -503,24 +525,26 @@ __global__ __launch_bounds__(kBlock, 1) void ba_syrk_bf16x6_kernel(const SyrkArg
 #endif
   issue(s0);
   for (int st = s0; st < s1; ++st) {
-    // ---- H_cd / Atb_d: fp32 MFMAs on the raw values, pixel 8 kq + i as the k index of sub-step i
+    // ---- H_cd / Atb_d on the bf16 pipe too: sum u b = sum (u / sqrt(s)) (sqrt(s) b) = sum u~ v with the SAME split v
+    // as H_dd (|u| <= sqrt(Jc^T M Jc) sqrt(s): u~ is bounded, and s = 0 implies M jd = 0, i.e. u = r = 0 exactly).
+    // 6 NBV bf16 MFMAs (16 cycles) per record block row instead of 8 NBV fp32 MFMAs (32 cycles).
     float sq[8];
+    u32x4 opu[NU][3];
+    {
+      float ut[NU][8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const bool ok = 32 * st + 8 * kq + i < N;
-      float ssum = ps[i][0];
+      for (int i = 0; i < 8; ++i) {
+        const bool ok = 32 * st + 8 * kq + i < N;
+        float ssum = ps[i][0];
 #pragma unroll
-      for (int pr = 1; pr < PAIRS; ++pr) ssum += ps[i][pr];
-      sq[i] = ok ? sqrtf(fmaxf(ssum, 0.f)) : 0.f;          // zero switches the pixel off
+        for (int pr = 1; pr < PAIRS; ++pr) ssum += ps[i][pr];
+        sq[i] = ok ? sqrtf(fmaxf(ssum, 0.f)) : 0.f;          // zero switches the pixel off
+        const float inv = sq[i] > 0.f ? 1.f / sq[i] : 0.f;
 #pragma unroll
-      for (int j = 0; j < NU; ++j) {
-        const float uv = (ok && uon[j]) ? pu[i][j] : 0.f;
-#pragma unroll
-        for (int h = 0; h < KH; ++h)
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            acu[j][4 * h + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(uv, pb[i][h][e], acu[j][4 * h + e], 0, 0, 0);
+        for (int j = 0; j < NU; ++j) ut[j][i] = uon[j] ? pu[i][j] * inv : 0.f;
       }
+#pragma unroll
+      for (int j = 0; j < NU; ++j) split8_bf16x3(ut[j], opu[j]);
     }
     // ---- exact 3-way bf16 split of v = sqrt(s) b; one register quad per (virtual block, piece)
     u32x4 op[NBV][3];
@@ -528,42 +552,40 @@ __global__ __launch_bounds__(kBlock, 1) void ba_syrk_bf16x6_kernel(const SyrkArg
     for (int h = 0; h < KH; ++h)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        unsigned pc[3][8];
+        float vv[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float v = sq[i] * pb[i][h][e];
-          const unsigned hi = __float_as_uint(v) & 0xffff0000u;
-          const float r1 = v - __uint_as_float(hi);
-          const unsigned mid = __float_as_uint(r1) & 0xffff0000u;
-          const float r2 = r1 - __uint_as_float(mid);
-          pc[0][i] = hi;
-          pc[1][i] = mid;
-          pc[2][i] = __float_as_uint(r2) & 0xffff0000u;
-        }
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-          for (int d = 0; d < 4; ++d) op[4 * h + e][t][d] = (pc[t][2 * d] >> 16) | pc[t][2 * d + 1];   // k = 2d | 2d + 1
+        for (int i = 0; i < 8; ++i) vv[i] = sq[i] * pb[i][h][e];
+        split8_bf16x3(vv, op[4 * h + e]);
       }
     issue(st + 1);                                          // the raw registers are free again
     __builtin_amdgcn_sched_barrier(0);                      // keep the prefetch ahead of the MFMA block
-    int idx = 0;
+    // Term-major order: consecutive MFMAs write DIFFERENT accumulators.  Block-major (six dependent MFMAs in a row on
+    // one accumulator) measured 19 cycles per MFMA instead of 16 and kept the wave stalled at issue behind each one.
+    // Per accumulator the order of the terms is unchanged (smallest first): bit-identical sums.
+    constexpr int kTa[6] = {2, 0, 1, 1, 0, 0}, kTb[6] = {0, 2, 1, 0, 1, 0};
+#if defined(BANET_SYRK_ABL) && BANET_SYRK_ABL >= 1   // development ablation (tools/time_syrk.py): one product instead of six
+    constexpr int kT0 = 5;
+#else
+    constexpr int kT0 = 0;
+#endif
 #pragma unroll
-    for (int bi = 0; bi < NBV; ++bi)
+    for (int t6 = kT0; t6 < 6; ++t6) {
 #pragma unroll
-      for (int bj = bi; bj < NBV; ++bj) {
-        f32x4 c = acc[idx];
-#define BANET_MM(ta, tb) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, op[bi][ta]), __builtin_bit_cast(bf16x8, op[bj][tb]), c, 0, 0, 0)
-        BANET_MM(2, 0);   // smallest terms first
-        BANET_MM(0, 2);
-        BANET_MM(1, 1);
-        BANET_MM(1, 0);
-        BANET_MM(0, 1);
-        BANET_MM(0, 0);
-#undef BANET_MM
-        acc[idx] = c;
-        ++idx;
-      }
+      for (int j = 0; j < NU; ++j)
+#pragma unroll
+        for (int bj = 0; bj < NBV; ++bj)
+          acu[j][bj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, opu[j][kTa[t6]]),
+                                                               __builtin_bit_cast(bf16x8, op[bj][kTb[t6]]), acu[j][bj], 0, 0, 0);
+      int idx = 0;
+#pragma unroll
+      for (int bi = 0; bi < NBV; ++bi)
+#pragma unroll
+        for (int bj = bi; bj < NBV; ++bj) {
+          acc[idx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, op[bi][kTa[t6]]),
+                                                             __builtin_bit_cast(bf16x8, op[bj][kTb[t6]]), acc[idx], 0, 0, 0);
+          ++idx;
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
 #ifdef BANET_TIMING
