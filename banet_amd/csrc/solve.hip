@@ -353,12 +353,19 @@ __device__ __attribute__((always_inline)) void ldlt_solve_blocked(float* A, int 
       float myinv = 1.f;
 #pragma unroll
       for (int j = 0; j < kPanel; ++j) {
-        const float inv = __builtin_amdgcn_rcpf(rdlane(a[j], j));        // v_rcp_f32: <= 1 ulp
+        // pivot row j: all broadcasts first, then the arithmetic (a v_readlane feeding the very next VALU instruction costs
+        // wait states; batched, the 16 - j reads pipeline)
+        float pr[kPanel];
+#pragma unroll
+        for (int c = j; c < kPanel; ++c) pr[c] = rdlane(a[c], j);
+        __builtin_amdgcn_sched_barrier(0);
+        const float inv = __builtin_amdgcn_rcpf(pr[j]);                  // v_rcp_f32: <= 1 ulp
         if (row == j) myinv = inv;
         const float l = row > j ? a[j] * inv : 0.f;
 #pragma unroll
-        for (int c = j + 1; c < kPanel; ++c) a[c] = fmaf(-l, rdlane(a[c], j), a[c]);
+        for (int c = j + 1; c < kPanel; ++c) a[c] = fmaf(-l, pr[c], a[c]);
         a[j] = row > j ? l : a[j];
+        __builtin_amdgcn_sched_barrier(0);
       }
       if (lane < kPanel) {
         sDinv[row] = myinv;
