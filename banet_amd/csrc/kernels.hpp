@@ -34,9 +34,14 @@ const float* finish_gather(const banet_level_t* lv, const GatherPlan& pl, const 
 // ---- syrk.hip --------------------------------------------------------------------------
 struct SyrkPlan {
   int Gs, tiles, pstride, nb;
-  int direct;   // 1: ba_syrk_direct_kernel (K = 64 / 128), 0: the LDS-tiled kernel
+  int direct;   // 0: the LDS-tiled kernel, 1: ba_syrk_direct_kernel (fp32 MFMA, A/B), 2: ba_syrk_bf16x6_kernel (K = 64 / 128, <= 4 frames),
+                // 3: syrk_wide.hip jobs (K = 256, or K = 128 with more than 4 target frames)
+  size_t off_aux;        // direct == 3: per-pixel (s, r) sums over the frames, inside the partial buffer
   size_t partial_bytes;
 };
+size_t syrk_wide_aux_bytes(int B, int N, int pairs);
+int launch_syrk_wide(const float* basis, const float* rec, int B, int N, int K, int pairs, int Gs, int pstride,
+                     const int32_t* active, int active_stride, float* partials, float* aux, hipStream_t s);
 int plan_syrk(int B, int N, int K, int pairs, int dbg, SyrkPlan* pl);
 int launch_syrk(const float* basis, const float* rec, int B, int N, int K, int pairs, const SyrkPlan& pl,
                 const int32_t* active, int active_stride, float* partials, hipStream_t s);

@@ -10,6 +10,7 @@
 // LDS double buffer, one barrier per tile.  Wave w owns block rows w and NB-1-w of the upper
 // triangle (NB+1 blocks: balanced); accumulators stay in registers for the whole kernel.
 #include "kernels.hpp"
+#include "syrk_split.hpp"
 
 namespace banet {
 
@@ -440,28 +441,6 @@ __global__ __launch_bounds__(kBlock, 1) void ba_syrk_direct_kernel(const SyrkArg
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// exact 3-way bf16 split of 8 fp32 values, two at a time: v_cvt_pk_bf16_f32 (round to nearest even) gives the packed
-// MFMA operand dword directly; v - hi and (v - hi) - mid are exact in fp32, so hi + mid + lo = v up to 2^-25 |v|.
-// 9 VALU instructions per two values (cvt_pk, shift, and, pk_add, ... ) against ~19 for mask-and-subtract per value.
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void split8_bf16x3(const float (&x)[8], u32x4_t (&out)[3]) {
-#pragma unroll
-  for (int d = 0; d < 4; ++d) {
-    f32x2_t v = {x[2 * d], x[2 * d + 1]};          // k = 2d (low half), 2d + 1 (high half)
-    const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
-    const f32x2_t hf = {__uint_as_float(hp << 16), __uint_as_float(hp & 0xffff0000u)};
-    const f32x2_t r1 = v - hf;
-    const unsigned mp = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2_t));
-    const f32x2_t mf = {__uint_as_float(mp << 16), __uint_as_float(mp & 0xffff0000u)};
-    const f32x2_t r2 = r1 - mf;
-    out[0][d] = hp;
-    out[1][d] = mp;
-    out[2][d] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2_t));
-  }
-}
-
 template <int KH, int PAIRS>
 __global__ __launch_bounds__(kBlock, 1) void ba_syrk_bf16x6_kernel(const SyrkArgs a) {
   constexpr int NBV = 4 * KH, NPAIR = NBV * (NBV + 1) / 2, K = 64 * KH;
@@ -769,6 +748,8 @@ int plan_syrk(int B, int N, int K, int pairs, int dbg, SyrkPlan* pl) {
   // K = 64 / 128: barrier-free kernels, one wave per SIMD, 256 workgroups in all: 2 = ba_syrk_bf16x6_kernel
   // (default), 1 = ba_syrk_direct_kernel (fp32 MFMA; reserved_ bit 8, A/B only)
   pl->direct = ((K == 64 || K == 128) && pairs <= 4) ? ((dbg & 256) ? 1 : 2) : 0;
+  // K = 256, or K = 128 with more than 4 target frames: the job kernels of syrk_wide.hip (reserved_ bit 8: the LDS-tiled kernel, A/B)
+  if (!(dbg & 256) && (K == 256 || (K == 128 && pairs > 4))) pl->direct = 3;
   int target = (((pl->direct || pl->nb > 8) ? 256 : 512) + B - 1) / B;   // LDS kernel: 2 resident workgroups per CU (1 at K > 128)
   int G = pl->direct ? (N + 4 * 4 * 16 - 1) / (4 * 4 * 16) : pl->tiles / 4;   // direct: >= 16 quads per wave
   if (G > target) G = target;
@@ -776,6 +757,8 @@ int plan_syrk(int B, int N, int K, int pairs, int dbg, SyrkPlan* pl) {
   pl->Gs = G;
   pl->pstride = (int)align_up((size_t)(6 * pairs + 1) * K + (size_t)K * K, 4);
   pl->partial_bytes = align_up((size_t)B * G * pl->pstride * sizeof(float), 256);
+  pl->off_aux = pl->partial_bytes;
+  if (pl->direct == 3) pl->partial_bytes += syrk_wide_aux_bytes(B, N, pairs);
   return BANET_OK;
 }
 
@@ -815,6 +798,9 @@ static void launch_direct(const SyrkArgs& a, int B, hipStream_t s) {
 
 int launch_syrk(const float* basis, const float* rec, int B, int N, int K, int pairs, const SyrkPlan& pl,
                 const int32_t* active, int active_stride, float* partials, hipStream_t s) {
+  if (pl.direct == 3)
+    return launch_syrk_wide(basis, rec, B, N, K, pairs, pl.Gs, pl.pstride, active, active_stride, partials,
+                            reinterpret_cast<float*>(reinterpret_cast<char*>(partials) + pl.off_aux), s);
   SyrkArgs a{basis, rec, active, active_stride, partials, N, K, pl.Gs, pl.tiles, pl.pstride, pairs, 0};
   if (pl.direct == 2) {
     if (K == 128)

@@ -515,10 +515,11 @@ def test_patch_gather_kernel_matches_oracle(H, W, K, big, pairs):
             assert relerr(outs[512][0][:, 6 * i:6 * i + 6, 6 * i:6 * i + 6], d["AtA"]) < 3e-5
 
 
-@pytest.mark.parametrize("C,K,pairs", [(128, 256, 7), (12, 200, 2), (128, 256, 1)])
+@pytest.mark.parametrize("C,K,pairs", [(128, 256, 7), (12, 200, 2), (128, 256, 1), (128, 128, 6), (20, 256, 5)])
 def test_large_basis_windows_match_oracle(C, K, pairs):
-    """BASELINE configs[4] class: K = 256 coefficients, up to 8 frames (P = 6*7 + 256 = 298).  The LDS-tiled SYRK runs
-    with 16 block rows, the solve keeps its matrix in the caller's workspace (it does not fit in LDS)."""
+    """BASELINE configs[4] class: K = 256 coefficients, up to 8 frames (P = 6*7 + 256 = 298).  K = 256 (and K = 128 with
+    more than 4 target frames) runs the job kernels of syrk_wide.hip, K = 200 the LDS-tiled SYRK with 16 block rows; the
+    solve keeps its matrix in the caller's workspace when it does not fit in LDS."""
     from banet_amd import dense as bdense, ops
     B, H, W = 2, 32, 40
     scenes = _window_scenes(B, H, W, C, K, [1], 55, pairs)
