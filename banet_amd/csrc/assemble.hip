@@ -1,6 +1,6 @@
-// One BA assembly pass = ba_gather_kernel (HBM-bound: warp, sample, residual, 2x2 channel
-// reductions, pose block) + ba_syrk_kernel (depth-basis blocks on the matrix cores) +
-// ba_reduce2_kernel (fixed-order sum of the per-workgroup partials).  Also hosts the optional
+// One BA assembly pass = a gather kernel (gather*.hip; HBM-bound: warp, sample, residual, 2x2 channel
+// reductions, pose block) + ba_fold_kernel + a SYRK kernel (syrk*.hip; depth-basis blocks on the matrix cores) +
+// ba_reduce2_kernel (fixed-order sum of the per-tile / per-workgroup partials).  Also hosts the optional
 // launch timer behind banet_profile_begin/_end.
 #include <vector>
 

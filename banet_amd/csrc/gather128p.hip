@@ -2,10 +2,13 @@
 // Two consecutive steps (8 pixels = a 4x2 block of the tile) share most of their 12-texel stencils: their
 // bounding box in the target map is 7x5 texels for near-unit local scale, against 8 x 12 = 96 tap loads.
 // The wave copies that box once per channel half (<= 36 texels x 256 B = 9 KB) into its OWN LDS patch
-// (9 coalesced 16-byte loads per lane instead of 24) and serves the taps with ds_read_b128: 2.4x fewer bytes
-// through the vector-memory pipeline that bounds the direct kernel.  No workgroup barrier: waves stay
-// independent (the workgroup-synchronous staged kernels in experiments/ lost to exactly that).  A step pair
-// whose box does not fit (local scale > 1 by more than a few %, strong rotation) takes the direct loads.
+// (9 coalesced 16-byte loads per lane instead of 24) and serves the taps with ds_read_b128.  Fewer bytes through
+// TA/L1 alone did not pay; what pays is that a unit's loads fit in 44 registers, so the NEXT unit's box is
+// prefetched while the current one is computed (software pipeline across units, 2 workgroups per CU).
+// No workgroup barrier: waves stay independent (the workgroup-synchronous staged kernels in experiments/ lost
+// to exactly that).  A step pair whose box does not fit (local scale > 1 by more than a few %, strong rotation)
+// takes the direct loads.  A multi-frame window's target frames are looped over inside a tile, so the tile's
+// depth D0 + b.W (a read of its basis rows) is computed once per window.
 #include "gather_common.hpp"
 
 namespace banet {

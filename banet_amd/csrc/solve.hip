@@ -7,7 +7,8 @@
 //                                tf.qr + triangular solve legacy/ba.py:292-293
 //   update                       bundlenet.py:185-190,269-276 ; legacy/ba.py:208-213,295-302
 //   accept / terminate           legacy/ba.py:132-140,304-345
-// The matrix lives in LDS (P <= 134 -> 72 KB of the 160 KB per CU).
+// The matrix lives in LDS (P <= 134 -> 72 KB of the 160 KB per CU); larger systems (K = 256, many frames) keep it in
+// the caller's workspace (template<bool BIG>, workgroup-private and L2-resident).
 #include <type_traits>
 
 #include "kernels.hpp"

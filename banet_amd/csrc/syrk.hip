@@ -1,3 +1,10 @@
+// The depth-basis blocks of the normal equations on gfx950.  Three kernels compute the same sums:
+//   ba_syrk_bf16x6_kernel  the product path for K = 64 / 128 and <= 4 target frames: bf16 matrix pipe at fp32 accuracy,
+//                          operands straight from registers (see its header comment further down);
+//                          K = 256 and more frames: the same scheme cut into jobs, syrk_wide.hip;
+//   ba_syrk_direct_kernel  its fp32-MFMA predecessor, kept for A/B (reserved_ bit 8);
+//   ba_syrk_kernel<NB>     LDS-tiled fp32 MFMA, any K <= 256 (the remaining basis sizes), described first:
+//
 // ba_syrk_kernel -- the depth-basis blocks of the normal equations on gfx950:
 //   H_dd = sum_n s_n b_n b_n^T   (K x K, fp32 MFMA v_mfma_f32_16x16x4_f32, upper 16x16 blocks)
 //   H_cd = sum_n u_n b_n^T       (6 x K, VALU rank-1 updates)
