@@ -19,7 +19,8 @@ import torch
 from . import ops
 
 __all__ = ["rotation2quaternion", "AngleaAxisRotation", "VMatrix", "CameraJacobianMatrix", "DepthJacobianMatrix",
-           "equation_construction", "equation_construction_grad", "resampler", "BundleNet"]
+           "equation_construction", "equation_construction_grad", "resampler", "BundleNet",
+           "lambda_weights_from_variables", "lambda_weights_to_variables"]
 
 equation_construction = ops.equation_construction            # bundlenet.py:77
 equation_construction_grad = ops.equation_construction_grad  # bundlenet.py:78
@@ -124,6 +125,51 @@ def he_normal_lambda_weights(C, seed, device="cpu"):
         std = math.sqrt(2.0 / dims[i]) / 0.87962566103423978
         w = torch.clamp(torch.randn(dims[i], dims[i + 1], generator=g), -2, 2) * std
         out.append((w.to(device), torch.zeros(dims[i + 1], device=device)))
+    return out
+
+
+def lambda_weights_from_variables(variables):
+    """Import the reference's lambda-MLP variables (bundlenet.py:102-110,168-172): a mapping name -> array holding
+    `lambda_<level>_<i>_filters` [1, Cin, Cout] (or [Cin, Cout]) and `lambda_<level>_<i>_biases` [Cout] for i = 1..5, e.g.
+    an .npz exported from a TF-1.x checkpoint.  Variable-scope prefixes (`lambda_<level>_<i>/...`, anything before the
+    last '/') and a ':0' suffix are ignored.  Returns {level: [(filters [Cin,Cout], biases [Cout]) x 5]} -- the
+    `lambda_weights` argument of BundleNet / legacy.Tracker."""
+    found = {}
+    for name, arr in variables.items():
+        base = str(name).split("/")[-1].split(":")[0]
+        parts = base.split("_")
+        if len(parts) != 4 or parts[0] != "lambda" or parts[3] not in ("filters", "biases") or not parts[2].isdigit():
+            continue
+        t = torch.as_tensor(arr, dtype=torch.float32)
+        if parts[3] == "filters":
+            if t.dim() == 3 and t.shape[0] == 1:
+                t = t[0]
+            if t.dim() != 2:
+                raise ValueError("%s: expected a [1, Cin, Cout] conv1d filter, got %s" % (name, tuple(t.shape)))
+        elif t.dim() != 1:
+            raise ValueError("%s: expected [Cout] biases, got %s" % (name, tuple(t.shape)))
+        found.setdefault(parts[1], {}).setdefault(int(parts[2]), {})[parts[3]] = t.contiguous()
+    out = {}
+    for level, layers in found.items():
+        seq = []
+        for i in range(1, 6):
+            lay = layers.get(i, {})
+            if "filters" not in lay or "biases" not in lay:
+                raise KeyError("lambda_%s_%d: filters / biases missing" % (level, i))
+            if lay["filters"].shape[1] != lay["biases"].shape[0] or (seq and seq[-1][0].shape[1] != lay["filters"].shape[0]):
+                raise ValueError("lambda_%s_%d: inconsistent layer shapes" % (level, i))
+            seq.append((lay["filters"], lay["biases"]))
+        out[level] = seq
+    return out
+
+
+def lambda_weights_to_variables(lambda_weights):
+    """Inverse of lambda_weights_from_variables: {name: numpy array} with the reference's names and shapes."""
+    out = {}
+    for level, seq in lambda_weights.items():
+        for i, (w, b) in enumerate(seq, 1):
+            out["lambda_%s_%d_filters" % (level, i)] = w.detach().cpu().numpy()[None]
+            out["lambda_%s_%d_biases" % (level, i)] = b.detach().cpu().numpy()
     return out
 
 

@@ -40,3 +40,26 @@ def test_oracle_sequence_recovers_motion_and_switches_keyframes():
     # frame 4 is tracked against key frame 3: relative motion, chained into the global pose (seq_example.py:168-169)
     np.testing.assert_allclose(out[3]["globalRotation"], np.matmul(out[3]["rotation"], out[2]["globalRotation"]), atol=1e-6)
     assert all(1 <= c <= m for o in out for c, m in zip(o["iters"], [5, 8, 8]))
+
+
+def test_lambda_weight_import_round_trip(tmp_path):
+    """the reference's lambda-MLP variables (bundlenet.py:102-110: lambda_<level>_<i>_filters [1,Cin,Cout], _biases [Cout])
+    import from / export to an .npz unchanged, scope prefixes and ':0' suffixes ignored; malformed sets are rejected"""
+    import numpy as np
+    import pytest
+    import torch
+    from banet_amd import bundlenet as bn
+    C = 8
+    lw = {"3": bn.he_normal_lambda_weights(C, 5), "0": bn.he_normal_lambda_weights(C, 6)}
+    var = bn.lambda_weights_to_variables(lw)
+    assert var["lambda_3_2_filters"].shape == (1, 2 * C, 4 * C) and var["lambda_0_5_biases"].shape == (1,)
+    path = tmp_path / "lambda.npz"
+    np.savez(path, **{"lambda_%s/%s:0" % (k.split("_")[1] + "_" + k.split("_")[2], k): v for k, v in var.items()})
+    back = bn.lambda_weights_from_variables(dict(np.load(path)))
+    assert sorted(back) == ["0", "3"]
+    for lev in lw:
+        for (w0, b0), (w1, b1) in zip(lw[lev], back[lev]):
+            assert torch.equal(w0, w1) and torch.equal(b0, b1)
+    del var["lambda_3_4_biases"]
+    with pytest.raises(KeyError):
+        bn.lambda_weights_from_variables(var)
