@@ -104,6 +104,12 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
   const int half = lane >> 5, li = lane & 31;
 
   float wreg[KV4 ? KV4 : 1][4];  // this lane's slice of the depth coefficients
+  // The waves of a workgroup start 7 us apart (s_sleep 127 = 8128 cycles): launched together they stay in lock-step through
+  // the first tiles (depth-dot burst, then every unit's loads at the same time); measured 320x240 x 8: 39.0 -> 37.6
+  // us/window, 640x480 x 8: 125.5 -> 124.1; 15 us per wave: no better.  (On the short levels, which run the direct
+  // kernel, any stagger loses.)
+  if (!(lv.reserved_ & 2048))   // bit 11: no stagger (A/B)
+    for (int i = 0; i < 2 * w; ++i) __builtin_amdgcn_s_sleep(127);
   if constexpr (KV4 > 0) {
 #pragma unroll
     for (int kc = 0; kc < KV4; ++kc)

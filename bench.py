@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--basis", type=int, default=K, help="depth-basis coefficients K")
     ap.add_argument("--iters", type=int, default=ITERS[0], help="LM iterations per level")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--reserved", type=int, default=0, help="development: banet_level_t.reserved_ bits for every level (A/B switches)")
     args = ap.parse_args()
 
     import torch
@@ -106,6 +107,8 @@ def main():
     intr, levels, gt = bsynth.make_dense_windows(B, Hh, Ww, C, Kk, SCALES, 1234 + 2 + rank, dev, trans_mag=0.06, pairs=pairs)
     mlps = [he_normal_lambda_weights(C, 100 + i) for i in range(len(SCALES))]
     ba = bdense.DenseBA(intr, levels, mlps, "bundle", 1000.0)
+    for prob in ba.problems:
+        prob.c.reserved_ = args.reserved
     T0 = (gt["T"] * 0.7).reshape(B * pairs, 3, 1).to(dev)   # translation prior: depth is unobservable from T = 0
 
     def step():
