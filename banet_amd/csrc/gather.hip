@@ -464,7 +464,12 @@ int plan_gather(const banet_level_t* lv, GatherPlan* pl) {
                 (lv->reserved_ & 512))) ? 1 : 0;   // bit 9: force it at any size (parity tests)
   const int resident = kCUs * (pl->patch ? BANET_G128P_WAVES : pl->c128 ? kC128BlocksPerCU : kGenericBlocksPerCU);
   const int VB = lv->B * npairs(lv);   // virtual windows
-  const int gy = pl->patch ? lv->B : VB;   // the patch kernel loops over a window's target frames inside a tile: grid.y = windows
+  // the patch kernel loops over a window's target frames inside a tile (depth dot once per window) where a window alone has
+  // >= 4 tiles per resident wave; below that the 4x coarser items cost more than the shared depth saves (80x60 x 32
+  // windows x 4 frames: 327 -> 478 us) and a work item stays one pair's tile
+  pl->pairloop = (pl->patch && npairs(lv) > 1 && ((long long)pl->tiles * lv->B >= 4LL * kCUs * BANET_G128P_WAVES * kNumWaves ||
+                                                   (lv->reserved_ & 4096))) ? 1 : 0;   // bit 12: force it (parity tests)
+  const int gy = pl->pairloop ? lv->B : VB;
   int target = (resident + gy - 1) / gy;
   // Mid-size levels (a few tiles per wave at most) start all their waves in the same phase: measured, ~1300 waves
   // finish a tile in 67 us but 2560 need 169 us (160x120 x 8: one tile per wave 21.1 us/window, two per wave on half
@@ -584,6 +589,7 @@ int launch_gather(const banet_level_t* lv, const GatherPlan& pl, const float* R,
   a.nbands = pl.nbands;
   a.pairs = npairs(lv);
   a.qshift = pl.qshift;
+  a.pairloop = pl.pairloop;
   int rc;
   if (pl.c128)
     rc = pl.patch ? launch_gather128p(a, lv->K, s) : launch_gather128(a, lv->K, s);

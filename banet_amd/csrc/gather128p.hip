@@ -87,8 +87,12 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
   __shared__ __attribute__((aligned(16))) float sPatch[kNumWaves][kPatchTexels * 64];   // one channel half of a step pair's box
   __shared__ int sGrp[kNumWaves][8][4];                                                  // per step pair: base offset, pw, staged
   const banet_level_t& lv = a.lv;
-  const int b = blockIdx.y, g = blockIdx.x;    // a workgroup serves one window; a multi-frame window's target frames
-                                               // ("pairs") are looped over INSIDE a tile: the depth D0 + b.W is computed once
+  // pairloop (levels with enough tiles per window): a workgroup serves one window and a multi-frame window's target frames
+  // ("pairs") are looped over INSIDE a tile, so the depth D0 + b.W is computed once; otherwise grid y = (window, pair)
+  // and a work item is one pair's tile (4x finer items for the levels where items are scarce).
+  const int g = blockIdx.x;
+  const int b = a.pairloop ? blockIdx.y : blockIdx.y / a.pairs;
+  const int pr_lo = a.pairloop ? 0 : blockIdx.y % a.pairs, pr_hi = a.pairloop ? a.pairs : pr_lo + 1;
   if (a.active != nullptr && a.active[(size_t)b * a.active_stride] == 0) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = wave_id();
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
 
   // ---- tile queue: band x = tiles [tiles x / nb, tiles (x+1) / nb); home band = this workgroup's XCD
   const int nb = a.nbands;
-  int* __restrict__ queue = a.queue + b * 8;
+  int* __restrict__ queue = a.queue + blockIdx.y * 8;
   int band = nb > 1 ? (g & 7) : 0, left = nb;
   auto band_lo = [&](int x) { return (int)(((long long)nitems * x) / nb); };
   auto pop_raw = [&](int x) {  // issues the atomic; the id is read (v_readfirstlane) only when it is needed
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
     }
 
 #pragma unroll 1
-    for (int pr = 0; pr < a.pairs; ++pr) {   // target frames of the window: same pixels, depth and source features
+    for (int pr = pr_lo; pr < pr_hi; ++pr) {   // target frames of the window: same pixels, depth and source features
     const int vb = b * a.pairs + pr;
     const float* __restrict__ tgt_b = lv.tgt + (size_t)vb * H * W * C;
     float* __restrict__ rec_b = KV4 ? a.rec + (size_t)vb * N * 8 : nullptr;
@@ -526,7 +530,7 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
 }
 
 int launch_gather128p(const GatherArgs& a, int K, hipStream_t s) {
-  dim3 grid(a.G, a.lv.B), block(kBlock);
+  dim3 grid(a.G, a.pairloop ? a.lv.B : a.lv.B * a.pairs), block(kBlock);
   if (K == 0)
     hipLaunchKernelGGL((ba_gather128p_kernel<0>), grid, block, 0, s, a);
   else if ((K & 3) == 0 && K <= 128)

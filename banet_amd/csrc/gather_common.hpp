@@ -18,6 +18,7 @@ struct GatherArgs {
   int* queue;       // [B][8] tile-queue heads (ba_gather128_kernel), zero at launch
   int nbands;
   int pairs;        // target frames per window: blockIdx.y = window * pairs + pair
+  int pairloop;     // ba_gather128p_kernel: 1 = grid y = window, the window's target frames are looped over inside a tile
   int qshift;       // ba_gather128_kernel: 0 = a work item is a tile, 2 = a quarter tile (small levels)
 };
 

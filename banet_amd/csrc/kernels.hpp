@@ -17,6 +17,7 @@ struct GatherPlan {
   int rows;     // partial rows per window written by the gather kernel (tiles or G)
   int frows;    // rows per window handed to ba_reduce2_kernel (after ba_fold_kernel when rows > kFoldRows)
   int nbands;   // tile-queue bands (8 = one per XCD)
+  int pairloop; // patch kernel: target frames looped over inside a tile (grid y = windows)
   int qshift;   // 2: quarter-tile work items (levels with fewer tiles than resident waves)
   size_t off_fold, off_queue;   // inside the partial region
   size_t partial_bytes, rec_bytes;

@@ -488,12 +488,14 @@ def test_patch_gather_kernel_matches_oracle(H, W, K, big, pairs):
     mlps = [orc.he_normal_mlp_weights(C, 9)]
     ba = bdense.DenseBA(t(intr), _torch_levels(levels), mlps, "bundle" if K else "bundle_camera", 1000.0)
     outs = {}
-    for bits in (512, 64):                                       # patch kernel forced / direct kernel
-        ba.problems[0].c.reserved_ = bits
+    for bits in (512, 64, 512 | 4096):                           # patch kernel forced / direct kernel / patch kernel with the
+        ba.problems[0].c.reserved_ = bits                         # target frames looped over inside a tile (large levels)
         outs[bits] = [n(x) for x in ops.ba_assemble(ba.problems[0], t(R), t(T), t(Wc) if K else None)]
     ba.problems[0].c.reserved_ = 0
     for x, y in zip(outs[512], outs[64]):
         assert relerr(x, y) < 2e-6, relerr(x, y)
+    for x, y in zip(outs[512 | 4096], outs[512]):                 # same arithmetic per pair: identical bits
+        np.testing.assert_array_equal(x, y)
     one = dict(lv)
     one["tgt"] = lv["tgt"][:, 0]
     a = odense.level_inputs(intr, one, True, np.float64)
