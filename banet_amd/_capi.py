@@ -52,6 +52,9 @@ EXPORTS = {
     "banet_resample_f32": (ctypes.c_int, [_FP] * 3 + [ctypes.c_int] * 6 + [_FP]),
     "banet_target_map_f32": (ctypes.c_int, [_FP] * 2 + [ctypes.c_int] * 4 + [_FP]),
     "banet_depth_output_f32": (ctypes.c_int, [_FP] * 4 + [ctypes.c_int] * 3 + [_FP]),
+    "banet_sample_stats_blocks": (ctypes.c_int, [ctypes.c_int]),
+    "banet_sample_stats_f32": (ctypes.c_int, [_FP] * 4 + [ctypes.c_int] * 5 + [_FP] * 3),
+    "banet_sample_stats_grad_f32": (ctypes.c_int, [_FP] * 4 + [ctypes.c_int] * 5 + [_FP] * 6),
     "banet_ba_assemble_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Level)]),
     "banet_ba_assemble_f32": (ctypes.c_int, [ctypes.POINTER(Level)] + [_FP] * 7 + [_FP, ctypes.c_size_t, _FP]),
     "banet_ba_solve_update_f32": (ctypes.c_int, [ctypes.POINTER(Level), ctypes.POINTER(Mlp), ctypes.c_float] + [_FP] * 4 +

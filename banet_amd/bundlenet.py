@@ -187,6 +187,10 @@ class BundleNet:
         # backward); False = the reference's registered gradient verbatim (inexact: matrix_solve's
         # gradient w.r.t. AtA is not symmetric, utils.cu:648-657 assumes it is)
         self.exact_gradients = True
+        # training graph: "lean" = C-wide statements as one HIP op with a HIP adjoint, normal equations by block (no
+        # samp / diff / grad / J tensors; always exact gradients); "reference" = the reference's statements one by one
+        # with the EquationConstruction op and its registered gradient
+        self.training_graph = "lean"
 
     # -- small helpers kept for API parity --------------------------------------------
     def grad_fixed(self, input, name=None):
@@ -222,7 +226,7 @@ class BundleNet:
         """bundlenet.py:122-191: one pose-only GN/LM step -> (updatedR, updatedT)."""
         if torch.is_grad_enabled() and any(torch.is_tensor(x) and x.requires_grad
                                            for x in (conv1, conv2, D, R, T) + self._lambda_tensors(level)):
-            R2, T2, _ = self._iteration_autograd(conv1, conv2, fx, fy, ox, oy, p, D, None, R, T, None, l2_regularizer_base,
+            R2, T2, _ = self._training_iteration(conv1, conv2, fx, fy, ox, oy, p, D, None, R, T, None, l2_regularizer_base,
                                                  level)
             return R2, T2
         B, H, W, C3 = conv2.shape
@@ -239,7 +243,7 @@ class BundleNet:
         """bundlenet.py:193-278: pose + depth-basis step -> (updatedR, updatedT, updatedW)."""
         if torch.is_grad_enabled() and any(torch.is_tensor(x) and x.requires_grad
                                            for x in (conv1, conv2, D, B, R, T, W) + self._lambda_tensors(level)):
-            return self._iteration_autograd(conv1, conv2, fx, fy, ox, oy, p, D, B, R, T, W, l2_regularizer_base, level)
+            return self._training_iteration(conv1, conv2, fx, fy, ox, oy, p, D, B, R, T, W, l2_regularizer_base, level)
         nb, H, Wd, C3 = conv2.shape
         C = conv1.shape[2]
         K = B.shape[-1]
@@ -256,6 +260,11 @@ class BundleNet:
     def _lambda_tensors(self, level):
         lw = self.lambda_weights.get(str(level))
         return tuple(t for pair in lw for t in pair if torch.is_tensor(t)) if lw else ()
+
+    def _training_iteration(self, *args):
+        if self.training_graph == "lean" and self.exact_gradients:
+            return self._iteration_autograd_lean(*args)
+        return self._iteration_autograd(*args)
 
     def _iteration_autograd(self, conv1, conv2, fx, fy, ox, oy, p, D, B, R, T, W, l2_regularizer_base, level):
         """The reference's differentiable graph, statement for statement (bundlenet.py:193-278, and
@@ -293,6 +302,66 @@ class BundleNet:
             jd = DepthJacobianMatrix(rx.unsqueeze(1), ry.unsqueeze(1), rz.unsqueeze(1), x, y, Z, fx, fy)
             J = torch.cat([J, jd.unsqueeze(-1) * B.unsqueeze(-2)], dim=-1)              # :260-261
         AtA, Atb = ops.equation_construction(J, grad, diff, symmetric_grad=self.exact_gradients)   # :263 (HIP fwd + bwd)
+        diag = torch.diagonal(AtA, dim1=1, dim2=2)
+        if bundle:
+            damp = torch.cat([diag[:, :-1] + 1e-5, torch.zeros(nb, 1, device=diag.device)], dim=-1)   # :266
+        else:
+            damp = diag + 1e-5                                                          # :182
+        AtA = AtA + torch.diag_embed(damp * lam.squeeze(-1))
+        sol = torch.linalg.solve(AtA, Atb)                                              # :267
+        wx, wy, wz = sol[:, 0], sol[:, 1], sol[:, 2]
+        dr = AngleaAxisRotation(wx, wy, wz)
+        dv = VMatrix(wx.reshape(-1), wy.reshape(-1), wz.reshape(-1))
+        updatedR = torch.matmul(dr, R)
+        updatedT = torch.matmul(dv, sol[:, 3:6]) + torch.matmul(dr, T)
+        updatedW = W + sol[:, 6:] if bundle else None
+        self.last = dict(AtA=AtA, Atb=Atb, lam=lam.reshape(-1), delta=sol[..., 0])
+        return updatedR, updatedT, updatedW
+
+    def _iteration_autograd_lean(self, conv1, conv2, fx, fy, ox, oy, p, D, B, R, T, W, l2_regularizer_base, level):
+        """The same iteration as _iteration_autograd (same values, same gradients) without its large intermediates:
+        the C-wide statements (:230-243) are one HIP op with a HIP adjoint (ops.sample_stats: per-pixel M = G^T G,
+        g = G^T d, mask and sum |d|), and J^T (G^T G) J / J^T G^T d (:263, utils.cu:331-414) are formed from M, g and the
+        per-pixel Jacobians by block -- pose block by small per-pixel algebra, depth blocks as basis GEMMs -- instead of
+        materialising samp [B,N,3C], diff, grad and J [B,N,2,P].  Everything else is the reference's statements."""
+        nb, npix, C = conv1.shape
+        bundle = B is not None
+        if bundle:
+            D = D + torch.matmul(B, W)                                                   # :207
+        Rp = torch.matmul(R, p)
+        rx, ry, rz = Rp[:, 0], Rp[:, 1], Rp[:, 2]
+        RPT = Rp * D.transpose(1, 2) + T                                                # :210-213
+        X, Y, Z = RPT[:, 0], RPT[:, 1], RPT[:, 2]
+        x, y = X / Z, Y / Z
+        px, py = fx * x + ox, fy * y + oy
+        stats, _mask, absd = ops.sample_stats(conv1, conv2, px, py)                      # :230-239 (HIP fwd + bwd)
+        avg = (absd / float(npix)).unsqueeze(1)                                         # :243
+        h = avg
+        lw = self.lambda_weights[str(level)]
+        for i, (w, b) in enumerate(lw):
+            z = torch.matmul(h, w.to(h.device)) + b.to(h.device)
+            h = torch.tanh(z) if i == 4 else torch.nn.functional.selu(z)
+        lam = torch.linalg.vector_norm(avg, dim=-1, keepdim=True) ** (2.0 + h)          # :249
+        if l2_regularizer_base is not None:
+            lam = l2_regularizer_base * lam
+        Jc = CameraJacobianMatrix(x, y, Z, fx, fy)                                      # [B,N,2,6]  :259
+        M11, M12, M22, g1, g2 = (stats[..., i] for i in range(5))
+        MJ0 = M11.unsqueeze(-1) * Jc[:, :, 0] + M12.unsqueeze(-1) * Jc[:, :, 1]         # rows of M Jc  [B,N,6]
+        MJ1 = M12.unsqueeze(-1) * Jc[:, :, 0] + M22.unsqueeze(-1) * Jc[:, :, 1]
+        Hcc = torch.matmul(Jc[:, :, 0].transpose(1, 2), MJ0) + torch.matmul(Jc[:, :, 1].transpose(1, 2), MJ1)   # [B,6,6]
+        bc = (Jc[:, :, 0] * g1.unsqueeze(-1) + Jc[:, :, 1] * g2.unsqueeze(-1)).sum(dim=1)                         # [B,6]
+        if bundle:
+            jd = DepthJacobianMatrix(rx.unsqueeze(1), ry.unsqueeze(1), rz.unsqueeze(1), x, y, Z, fx, fy)   # [B,N,2]
+            u = MJ0 * jd[..., 0:1] + MJ1 * jd[..., 1:2]                                 # Jc^T M jd  [B,N,6]
+            s = M11 * jd[..., 0] ** 2 + 2.0 * M12 * jd[..., 0] * jd[..., 1] + M22 * jd[..., 1] ** 2      # jd^T M jd
+            r = jd[..., 0] * g1 + jd[..., 1] * g2                                       # jd^T g
+            Hcd = torch.matmul(u.transpose(1, 2), B)                                    # [B,6,K]
+            Hdd = torch.matmul(B.transpose(1, 2), B * s.unsqueeze(-1))                  # [B,K,K]
+            bd = torch.matmul(B.transpose(1, 2), r.unsqueeze(-1)).squeeze(-1)           # [B,K]
+            AtA = torch.cat([torch.cat([Hcc, Hcd], dim=2), torch.cat([Hcd.transpose(1, 2), Hdd], dim=2)], dim=1)
+            Atb = torch.cat([bc, bd], dim=1).unsqueeze(-1)
+        else:
+            AtA, Atb = Hcc, bc.unsqueeze(-1)
         diag = torch.diagonal(AtA, dim1=1, dim2=2)
         if bundle:
             damp = torch.cat([diag[:, :-1] + 1e-5, torch.zeros(nb, 1, device=diag.device)], dim=-1)   # :266

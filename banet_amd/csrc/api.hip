@@ -239,6 +239,28 @@ int banet_depth_output_f32(const float* init_depth, const float* basis, const fl
   return launch_depth_output(init_depth, basis, Wc, out, B, N, K, static_cast<hipStream_t>(stream));
 }
 
+int banet_sample_stats_blocks(int N) { return N > 0 ? sample_stats_blocks(N) : 0; }
+
+static bool sstats_shape_ok(int B, int N, int C, int H, int W) {
+  return B > 0 && N > 0 && C > 0 && H > 0 && W > 0 && (unsigned long long)B * H * W * 3ull * C < (1ull << 32);
+}
+
+int banet_sample_stats_f32(const float* conv1, const float* conv2, const float* px, const float* py, int B, int N, int C, int H,
+                           int W, float* stats, float* absd_part, banet_stream_t stream) {
+  if (!conv1 || !conv2 || !px || !py || !stats || !absd_part) return BANET_ERR_INVALID_ARG;
+  if (!sstats_shape_ok(B, N, C, H, W)) return BANET_ERR_INVALID_ARG;
+  return launch_sample_stats(conv1, conv2, px, py, B, N, C, H, W, stats, absd_part, static_cast<hipStream_t>(stream));
+}
+
+int banet_sample_stats_grad_f32(const float* conv1, const float* conv2, const float* px, const float* py, int B, int N, int C,
+                                int H, int W, const float* dstats, const float* dabs, float* dconv1, float* dconv2, float* dpos,
+                                banet_stream_t stream) {
+  if (!conv1 || !conv2 || !px || !py || !dstats || !dabs || !dconv1 || !dconv2 || !dpos) return BANET_ERR_INVALID_ARG;
+  if (!sstats_shape_ok(B, N, C, H, W)) return BANET_ERR_INVALID_ARG;
+  return launch_sample_stats_grad(conv1, conv2, px, py, B, N, C, H, W, dstats, dabs, dconv1, dconv2, dpos,
+                                  static_cast<hipStream_t>(stream));
+}
+
 int banet_profile_begin(int max_launches) { return profile_begin(max_launches); }
 
 int banet_profile_end(int max_tags, int32_t* tag_points, int32_t* tag_launches, double* tag_ms, int32_t* ntags) {

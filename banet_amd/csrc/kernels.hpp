@@ -118,4 +118,12 @@ size_t solve_big_bytes(int B, int P, int C);
 void launch_ctl_init(LmCtl* ctl, int32_t* iters, int B, hipStream_t s);
 void launch_zero_iters(int32_t* iters, int B, hipStream_t s);
 
+// ---- sstats.hip: per-pixel sampling statistics and their adjoint (differentiable layer support) ----
+int sample_stats_blocks(int N);
+int launch_sample_stats(const float* conv1, const float* conv2, const float* px, const float* py, int B, int N, int C, int H,
+                        int W, float* stats, float* absd_part, hipStream_t s);
+int launch_sample_stats_grad(const float* conv1, const float* conv2, const float* px, const float* py, int B, int N, int C,
+                             int H, int W, const float* dstats, const float* dabs, float* dconv1, float* dconv2, float* dpos,
+                             hipStream_t s);
+
 }  // namespace banet

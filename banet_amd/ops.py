@@ -290,3 +290,61 @@ def depth_output(init_depth, basis, Wc):
     capi.check(capi.lib().banet_depth_output_f32(capi.ptr(init), capi.ptr(basis), capi.ptr(Wc), capi.ptr(out), B, N, K,
                                                  capi.stream()))
     return out
+
+
+# --------------------------------------------------------------------------------------
+# differentiable layer support: per-pixel sampling statistics (sstats.hip)
+# --------------------------------------------------------------------------------------
+def sample_stats_forward(conv1, conv2, px, py):
+    """banet_sample_stats_f32 -> (stats [B,N,8] = (M11, M12, M22, g1, g2, mask, 0, 0), absd [B,C] = sum_n |d|)."""
+    conv1, conv2, px, py = capi.f32c(conv1), capi.f32c(conv2), capi.f32c(px), capi.f32c(py)
+    B, N, C = conv1.shape
+    H, W = conv2.shape[1], conv2.shape[2]
+    if conv2.shape[0] != B or conv2.shape[3] != 3 * C or tuple(px.shape) != (B, N) or tuple(py.shape) != (B, N):
+        raise capi.BanetError("sample_stats: expected conv1 [B,N,C], conv2 [B,H,W,3C], px / py [B,N]")
+    L = capi.lib()
+    G = L.banet_sample_stats_blocks(N)
+    stats = torch.empty((B, N, 8), dtype=torch.float32, device=conv1.device)
+    part = torch.empty((B, G, C), dtype=torch.float32, device=conv1.device)
+    capi.check(L.banet_sample_stats_f32(capi.ptr(conv1), capi.ptr(conv2), capi.ptr(px), capi.ptr(py), B, N, C, H, W,
+                                        capi.ptr(stats), capi.ptr(part), capi.stream()))
+    return stats, part.sum(dim=1)
+
+
+def sample_stats_grad(conv1, conv2, px, py, dstats, dabs):
+    """banet_sample_stats_grad_f32 -> (dconv1 [B,N,C], dconv2 [B,H,W,3C], dpos [B,N,2])."""
+    conv1, conv2, px, py = capi.f32c(conv1), capi.f32c(conv2), capi.f32c(px), capi.f32c(py)
+    dstats, dabs = capi.f32c(dstats), capi.f32c(dabs)
+    B, N, C = conv1.shape
+    H, W = conv2.shape[1], conv2.shape[2]
+    dconv1 = torch.empty_like(conv1)
+    dconv2 = torch.zeros_like(conv2)
+    dpos = torch.empty((B, N, 2), dtype=torch.float32, device=conv1.device)
+    capi.check(capi.lib().banet_sample_stats_grad_f32(capi.ptr(conv1), capi.ptr(conv2), capi.ptr(px), capi.ptr(py), B, N, C, H, W,
+                                                      capi.ptr(dstats), capi.ptr(dabs), capi.ptr(dconv1), capi.ptr(dconv2),
+                                                      capi.ptr(dpos), capi.stream()))
+    return dconv1, dconv2, dpos
+
+
+class _SampleStats(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, conv1, conv2, px, py):
+        ctx.save_for_backward(conv1, conv2, px, py)
+        stats, absd = sample_stats_forward(conv1, conv2, px, py)
+        ctx.mark_non_differentiable(stats[..., 5:])
+        return stats[..., :5], stats[..., 5], absd
+
+    @staticmethod
+    def backward(ctx, dstats5, _dmask, dabs):
+        conv1, conv2, px, py = ctx.saved_tensors
+        B, N, _ = conv1.shape
+        dstats = torch.zeros((B, N, 8), dtype=torch.float32, device=conv1.device)
+        dstats[..., :5] = dstats5
+        dconv1, dconv2, dpos = sample_stats_grad(conv1, conv2, px, py, dstats, dabs.contiguous())
+        return dconv1, dconv2, dpos[..., 0], dpos[..., 1]
+
+
+def sample_stats(conv1, conv2, px, py):
+    """Differentiable (M, g, mask, sum |d|) of bundlenet.py:230-243 without materialising samp / diff / grad:
+    returns (stats [B,N,5] = (M11, M12, M22, g1, g2), mask [B,N], absd [B,C])."""
+    return _SampleStats.apply(conv1, conv2, px, py)

@@ -31,7 +31,7 @@ extern "C" {
 typedef void* banet_stream_t; /* a hipStream_t (NULL = default stream) */
 #endif
 
-#define BANET_VERSION 110 /* 0.1.1: banet_level_t.pairs */
+#define BANET_VERSION 120 /* 0.1.2: banet_sample_stats[_grad]_f32 (0.1.1: banet_level_t.pairs) */
 
 enum {
   BANET_OK = 0,
@@ -188,7 +188,24 @@ int banet_target_map_f32(const float* img, float* out, int B, int H, int W, int 
 int banet_depth_output_f32(const float* init_depth, const float* basis, const float* Wc,
                            float* out, int B, int N, int K, banet_stream_t stream);
 
-/* (7) optional kernel timing, used by bench.py for the roofline figure.  Between
+/* (7) differentiable layer support -- the C-wide part of one BundleIteration / CameraIteration in the reference's
+ *     own tensor layout (bundlenet.py:230-243) and its adjoint (what TF autodiff derives from the same statements),
+ *     so that a training graph never materialises samp [B,N,3C], diff, grad or J [B,N,2,P]:
+ *   banet_sample_stats_f32      conv1 [B,N,C], conv2 [B,H,W,3C] = [f|gx|gy], px, py [B,N] ->
+ *       stats [B,N,8] = (M11, M12, M22, g1, g2, mask, 0, 0) with M = G^T G, g = G^T d,
+ *       d = (conv1 - samp_f) mask, G = [samp_gx, samp_gy] mask, mask = px in [0,W-1] and py in [0,H-1];
+ *       absd_part [B, banet_sample_stats_blocks(N), C] = per-block sums of |d| (add them in order for sum_n |d|)
+ *   banet_sample_stats_grad_f32 dstats [B,N,8] (first five used), dabs [B,C] = dL/d(sum_n |d|) ->
+ *       dconv1 [B,N,C], dconv2 [B,H,W,3C] (ACCUMULATED with float atomics: zero it first), dpos [B,N,2] = dL/d(px,py)
+ *     C <= 256, B H W 3C < 2^32.                                                                                   */
+int banet_sample_stats_blocks(int N);
+int banet_sample_stats_f32(const float* conv1, const float* conv2, const float* px, const float* py, int B, int N, int C,
+                           int H, int W, float* stats, float* absd_part, banet_stream_t stream);
+int banet_sample_stats_grad_f32(const float* conv1, const float* conv2, const float* px, const float* py, int B, int N,
+                                int C, int H, int W, const float* dstats, const float* dabs, float* dconv1,
+                                float* dconv2, float* dpos, banet_stream_t stream);
+
+/* (8) optional kernel timing, used by bench.py for the roofline figure.  Between
  *     banet_profile_begin and banet_profile_end every launch of the fused assembly kernel
  *     (from banet_ba_assemble_f32 / banet_lm_level_f32) is bracketed by two hipEvents recorded
  *     on its stream.  banet_profile_end synchronises those events and returns, per distinct

@@ -792,11 +792,13 @@ def _sparse_case(seed, B=2, H=24, W=32, C=6, K=5, N=300):
                 mlp=orc.he_normal_mlp_weights(C, 7))
 
 
-def test_training_graph_matches_fused_forward_and_finite_difference_gradients():
+@pytest.mark.parametrize("graph", ["lean", "reference"])
+def test_training_graph_matches_fused_forward_and_finite_difference_gradients(graph):
     from banet_amd.bundlenet import BundleNet
     c = _sparse_case(17)
     names = ["conv1", "conv2", "fx", "fy", "ox", "oy", "p", "D", "Bs", "R", "T", "W"]
     net = BundleNet(lambda_weights={"2": [(t(w), t(b)) for w, b in c["mlp"]]})
+    net.training_graph = graph
     args = {k: t(c[k]) for k in names}
     with torch.no_grad():
         Rf, Tf, Wf = net.BundleIteration(*[args[k] for k in names], 1000.0, "2")           # fused HIP path
@@ -823,6 +825,66 @@ def test_training_graph_matches_fused_forward_and_finite_difference_gradients():
         fd = (oracle_loss({k: c[k].astype(np.float64) + eps * v}) - oracle_loss({k: c[k].astype(np.float64) - eps * v})) / (2 * eps)
         ad = float((grads[k] * v).sum())
         assert abs(ad - fd) <= 3e-2 * max(abs(fd), abs(ad)) + 1e-6, (k, ad, fd)
+
+
+def test_lean_training_graph_equals_the_reference_style_graph():
+    """the two training graphs (ops.sample_stats + block-wise normal equations vs the reference's statements with the
+    EquationConstruction op) give the same outputs and the same gradients w.r.t. every input and the lambda-MLP weights;
+    pose-only iteration included"""
+    from banet_amd.bundlenet import BundleNet
+    c = _sparse_case(23)
+    names = ["conv1", "conv2", "fx", "fy", "ox", "oy", "p", "D", "Bs", "R", "T", "W"]
+    rng = np.random.RandomState(11)
+    res = {}
+    for graph in ("lean", "reference"):
+        lw = [(t(w).requires_grad_(True), t(b).requires_grad_(True)) for w, b in c["mlp"]]
+        net = BundleNet(lambda_weights={"2": lw})
+        net.training_graph = graph
+        leaves = {k: t(c[k]).requires_grad_(True) for k in ("conv1", "conv2", "D", "Bs", "R", "T", "W")}
+        call = [leaves[k] if k in leaves else t(c[k]) for k in names]
+        Ra, Ta, Wa = net.BundleIteration(*call, 1000.0, "2")
+        if graph == "lean":
+            cR, cT, cW = [t(rng.standard_normal(x.shape)) for x in (n(Ra), n(Ta), n(Wa))]
+        loss = (Ra * cR).sum() + (Ta * cT).sum() + (Wa * cW).sum()
+        params = list(leaves.values()) + [x for wb in lw for x in wb]
+        g = torch.autograd.grad(loss, params)
+        cam = [leaves[k] if k in leaves else t(c[k]) for k in names if k not in ("Bs", "W")]
+        Rc, Tc = net.CameraIteration(*cam, 1.0, "2")
+        gc = torch.autograd.grad((Rc * cR).sum() + (Tc * cT).sum(), [leaves[k] for k in ("conv1", "conv2", "D", "T")])
+        res[graph] = ([n(Ra), n(Ta), n(Wa), n(Rc), n(Tc)], [n(x) for x in g] + [n(x) for x in gc])
+    for a, b in zip(res["lean"][0], res["reference"][0]):
+        assert relerr(a, b) < 1e-4, relerr(a, b)                     # the parity tolerance on updates
+    for i, (a, b) in enumerate(zip(res["lean"][1], res["reference"][1])):
+        assert relerr(a, b) < 2e-3, (i, relerr(a, b))
+
+
+@pytest.mark.parametrize("B,N,C,H,W", [(2, 300, 128, 24, 32), (1, 77, 5, 9, 11), (2, 64, 200, 12, 16)])
+def test_sample_stats_op_matches_the_torch_statements(B, N, C, H, W):
+    """ops.sample_stats (HIP forward + adjoint) against bundlenet.py:230-243 written with differentiable torch ops:
+    values, and gradients w.r.t. conv1, conv2 and the sampling positions; points on the rim, outside, and on integer
+    coordinates included"""
+    from banet_amd import ops
+    from banet_amd.bundlenet import _resampler_autograd
+    rng = np.random.RandomState(N + C)
+    conv1 = t(rng.standard_normal((B, N, C))).requires_grad_(True)
+    conv2 = t(rng.standard_normal((B, H, W, 3 * C))).requires_grad_(True)
+    pos = rng.uniform(-1.5, 1.5, (B, N, 2)) + rng.uniform(0, 1, (B, N, 2)) * np.array([W - 1, H - 1])
+    pos[:, :6] = np.array([[0.0, 0.0], [W - 1.0, H - 1.0], [3.0, 2.0], [W - 1.0, 1.5], [0.25, H - 1.0], [-0.5, 3.0]])
+    px, py = t(pos[..., 0]).requires_grad_(True), t(pos[..., 1]).requires_grad_(True)
+    cs, ca = t(rng.standard_normal((B, N, 5))), t(rng.standard_normal((B, C)))
+    stats, mask, absd = ops.sample_stats(conv1, conv2, px, py)
+    g_hip = torch.autograd.grad((stats * cs).sum() + (absd * ca).sum(), [conv1, conv2, px, py])
+    samp = _resampler_autograd(conv2, torch.stack([px, py], dim=-1))
+    m = (~((px < 0) | (px > float(W - 1)) | (py < 0) | (py > float(H - 1)))).to(torch.float32)
+    d = (conv1 - samp[..., :C]) * m[..., None]
+    gx, gy = samp[..., C:2 * C] * m[..., None], samp[..., 2 * C:] * m[..., None]
+    ref = torch.stack([(gx * gx).sum(-1), (gx * gy).sum(-1), (gy * gy).sum(-1), (gx * d).sum(-1), (gy * d).sum(-1)], dim=-1)
+    ref_abs = d.abs().sum(dim=1)
+    g_ref = torch.autograd.grad((ref * cs).sum() + (ref_abs * ca).sum(), [conv1, conv2, px, py])
+    assert torch.equal(mask, m)
+    assert relerr(n(stats), n(ref)) < 1e-5 and relerr(n(absd), n(ref_abs)) < 1e-5
+    for a, b in zip(g_hip, g_ref):
+        assert relerr(n(a), n(b)) < 1e-4, relerr(n(a), n(b))
 
 
 def test_solve_is_hip_graph_capturable():
