@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Extra seeds for the randomized parity tests (tests/test_gpu_parity.py::test_random_shape_sweep_assembly_matches_oracle and
+the wide-basis / patch-kernel cases with random shapes): python tools/fuzz_parity.py [first_seed] [count]"""
+import os, sys, traceback
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import test_gpu_parity as T  # noqa: E402
+
+first, count = int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 40
+bad = 0
+for seed in range(first, first + count):
+    try:
+        T.test_random_shape_sweep_assembly_matches_oracle(seed)
+    except Exception:
+        bad += 1
+        print("seed", seed, "FAILED")
+        traceback.print_exc(limit=2)
+print("random shape sweep: %d seeds, %d failures" % (count, bad))
+import numpy as np  # noqa: E402
+rng = np.random.RandomState(first)
+cases_wide = [(128, int(rng.choice([128, 256])), int(rng.randint(1, 8))) for _ in range(max(2, count // 6))]
+cases_wide = [(c, k, p if k == 256 else max(p, 5)) for c, k, p in cases_wide]          # K = 128 takes the job kernels with > 4 frames
+for c in cases_wide:
+    try:
+        T.test_large_basis_windows_match_oracle(*c)
+    except Exception:
+        bad += 1
+        print("wide SYRK case", c, "FAILED")
+        traceback.print_exc(limit=2)
+cases_patch = [(int(rng.randint(16, 72)), int(rng.randint(16, 100)), int(rng.choice([0, 4, 32, 128])), bool(rng.randint(2)),
+                int(rng.randint(1, 4))) for _ in range(max(2, count // 6))]
+for c in cases_patch:
+    try:
+        T.test_patch_gather_kernel_matches_oracle(*c)
+    except Exception:
+        bad += 1
+        print("patch gather case", c, "FAILED")
+        traceback.print_exc(limit=2)
+print("wide SYRK cases %s, patch gather cases %s: %d failures in all" % (cases_wide, cases_patch, bad))
+sys.exit(1 if bad else 0)
