@@ -10,6 +10,8 @@
 //      v_mfma_f32_16x16x4_f32, upper-triangular 16x16 blocks only, accumulators in registers
 //   D  Atb += J_n^T g_n, lane = column
 // Partials are reduced in fixed order by ba_reduce_kernel (assemble.hip).
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 namespace banet {
@@ -338,9 +340,21 @@ int plan_eq(int B, int N, int C, int P, EqPlan* pl) {
   int G = pl->tiles / 2;
   if (G > target) G = target;
   if (G < 1) G = 1;
+  // P <= 144: the SYRK formulation (eqcon_syrk.hip), one workgroup per CU, >= 1 step of 16 pixels per wave
+  // (environment BANET_EQ_LDS_KERNEL=1 keeps the LDS-operand kernel: development A/B only)
+  static const bool force_lds = getenv("BANET_EQ_LDS_KERNEL") != nullptr && atoi(getenv("BANET_EQ_LDS_KERNEL")) != 0;
+  pl->fast = (pl->nb <= 9 && !force_lds) ? 1 : 0;
+  if (pl->fast) {
+    G = (256 + B - 1) / B;
+    const int steps = (N + 15) / 16;
+    if (G > (steps + 3) / 4) G = (steps + 3) / 4;
+    if (G < 1) G = 1;
+  }
   pl->Gr = G;
   pl->pstride = (int)align_up((size_t)P * P + P, 4);
   pl->partial_bytes = align_up((size_t)B * G * pl->pstride * sizeof(float), 256);
+  pl->off_rec = pl->partial_bytes;
+  if (pl->fast) pl->partial_bytes += eq_syrk_record_bytes(B, N);
   return BANET_OK;
 }
 
@@ -354,6 +368,13 @@ static void launch_eq_nb(const EqArgs& a, hipStream_t s) {
 
 int launch_eq(const float* J, const float* G, const float* d, float* AtA, float* Atb, int B, int N, int C, int P,
               const EqPlan& pl, float* partials, hipStream_t s) {
+  if (pl.fast) {
+    const int rc = launch_eq_syrk(J, G, d, B, N, C, P, pl.nb, pl.Gr, pl.pstride, partials,
+                                  reinterpret_cast<float*>(reinterpret_cast<char*>(partials) + pl.off_rec), s);
+    if (rc != BANET_OK) return rc;
+    launch_reduce(partials, B, pl.Gr, pl.pstride, P, AtA, Atb, s);
+    return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;
+  }
   EqArgs a{J, G, d, partials, B, N, C, P, pl.Gr, pl.tiles, pl.pstride};
   switch (pl.nb) {
     case 1: launch_eq_nb<1>(a, s); break;

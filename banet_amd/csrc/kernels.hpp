@@ -77,8 +77,13 @@ int launch_depth_output(const float* init, const float* basis, const float* Wc, 
 void launch_reduce(const float* partials, int B, int G, int pstride, int P, float* AtA, float* Atb, hipStream_t s);
 struct EqPlan {
   int Gr, tiles, pstride, nb;
+  int fast;            // 1: eqcon_syrk.hip (P <= 144): per-pixel records + W^T W on the bf16 pipe
+  size_t off_rec;      // fast: the records [B][N][8] inside the workspace
   size_t partial_bytes;
 };
+size_t eq_syrk_record_bytes(int B, int N);
+int launch_eq_syrk(const float* J, const float* G, const float* d, int B, int N, int C, int P, int nb, int Gr, int pstride,
+                   float* partials, float* rec, hipStream_t s);
 int plan_eq(int B, int N, int C, int P, EqPlan* pl);
 int launch_eq(const float* J, const float* G, const float* d, float* AtA, float* Atb, int B, int N, int C, int P,
               const EqPlan& pl, float* partials, hipStream_t s);
