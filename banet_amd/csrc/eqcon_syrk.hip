@@ -32,7 +32,7 @@ __device__ __forceinline__ f32x4 mm6e(const u32x4_t (&x)[3], const u32x4_t (&y)[
 
 // ---- per-pixel records -----------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void eq_pixel_records_kernel(const float* __restrict__ G, const float* __restrict__ d, int N,
-                                                                  int C, float* __restrict__ rec) {
+                                                                  int C, int raw, float* __restrict__ rec) {
   const int b = blockIdx.y, lane = threadIdx.x & 63, w = wave_id();
   const int pt0 = blockIdx.x * 32, npx = min(32, N - pt0);
   const bool vec2 = (C & 1) == 0;
@@ -90,8 +90,13 @@ __global__ __launch_bounds__(kBlock) void eq_pixel_records_kernel(const float* _
       const float h0 = q.g1 * i11;
       const float h1 = (q.g2 - l21 * h0) * i22;
       float4* o = reinterpret_cast<float4*>(rec + ((size_t)b * N + pt0 + n) * 8);
-      o[0] = make_float4(l11, l21, l22, h0);
-      o[1] = make_float4(h1, 0.f, 0.f, 0.f);
+      if (raw) {   // EquationConstructionGrad wants M and g themselves (eqcon_grad.hip)
+        o[0] = make_float4(q.m11, q.m12, q.m22, q.g1);
+        o[1] = make_float4(q.g2, 0.f, 0.f, 0.f);
+      } else {
+        o[0] = make_float4(l11, l21, l22, h0);
+        o[1] = make_float4(h1, 0.f, 0.f, 0.f);
+      }
     }
   }
 }
@@ -233,11 +238,15 @@ __global__ __launch_bounds__(kBlock, 1) void eq_syrk_kernel(const EqSyrkArgs a) 
   }
 }
 
+void launch_eq_pixel_records(const float* G, const float* d, int B, int N, int C, int raw, float* rec, hipStream_t s) {
+  hipLaunchKernelGGL(eq_pixel_records_kernel, dim3((N + 31) / 32, B), dim3(kBlock), 0, s, G, d, N, C, raw, rec);
+}
+
 size_t eq_syrk_record_bytes(int B, int N) { return align_up((size_t)B * N * 8 * sizeof(float), 256); }
 
 int launch_eq_syrk(const float* J, const float* G, const float* d, int B, int N, int C, int P, int nb, int Gr, int pstride,
                    float* partials, float* rec, hipStream_t s) {
-  hipLaunchKernelGGL(eq_pixel_records_kernel, dim3((N + 31) / 32, B), dim3(kBlock), 0, s, G, d, N, C, rec);
+  launch_eq_pixel_records(G, d, B, N, C, 0, rec, s);
   const EqSyrkArgs a{J, rec, partials, N, P, Gr, pstride};
   const dim3 grid(Gr, B), block(kBlock);
   switch (nb) {

@@ -87,6 +87,9 @@ int launch_eq_syrk(const float* J, const float* G, const float* d, int B, int N,
 int plan_eq(int B, int N, int C, int P, EqPlan* pl);
 int launch_eq(const float* J, const float* G, const float* d, float* AtA, float* Atb, int B, int N, int C, int P,
               const EqPlan& pl, float* partials, hipStream_t s);
+size_t eq_grad_fast_ws_bytes(int B, int N, int P);   // eqcon_grad.hip: 0 = no fast path for this shape
+int launch_eq_grad_fast(const float* J, const float* G, const float* d, const float* g0, const float* g1, float* gJ, float* gG,
+                        float* gd, int B, int N, int C, int P, void* ws, hipStream_t s);
 int launch_eq_grad(const float* J, const float* G, const float* d, const float* g0, const float* g1, float* gJ,
                    float* gG, float* gd, int B, int N, int C, int P, hipStream_t s);
 

@@ -48,8 +48,11 @@ def equation_construction_grad(jacobian, gradient, difference, left_grad, right_
     B, N, C, P = _eq_shapes(J, G, d)
     L = capi.lib()
     gJ, gG, gd = torch.empty_like(J), torch.empty_like(G), torch.empty_like(d)
+    nb = L.banet_equation_construction_grad_workspace_bytes(B, N, C, P)      # 0: no workspace needed for this shape
+    ws = capi.workspace(nb, J.device) if nb else None
     capi.check(L.banet_equation_construction_grad_f32(capi.ptr(J), capi.ptr(G), capi.ptr(d), capi.ptr(g0), capi.ptr(g1),
-                                                      capi.ptr(gJ), capi.ptr(gG), capi.ptr(gd), B, N, C, P, None, 0,
+                                                      capi.ptr(gJ), capi.ptr(gG), capi.ptr(gd), B, N, C, P,
+                                                      ctypes.c_void_p(ws.data_ptr()) if nb else None, ws.numel() if nb else 0,
                                                       capi.stream()))
     return gJ, gG, gd
 

@@ -64,7 +64,10 @@ int banet_equation_construction_f32(const float* jacobian, const float* gradient
  *       left_grad g0 [B,P,P], right_grad g1 [B,P,1]
  *       A_n = G_n J_n ; dA_n = 2 A_n g0 + d_n g1^T   (alpha = 2.0 as utils.cu:651)
  *       jacobian_grad = G^T dA [B,N,2,P]; gradient_grad = dA J^T [B,N,C,2];
- *       difference_grad = A g1 [B,N,C,1]                                                 */
+ *       difference_grad = A g1 [B,N,C,1]
+ *     Workspace: optional.  With ws_bytes >= banet_equation_construction_grad_workspace_bytes (P <= 144, 256-byte
+ *     aligned) the matrix-pipe kernels run; with ws = NULL (or for shapes whose size is 0) the first-generation
+ *     kernel, same results to rounding.                                                   */
 size_t banet_equation_construction_grad_workspace_bytes(int B, int N, int C, int P);
 int banet_equation_construction_grad_f32(const float* jacobian, const float* gradient,
                                          const float* difference, const float* left_grad,
