@@ -100,6 +100,16 @@ def test_equation_construction_grad_matches_oracle(B, N, C, P):
     for got, want in ((gJ, rJ), (gG, rG), (gd, rd)):
         assert got.shape == want.shape
         assert relerr(n(got), want) < 3e-5, relerr(n(got), want)
+    # without a workspace the entry point runs the first-generation kernel: same results
+    import ctypes
+    from banet_amd import _capi as capi
+    Jc, Gc, dc, g0c, g1c = (t(x).contiguous() for x in (J, G, d, g0, g1))
+    oJ, oG, od = torch.empty_like(Jc), torch.empty_like(Gc), torch.empty_like(dc)
+    capi.check(capi.lib().banet_equation_construction_grad_f32(capi.ptr(Jc), capi.ptr(Gc), capi.ptr(dc), capi.ptr(g0c), capi.ptr(g1c),
+                                                               capi.ptr(oJ), capi.ptr(oG), capi.ptr(od), B, N, C, P, None, 0,
+                                                               capi.stream()))
+    for got, want in ((oJ, rJ), (oG, rG), (od, rd)):
+        assert relerr(n(got), want) < 3e-5, relerr(n(got), want)
     # and the autograd pairing of bundlenet.py:79-82
     Jt, Gt, dt_ = t(J).requires_grad_(), t(G).requires_grad_(), t(d).requires_grad_()
     AtA, Atb = ops.equation_construction(Jt, Gt, dt_)
