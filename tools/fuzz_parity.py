@@ -38,5 +38,25 @@ for c in cases_patch:
         bad += 1
         print("patch gather case", c, "FAILED")
         traceback.print_exc(limit=2)
-print("wide SYRK cases %s, patch gather cases %s: %d failures in all" % (cases_wide, cases_patch, bad))
+print("wide SYRK cases %s, patch gather cases %s: %d failures so far" % (cases_wide, cases_patch, bad))
+cases_eq = [(int(rng.randint(1, 4)), int(rng.randint(1, 700)), int(rng.choice([1, 3, 8, 64, 128, 200])), int(rng.choice([6, 7, 12, 38, 70, 134, 143, 144, 145, 160])))
+            for _ in range(max(4, count // 4))]
+for c in cases_eq:
+    for fn in (T.test_equation_construction_matches_oracle, T.test_equation_construction_grad_matches_oracle):
+        try:
+            fn(*c)
+        except Exception:
+            bad += 1
+            print("EquationConstruction case", c, fn.__name__, "FAILED")
+            traceback.print_exc(limit=2)
+cases_ss = [(int(rng.randint(1, 3)), int(rng.randint(8, 400)), int(rng.choice([1, 5, 64, 128, 256])), int(rng.randint(4, 30)), int(rng.randint(4, 40)))
+            for _ in range(max(4, count // 6))]
+for c in cases_ss:
+    try:
+        T.test_sample_stats_op_matches_the_torch_statements(*c)
+    except Exception:
+        bad += 1
+        print("sample_stats case", c, "FAILED")
+        traceback.print_exc(limit=2)
+print("EquationConstruction cases %s, sample_stats cases %s: %d failures in all" % (cases_eq, cases_ss, bad))
 sys.exit(1 if bad else 0)
