@@ -34,6 +34,33 @@ def valid_point_and_depth(image, depth, num_points, thres, rng):
     return np.reshape(p[pick, :], (1, num_points, 2)), np.reshape(d[pick], (1, num_points, 1)).astype(np.float32)
 
 
+def rotation_to_quaternion_xyzw(R):
+    """Unit quaternion (x, y, z, w), w >= 0, of a 3x3 rotation matrix (float64, Shepperd's branch on the largest of
+    trace / diagonal entries) -- what seq_example.py:176 obtains from quaternion.from_rotation_matrix for its TUM line
+    (q and -q denote the same rotation; the sign is fixed here by w >= 0)."""
+    m = np.asarray(R, dtype=np.float64).reshape(3, 3)
+    t = np.trace(m)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2.0
+        q = np.array([(m[2, 1] - m[1, 2]) / s, (m[0, 2] - m[2, 0]) / s, (m[1, 0] - m[0, 1]) / s, 0.25 * s])
+    else:
+        i = int(np.argmax(np.diag(m)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(1.0 + m[i, i] - m[j, j] - m[k, k]) * 2.0
+        q = np.zeros(4)
+        q[i] = 0.25 * s
+        q[j] = (m[j, i] + m[i, j]) / s
+        q[k] = (m[k, i] + m[i, k]) / s
+        q[3] = (m[k, j] - m[j, k]) / s
+    q /= np.linalg.norm(q)
+    return q if q[3] >= 0 else -q
+
+
+def tum_line(stamp, camera, quaternion_xyzw):
+    """'timestamp tx ty tz qx qy qz qw' -- the trajectory line seq_example.py:177 prints (TUM RGB-D format)."""
+    return " ".join(repr(float(v)) for v in (stamp,) + tuple(camera) + tuple(quaternion_xyzw))
+
+
 class KeyframeTracker:
     """State machine of legacy/seq_example.py:150-208.  `track` returns the frame's global pose
     (rotation, translation as the reference chains them), camera centre and whether the frame became
@@ -80,6 +107,7 @@ class KeyframeTracker:
         self.globalRotations.append(gR)
         self.globalTranslations.append(gT)
         camera = -torch.matmul(gR.transpose(1, 2).double(), gT.double()).flatten()                   # :174-175
+        quat = rotation_to_quaternion_xyzw(gR.transpose(1, 2).double()[0].cpu().numpy())             # :176
         switched = keep_ratio < self.min_keep_ratio or (float(stamp) - self.key_stamp) > self.max_gap   # :191
         if switched:
             self.keyframeIndex = self.frameIndex
@@ -89,5 +117,6 @@ class KeyframeTracker:
         else:
             self.initR, self.initT = rotation, translation
         return dict(rotation=rotation, translation=translation, keep_ratio=keep_ratio, globalRotation=gR,
-                    globalTranslation=gT, camera=camera, new_keyframe=switched, iters=[int(c[0]) for c in
+                    globalTranslation=gT, camera=camera, quaternion=quat,
+                    tum=tum_line(stamp, camera.cpu().numpy(), quat), new_keyframe=switched, iters=[int(c[0]) for c in
                                                                                          self.tracker.level_iters_run])

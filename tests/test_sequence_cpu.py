@@ -63,3 +63,25 @@ def test_lambda_weight_import_round_trip(tmp_path):
     del var["lambda_3_4_biases"]
     with pytest.raises(KeyError):
         bn.lambda_weights_from_variables(var)
+
+
+def test_rotation_to_quaternion_and_tum_line():
+    """the TUM trajectory line of seq_example.py:174-177: camera centre + quaternion (x, y, z, w) of the transposed global rotation"""
+    import numpy as np
+    from banet_amd import sequence as seq
+    from oracle import synth
+    rng = np.random.RandomState(3)
+    for _ in range(50):
+        w = rng.uniform(-1, 1, 3) * rng.choice([1e-4, 0.3, 3.0])
+        R = synth.rodrigues(w).astype(np.float64)
+        x, y, z, ww = seq.rotation_to_quaternion_xyzw(R)
+        assert abs(x * x + y * y + z * z + ww * ww - 1) < 1e-12 and ww >= 0
+        Rq = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * ww), 2 * (x * z + y * ww)],
+                       [2 * (x * y + z * ww), 1 - 2 * (x * x + z * z), 2 * (y * z - x * ww)],
+                       [2 * (x * z - y * ww), 2 * (y * z + x * ww), 1 - 2 * (x * x + y * y)]])
+        assert np.abs(Rq - R).max() < 1e-6
+    R180 = np.diag([1.0, -1.0, -1.0])                                   # trace = -1: the diagonal branch
+    q = seq.rotation_to_quaternion_xyzw(R180)
+    assert np.allclose(np.abs(q), [1, 0, 0, 0], atol=1e-12)
+    line = seq.tum_line(1305031102.175304, [0.1, -0.2, 0.3], [0.0, 0.0, 0.0, 1.0])
+    assert line.split() == ["1305031102.175304", "0.1", "-0.2", "0.3", "0.0", "0.0", "0.0", "1.0"]
