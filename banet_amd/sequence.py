@@ -34,6 +34,59 @@ def valid_point_and_depth(image, depth, num_points, thres, rng):
     return np.reshape(p[pick, :], (1, num_points, 2)), np.reshape(d[pick], (1, num_points, 1)).astype(np.float32)
 
 
+def valid_point_and_depth2(image1, image2, depth1, depth2, rotation, translation, intrinsics, num_points, rng,
+                           grad_thres=80.0, color_thres=64.0, depth_tol=0.2):
+    """legacy/eval.py:102-147: BA points for a frame pair with known relative pose -- strong gradient and valid depth in
+    frame 1, and consistent with frame 2 under the ground-truth motion: the projection falls inside the image, the
+    colours differ by less than `color_thres`, the depths agree within `depth_tol` (relative).  Vectorised; the reference's
+    double loop visits the pixels in the same row-major order, so the candidate list is identical.  As there, the
+    gradient test uses the x-derivative twice (:109-110) and positions are truncated with int().  Sampled with
+    replacement -> points [1,num,2] (x,y) float32, depths [1,num,1]."""
+    H, W = depth1.shape
+    fx, fy, ox, oy = [float(v) for v in np.asarray(intrinsics).flatten()[:4]]
+    dx = sobel_x(image1)
+    dxy = np.sqrt(2.0 * np.sum(np.square(dx), axis=-1))
+    jj, ii = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    d1 = depth1.astype(np.float64)
+    ray = np.stack([(jj - ox) / fx, (ii - oy) / fy, np.ones_like(jj)], axis=-1) * d1[..., None]
+    X = ray @ np.asarray(rotation, dtype=np.float64).reshape(3, 3).T + np.asarray(translation, dtype=np.float64).reshape(3)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        px = X[..., 0] / X[..., 2] * fx + ox
+        py = X[..., 1] / X[..., 2] * fy + oy
+    ok = (depth1 >= 1e-5) & (dxy >= grad_thres) & np.isfinite(px) & np.isfinite(py)
+    pxi = np.where(ok, px, 0.0).astype(np.int64)                      # int(): truncation toward zero, like the reference
+    pyi = np.where(ok, py, 0.0).astype(np.int64)
+    ok &= (pyi >= 0) & (pyi < H) & (pxi >= 0) & (pxi < W)
+    pxi, pyi = np.clip(pxi, 0, W - 1), np.clip(pyi, 0, H - 1)
+    c2 = image2.astype(np.float32)[pyi, pxi]
+    ok &= np.linalg.norm(image1.astype(np.float32) - c2, axis=-1) <= color_thres
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ok &= np.abs(X[..., 2] - depth2[pyi, pxi]) / X[..., 2] <= depth_tol
+    idx = np.flatnonzero(ok.flatten())                                  # row-major = the reference's loop order
+    pts = np.stack([idx % W, idx // W], axis=-1).astype(np.float32)
+    dep = depth1.flatten()[idx].astype(np.float32)
+    pick = rng.randint(0, idx.size, num_points)
+    return pts[pick].reshape(1, num_points, 2), dep[pick].reshape(1, num_points, 1)
+
+
+def pose_errors(rotation, translation, rotation_gt, translation_gt):
+    """legacy/eval.py:225-234 (and example.py:112-121): rotation error in degrees from the quaternion dot product (the
+    reference's `2*180*arccos(.)/3.14`, with its 3.14), the predicted rotation angle, the translation error norm and the
+    predicted translation norm."""
+    def quat_wxyz(R):   # eval.py:25-34 rotation2quaternion3D
+        R = np.asarray(R, dtype=np.float64).reshape(3, 3)
+        q0 = np.sqrt(1.0 + R[0, 0] + R[1, 1] + R[2, 2]) / 2.0
+        q = np.array([q0, (R[2, 1] - R[1, 2]) / (4.0 * q0), (R[0, 2] - R[2, 0]) / (4.0 * q0), (R[1, 0] - R[0, 1]) / (4.0 * q0)])
+        return q / np.linalg.norm(q)
+    qp = quat_wxyz(rotation)
+    x, y, z, w = rotation_to_quaternion_xyzw(rotation_gt)
+    qg = np.array([w, x, y, z])                                          # w >= 0 as eval.py:222-223 enforces
+    tp, tg = np.asarray(translation, dtype=np.float64).flatten(), np.asarray(translation_gt, dtype=np.float64).flatten()
+    return dict(rotation_error_deg=2 * 180 * np.arccos(np.clip(np.dot(qg, qp), -1.0, 1.0)) / 3.14,
+                rotation_deg=2 * 180 * np.arccos(np.clip(qp[0], -1.0, 1.0)) / 3.14,
+                translation_error=float(np.linalg.norm(tg - tp)), translation_norm=float(np.linalg.norm(tp)))
+
+
 def rotation_to_quaternion_xyzw(R):
     """Unit quaternion (x, y, z, w), w >= 0, of a 3x3 rotation matrix (float64, Shepperd's branch on the largest of
     trace / diagonal entries) -- what seq_example.py:176 obtains from quaternion.from_rotation_matrix for its TUM line

@@ -85,3 +85,59 @@ def test_rotation_to_quaternion_and_tum_line():
     assert np.allclose(np.abs(q), [1, 0, 0, 0], atol=1e-12)
     line = seq.tum_line(1305031102.175304, [0.1, -0.2, 0.3], [0.0, 0.0, 0.0, 1.0])
     assert line.split() == ["1305031102.175304", "0.1", "-0.2", "0.3", "0.0", "0.0", "0.0", "1.0"]
+
+
+def test_gt_consistent_point_selection_and_pose_errors():
+    """legacy/eval.py:102-147 (vectorised here) against a direct restatement of the reference's double loop, and the
+    error metrics of eval.py:225-234"""
+    import numpy as np
+    from banet_amd import sequence as seq
+    from oracle import synth
+    rng = np.random.RandomState(4)
+    H, W = 24, 32
+    K = np.array([[30.0, 30.0, W / 2.0, H / 2.0]])
+    jj = np.arange(W, dtype=np.float32)[None, :, None] + np.zeros((H, 1, 3), np.float32)
+    img1 = (128 + 100 * np.sin(0.25 * jj + np.array([0.0, 0.7, 1.9], np.float32))).astype(np.float32)   # smooth, strong x-gradients
+    img1 += rng.rand(H, W, 3).astype(np.float32) * 4
+    img2 = img1 + rng.randn(H, W, 3).astype(np.float32) * 30 * (rng.rand(H, W, 1) < 0.3)   # some pixels fail the colour test
+    d1 = (1.5 + rng.rand(H, W)).astype(np.float32)
+    d1[rng.rand(H, W) < 0.1] = 0.0
+    d2 = (2.0 + 0.0 * d1) * (1 + 0.12 * rng.randn(H, W)).astype(np.float32)            # some fail the depth test
+    R = synth.rodrigues(np.array([0.01, -0.02, 0.015])).astype(np.float64)
+    t = np.array([0.02, -0.01, 0.03])
+
+    def reference_loop():                                                   # eval.py:112-141 statement by statement
+        dx = seq.sobel_x(img1)
+        dxy = np.sqrt(np.sum(np.square(dx), axis=-1) + np.sum(np.square(dx), axis=-1))
+        pts, deps = [], []
+        k = K.flatten()
+        for i in range(H):
+            for j in range(W):
+                if d1[i, j] < 1e-5 or dxy[i, j] < 80:
+                    continue
+                px, py = (j - k[2]) / k[0], (i - k[3]) / k[1]
+                rot = np.matmul(R, d1[i, j] * np.reshape(np.asarray([px, py, 1.0]), [3, 1])).flatten() + t
+                px, py = rot[0] / rot[2] * k[0] + k[2], rot[1] / rot[2] * k[1] + k[3]
+                if int(py) < 0 or int(py) >= H or int(px) < 0 or int(px) >= W:
+                    continue
+                if np.linalg.norm(img1[i, j, :] - img2[int(py), int(px), :]) > 64:
+                    continue
+                if abs(rot[2] - d2[int(py), int(px)]) / rot[2] > 0.2:
+                    continue
+                pts.append([j, i])
+                deps.append(d1[i, j])
+        return np.asarray(pts, np.float32), np.asarray(deps, np.float32)
+
+    want_p, want_d = reference_loop()
+    assert 20 < len(want_p) < H * W
+    num = 64
+    got_p, got_d = seq.valid_point_and_depth2(img1, img2, d1, d2, R, t, K, num, np.random.RandomState(9))
+    pick = np.random.RandomState(9).randint(0, len(want_p), num)
+    np.testing.assert_array_equal(got_p[0], want_p[pick])
+    np.testing.assert_array_equal(got_d[0, :, 0], want_d[pick])
+    e = seq.pose_errors(R, t, R, t)
+    assert e["rotation_error_deg"] < 1e-3 and e["translation_error"] == 0.0
+    R2 = synth.rodrigues(np.array([0.0, 0.0, 0.1])).astype(np.float64)
+    e = seq.pose_errors(R2, t, np.eye(3), t * 0)
+    assert abs(e["rotation_error_deg"] - 0.1 * 180 / 3.14) < 1e-6 and abs(e["rotation_deg"] - 0.1 * 180 / 3.14) < 1e-6
+    assert abs(e["translation_error"] - np.linalg.norm(t)) < 1e-12
