@@ -773,6 +773,12 @@ def test_keyframe_sequence_driver_matches_oracle():
         assert relerr(n(g["globalTranslation"]), w["globalTranslation"]) < 1e-4
         assert abs(g["keep_ratio"] - w["keep_ratio"]) < 1e-5
         assert np.abs(n(g["camera"]) - w["camera"]).max() < 1e-4 * max(1.0, np.abs(w["camera"]).max())
+        x, y, z, qw = g["quaternion"]                                   # TUM line: quaternion of the transposed global rotation
+        Rq = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * qw), 2 * (x * z + y * qw)],
+                       [2 * (x * y + z * qw), 1 - 2 * (x * x + z * z), 2 * (y * z - x * qw)],
+                       [2 * (x * z - y * qw), 2 * (y * z + x * qw), 1 - 2 * (x * x + y * y)]])
+        assert np.abs(Rq - n(g["globalRotation"])[0].T).max() < 1e-5
+        assert len(g["tum"].split()) == 8 and abs(float(g["tum"].split()[1]) - float(n(g["camera"])[0])) < 1e-12
     # the tracker recovers the motion (frame 1 vs key frame 0; legacy z-depth convention)
     R1 = synth.rodrigues(np.asarray(poses[1][0], np.float64))
     assert np.abs(n(got[0]["rotation"])[0] - R1).max() < 2e-3
