@@ -19,11 +19,18 @@ import torch
 from . import ops
 
 __all__ = ["rotation2quaternion", "AngleaAxisRotation", "VMatrix", "CameraJacobianMatrix", "DepthJacobianMatrix",
-           "equation_construction", "equation_construction_grad", "resampler", "BundleNet",
+           "equation_construction", "equation_construction_grad", "equation_construction_gradient", "resampler", "BundleNet",
            "lambda_weights_from_variables", "lambda_weights_to_variables"]
 
 equation_construction = ops.equation_construction            # bundlenet.py:77
 equation_construction_grad = ops.equation_construction_grad  # bundlenet.py:78
+
+
+def equation_construction_gradient(inputs, left_grad, right_grad):
+    """bundlenet.py:79-82, the function the reference registers with @ops.RegisterGradient("EquationConstruction"):
+    `inputs` = the op's (jacobian, gradient, difference) -> their gradients.  (Registered here through
+    torch.autograd / torch.library in banet_amd/ops.py.)"""
+    return ops.equation_construction_grad(inputs[0], inputs[1], inputs[2], left_grad, right_grad)
 
 
 def rotation2quaternion(R, name=None):

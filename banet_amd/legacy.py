@@ -49,6 +49,34 @@ class Tracker:
         y = ((points2d[:, :, 1] - oy) / fy).unsqueeze(1)
         return torch.cat([x, y, torch.ones_like(x)], dim=1)
 
+    def CameraJacobianMatrix(self, x, y, Z, fx, fy, name=None):
+        """legacy/ba.py:36-48 -> [B,N,2,6]: the same entries as bundlenet.py:49-61 WITHOUT its leading minus."""
+        from . import bundlenet
+        return -bundlenet.CameraJacobianMatrix(x, y, Z, fx, fy)
+
+    def VMatrix(self, wx, wy, wz, name=None):
+        """legacy/ba.py:51-58 (applied per item; the reference's stack-on-axis-0 form is only correct for B = 1)."""
+        from . import bundlenet
+        return bundlenet.VMatrix(wx, wy, wz)
+
+    def AngleaAxisRotation(self, wx, wy, wz, name=None):
+        """legacy/ba.py:60-80: Rodrigues' formula, dividing by theta unguarded (NaN for a zero rotation, as in the
+        reference; the fused kernels return the identity there)."""
+        ones = torch.ones_like(wx)
+        theta = torch.sqrt(wx * wx + wy * wy + wz * wz)
+        wx, wy, wz = wx / theta, wy / theta, wz / theta
+        c, s = torch.cos(theta), torch.sin(theta)
+        m = torch.stack([c + wx * wx * (ones - c), wz * s + wx * wy * (ones - c), -wy * s + wx * wz * (ones - c),
+                         wx * wy * (ones - c) - wz * s, c + wy * wy * (ones - c), wx * s + wy * wz * (ones - c),
+                         wy * s + wx * wz * (ones - c), -wx * s + wy * wz * (ones - c), c + wz * wz * (ones - c)], dim=-1)
+        return m.reshape(-1, 3, 3).transpose(1, 2)
+
+    def conv1d(self, x, num_out_layers, name, activation=torch.nn.functional.elu):
+        """legacy/ba.py conv1d (k = 1): `name` = lambda_<level>_<i>, weights from self.lambda_weights[level]."""
+        _, level, i = name.split("_")
+        w, b = self.lambda_weights[level][int(i) - 1]
+        return activation(torch.matmul(x, w.to(x.device)) + b.to(x.device))
+
     def _level(self, variant, conv1, conv2, fx, fy, ox, oy, p, D):
         B, H, W, C3 = conv2.shape
         return ops.LevelProblem(variant, conv1, conv2, D, H, W, conv1.shape[2], rays=p, fx=fx, fy=fy, ox=ox, oy=oy,

@@ -50,3 +50,31 @@ def test_legacy_normal_equations_match_oracle():
                                                         tt(R), tt(T), None, False, False)
     np.testing.assert_allclose(AtA.numpy(), dbg["AtA"], rtol=1e-9, atol=1e-9 * np.abs(dbg["AtA"]).max())
     np.testing.assert_allclose(Atb.numpy()[..., None], dbg["Atb"], rtol=1e-9, atol=1e-9 * np.abs(dbg["Atb"]).max())
+
+
+def test_legacy_tracker_helper_methods_match_oracle():
+    """the small methods of legacy/ba.py's Tracker (Jacobian without the bundlenet minus sign, V matrix, unguarded
+    Rodrigues, k = 1 conv) as pure torch functions, against the numpy oracle"""
+    import numpy as np
+    import torch
+    from banet_amd import legacy
+    from oracle import banet_oracle as orc
+    rng = np.random.RandomState(2)
+    B, N = 2, 7
+    x, y = rng.uniform(-0.5, 0.5, (B, N)).astype(np.float32), rng.uniform(-0.5, 0.5, (B, N)).astype(np.float32)
+    Z = rng.uniform(1, 3, (B, N)).astype(np.float32)
+    fx, fy = np.full((B, N), 300.0, np.float32), np.full((B, N), 280.0, np.float32)
+    w1, b1 = rng.standard_normal((4, 8)).astype(np.float32), rng.standard_normal(8).astype(np.float32)
+    tr = legacy.Tracker(lambda_weights={"2": [(torch.from_numpy(w1), torch.from_numpy(b1))]})
+    T = torch.from_numpy
+    J = tr.CameraJacobianMatrix(T(x), T(y), T(Z), T(fx), T(fy)).numpy()
+    np.testing.assert_allclose(J, orc.camera_jacobian(x, y, Z, fx, fy, +1), rtol=1e-6, atol=1e-6)
+    w = rng.uniform(-0.3, 0.3, (B, 3)).astype(np.float32)
+    Rm = tr.AngleaAxisRotation(T(w[:, 0:1]), T(w[:, 1:2]), T(w[:, 2:3])).numpy()
+    np.testing.assert_allclose(Rm, orc.angle_axis_rotation(w, clamp_theta=False), rtol=1e-5, atol=1e-6)
+    V = tr.VMatrix(T(w[:, 0:1]), T(w[:, 1:2]), T(w[:, 2:3])).numpy()
+    np.testing.assert_allclose(V, orc.vmatrix(w), rtol=1e-5, atol=1e-6)
+    assert np.isnan(tr.AngleaAxisRotation(torch.zeros(1, 1), torch.zeros(1, 1), torch.zeros(1, 1)).numpy()).any()   # as the reference
+    xin = rng.standard_normal((B, 1, 4)).astype(np.float32)
+    out = tr.conv1d(T(xin), 8, "lambda_2_1", activation=torch.nn.functional.selu).numpy()
+    np.testing.assert_allclose(out, orc.selu(xin @ w1 + b1), rtol=1e-5, atol=1e-6)
