@@ -92,11 +92,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # development overrides (to exercise the multi-rank path on a one-GPU box): BANET_BENCH_DEVICE pins every rank to one
+    # device, BANET_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU)
+    dev_index = int(os.environ.get("BANET_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("BANET_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL over xGMI
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     pairs = args.frames - 1
     assert 1 <= pairs <= 7, "--frames 2..8"
