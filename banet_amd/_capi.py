@@ -42,6 +42,14 @@ class State(ctypes.Structure):
                 ("delta", _FP)]
 
 
+class LmParams(ctypes.Structure):
+    """mirror of banet_lm_params_t (the run-time LM configuration of legacy/ba.py:5-9)"""
+    _fields_ = [("angle_change", ctypes.c_float), ("translation_change", ctypes.c_float),
+                ("residual_ratio", ctypes.c_float), ("solver", ctypes.c_int32)]
+
+
+SOLVER_QR, SOLVER_INVERSE = 0, 1
+
 EXPORTS = {
     "banet_version": (ctypes.c_int, []),
     "banet_error_string": (ctypes.c_char_p, [ctypes.c_int]),
@@ -62,6 +70,10 @@ EXPORTS = {
     "banet_lm_level_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Level)]),
     "banet_lm_level_f32": (ctypes.c_int, [ctypes.POINTER(Level), ctypes.POINTER(Mlp), ctypes.c_float, ctypes.c_int,
                                           ctypes.c_int, ctypes.POINTER(State), _FP, ctypes.c_size_t, _FP]),
+    "banet_lm_params_default": (None, [ctypes.POINTER(LmParams)]),
+    "banet_lm_level_ex_f32": (ctypes.c_int, [ctypes.POINTER(Level), ctypes.POINTER(Mlp), ctypes.c_float, ctypes.c_int,
+                                             ctypes.c_int, ctypes.POINTER(LmParams), ctypes.POINTER(State), _FP,
+                                             ctypes.c_size_t, _FP]),
     "banet_profile_begin": (ctypes.c_int, [ctypes.c_int]),
     "banet_profile_end": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),
                                          ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]),

@@ -93,8 +93,9 @@ def DepthJacobianMatrix(rx, ry, rz, x, y, Z, fx, fy, name=None):
 
 def resampler(data, warp):
     """tf.contrib.resampler.resampler: bilinear, zero padding.  data [B,H,W,C], warp [B,N,2] (x,y)
-    -> [B,N,C] (bundlenet.py:290,320,343-344,385) -- HIP kernel ba_resample_kernel."""
-    return ops.resample(data, warp, clamp=False)
+    -> [B,N,C] (bundlenet.py:290,320,343-344,385) -- HIP kernel ba_resample_kernel; when `data` or `warp`
+    requires grad, the differentiable expression with the TF op's gradients (map and coordinates)."""
+    return _resample(data, warp)
 
 
 def _resampler_autograd(data, warp):
@@ -121,6 +122,38 @@ def _resampler_autograd(data, warp):
     out = (dx * dy).unsqueeze(-1) * tap(fx_, fy_) + ((1 - dx) * (1 - dy)).unsqueeze(-1) * tap(cx, cy) \
         + (dx * (1 - dy)).unsqueeze(-1) * tap(fx_, cy) + ((1 - dx) * dy).unsqueeze(-1) * tap(cx, fy_)
     return torch.where(ok.unsqueeze(-1), out, torch.zeros_like(out))
+
+
+def _grad_fixed_autograd(img):
+    """bundlenet.py:92-100 as a differentiable torch expression: REFLECT pad by one pixel, central differences
+    0.5 (f[x+1] - f[x-1]) -> [gx | gy] (exactly zero on the one-pixel rim).  img [B,H,W,C] -> [B,H,W,2C]."""
+    x = torch.nn.functional.pad(img.permute(0, 3, 1, 2), (1, 1, 1, 1), mode="reflect")
+    gx = 0.5 * (x[:, :, 1:-1, 2:] - x[:, :, 1:-1, :-2])
+    gy = 0.5 * (x[:, :, 2:, 1:-1] - x[:, :, :-2, 1:-1])
+    return torch.cat([gx, gy], dim=1).permute(0, 2, 3, 1)
+
+
+def _wants_grad(*tensors):
+    return torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors)
+
+
+def _resample(data, warp):
+    """resampler(): the HIP kernel when nothing upstream needs a gradient, the differentiable expression otherwise
+    (the reference differentiates through tf.contrib.resampler w.r.t. both arguments)."""
+    return _resampler_autograd(data, warp) if _wants_grad(data, warp) else ops.resample(data, warp, clamp=False)
+
+
+def _target_map(img):
+    """[f | gx | gy] (bundlenet.py:323-324): HIP kernel, or the differentiable expression when img needs a gradient."""
+    return torch.cat([img, _grad_fixed_autograd(img)], dim=-1) if _wants_grad(img) else ops.target_map(img)
+
+
+def _depth_output(init_depth, basis, W):
+    """init_depth + basis . W (bundlenet.py:397): HIP kernel, or differentiable w.r.t. init_depth, basis and W."""
+    if _wants_grad(init_depth, basis, W):
+        nb, K = basis.shape[0], basis.shape[-1]
+        return init_depth + torch.matmul(basis.reshape(nb, -1, K), W.reshape(nb, K, 1)).reshape(init_depth.shape)
+    return ops.depth_output(init_depth, basis.reshape(basis.shape[0], -1, basis.shape[-1]), W)
 
 
 def he_normal_lambda_weights(C, seed, device="cpu"):
@@ -189,7 +222,7 @@ class BundleNet:
         self.is_training = is_training
         self.reuse_variables = reuse_variables
         self.lambda_weights = dict(lambda_weights or {})
-        self._mlp_cache = {}
+        self._mlp_cache = ops.MlpCache()
         # training graph: True = exact gradients (the upstream dL/dAtA is symmetrised before the op's
         # backward); False = the reference's registered gradient verbatim (inexact: matrix_solve's
         # gradient w.r.t. AtA is not symmetric, utils.cu:648-657 assumes it is)
@@ -202,6 +235,8 @@ class BundleNet:
     # -- small helpers kept for API parity --------------------------------------------
     def grad_fixed(self, input, name=None):
         """bundlenet.py:92-100"""
+        if _wants_grad(input):
+            return _grad_fixed_autograd(input)
         C = input.shape[-1]
         return ops.target_map(input)[..., C:]          # [gx | gy] of ba_target_map_kernel
 
@@ -221,12 +256,7 @@ class BundleNet:
         return p / torch.sqrt(torch.clamp((p * p).sum(dim=1, keepdim=True), min=1e-12))
 
     def _mlp(self, level, device):
-        key = (str(level), str(device))
-        if key not in self._mlp_cache:
-            if str(level) not in self.lambda_weights:
-                raise KeyError("no lambda weights for level %r (set BundleNet.lambda_weights[level])" % (level,))
-            self._mlp_cache[key] = ops.MlpWeights(self.lambda_weights[str(level)], device)
-        return self._mlp_cache[key]
+        return self._mlp_cache.get(self.lambda_weights, level, device)
 
     # -- the two iteration bodies -------------------------------------------------------
     def CameraIteration(self, conv1, conv2, fx, fy, ox, oy, p, D, R, T, l2_regularizer_base=None, level=None):
@@ -302,8 +332,8 @@ class BundleNet:
             z = torch.matmul(h, w.to(h.device)) + b.to(h.device)
             h = torch.tanh(z) if i == 4 else torch.nn.functional.selu(z)
         lam = torch.linalg.vector_norm(avg, dim=-1, keepdim=True) ** (2.0 + h)          # :249
-        if l2_regularizer_base is not None:
-            lam = l2_regularizer_base * lam
+        if bundle and l2_regularizer_base is not None:                                   # :252-253; CameraIteration (:122-191)
+            lam = l2_regularizer_base * lam                                             # ignores the argument
         J = CameraJacobianMatrix(x, y, Z, fx, fy)                                       # :259
         if bundle:
             jd = DepthJacobianMatrix(rx.unsqueeze(1), ry.unsqueeze(1), rz.unsqueeze(1), x, y, Z, fx, fy)
@@ -349,8 +379,8 @@ class BundleNet:
             z = torch.matmul(h, w.to(h.device)) + b.to(h.device)
             h = torch.tanh(z) if i == 4 else torch.nn.functional.selu(z)
         lam = torch.linalg.vector_norm(avg, dim=-1, keepdim=True) ** (2.0 + h)          # :249
-        if l2_regularizer_base is not None:
-            lam = l2_regularizer_base * lam
+        if bundle and l2_regularizer_base is not None:                                   # :252-253; CameraIteration (:122-191)
+            lam = l2_regularizer_base * lam                                             # ignores the argument
         Jc = CameraJacobianMatrix(x, y, Z, fx, fy)                                      # [B,N,2,6]  :259
         M11, M12, M22, g1, g2 = (stats[..., i] for i in range(5))
         MJ0 = M11.unsqueeze(-1) * Jc[:, :, 0] + M12.unsqueeze(-1) * Jc[:, :, 1]         # rows of M Jc  [B,N,6]
@@ -417,7 +447,7 @@ class BundleNet:
         for level in range(0, 4):
             scale = 2 ** (3 - level)
             layer1 = resampler(layers[level], _points / scale)
-            layer2 = ops.target_map(self._swap_halves(layers[level]))      # [f | gx | gy]
+            layer2 = _target_map(self._swap_halves(layers[level]))         # [f | gx | gy], differentiable when needed
             R, T = self.CameraIteration(layer1, layer2, self.fx / scale, self.fy / scale, self.ox / scale,
                                         self.oy / scale, p, d, R, T, 1.0, str(level))
             rotations.append(R)
@@ -444,12 +474,12 @@ class BundleNet:
         for level in range(2, 4):
             scale = 2 ** (3 - level)
             layer1 = resampler(layers[level], _points / scale)
-            layer2 = ops.target_map(self._swap_halves(layers[level]))      # [f | gx | gy]
+            layer2 = _target_map(self._swap_halves(layers[level]))         # [f | gx | gy], differentiable when needed
             R, T, W = self.BundleIteration(layer1, layer2, self.fx / scale, self.fy / scale, self.ox / scale,
                                            self.oy / scale, p, d, b, R, T, W, 1000.0, str(level))
             out_R.append(R)
             out_T.append(T)
-            out_D.append(ops.depth_output(init_depth, basis.reshape(nbatch, -1, nbasis), W))
+            out_D.append(_depth_output(init_depth, basis, W))              # :397, differentiable w.r.t. init_depth / basis / W
         return out_R, out_T, out_D
 
     # -- losses (bundlenet.py:401-463) ---------------------------------------------------
@@ -464,14 +494,18 @@ class BundleNet:
         npixels = height * width
         dev = depth.device
         mask = mask.reshape(nbatch, npixels)
-        self._crop_intrinsics(intrisic, npixels)
+        # locals, as the reference (:441-445): lossF must not disturb the intrinsics a Resize call left on self
+        fx = 40.0 * intrisic[:, 0].repeat(1, npixels) / 39.0
+        fy = 32.0 * intrisic[:, 1].repeat(1, npixels) / 29.0
+        ox = (40.0 * intrisic[:, 2].repeat(1, npixels) / 39.0) - (160.0 / 39.0)
+        oy = (32.0 * intrisic[:, 3].repeat(1, npixels) / 29.0) - (128.0 / 29.0)
         ys, xs = torch.meshgrid(torch.arange(height, device=dev), torch.arange(width, device=dev), indexing="ij")
         pts = torch.stack([xs.reshape(-1).float(), ys.reshape(-1).float()], dim=-1)[None].repeat(nbatch, 1, 1)
-        p = self.computeCoordinates(pts, self.fx, self.fy, self.ox, self.oy)
+        p = self.computeCoordinates(pts, fx, fy, ox, oy)
 
         def flow(R, T):
             X = torch.matmul(R, p) * depth.reshape(nbatch, 1, npixels) + T.reshape(nbatch, 3, 1)
-            return self.fx * X[:, 0] / X[:, 2] + self.ox, self.fy * X[:, 1] / X[:, 2] + self.oy
+            return fx * X[:, 0] / X[:, 2] + ox, fy * X[:, 1] / X[:, 2] + oy
 
         fxp, fyp = flow(predR, predT)
         fxg, fyg = flow(gtR, gtT)

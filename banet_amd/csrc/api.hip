@@ -78,6 +78,7 @@ static SolveArgs make_solve_args(const banet_level_t* lv, const banet_mlp_t* mlp
   a.queue = nullptr;
   a.nqueue = 0;
   a.bigA = nullptr;
+  banet_lm_params_default(&a.lm);
   return a;
 }
 
@@ -182,8 +183,22 @@ size_t banet_lm_level_workspace_bytes(const banet_level_t* lv) {
   return carve_level(lv, pl, nullptr).total;
 }
 
+void banet_lm_params_default(banet_lm_params_t* p) {
+  if (!p) return;
+  p->angle_change = (float)(0.002 * (3.14 / 180.0));   // legacy/ba.py:6 (3.14, not pi)
+  p->translation_change = 0.0002f;                      // legacy/ba.py:7
+  p->residual_ratio = 1.0f;                             // legacy/ba.py:8
+  p->solver = BANET_SOLVER_QR;                          // legacy/ba.py:9
+}
+
 int banet_lm_level_f32(const banet_level_t* lv, const banet_mlp_t* mlp, float l2_base, int max_iters,
                        int early_termination, banet_state_t* st, void* ws, size_t ws_bytes, banet_stream_t stream) {
+  return banet_lm_level_ex_f32(lv, mlp, l2_base, max_iters, early_termination, nullptr, st, ws, ws_bytes, stream);
+}
+
+int banet_lm_level_ex_f32(const banet_level_t* lv, const banet_mlp_t* mlp, float l2_base, int max_iters,
+                          int early_termination, const banet_lm_params_t* params, banet_state_t* st, void* ws,
+                          size_t ws_bytes, banet_stream_t stream) {
   int rc = check_level(lv);
   if (rc != BANET_OK) return rc;
   rc = check_state(lv, mlp, st);
@@ -199,6 +214,12 @@ int banet_lm_level_f32(const banet_level_t* lv, const banet_mlp_t* mlp, float l2
   SolveArgs a = make_solve_args(lv, mlp, l2_base, w.AtA, w.Atb, w.absres, w.nvalid, st);
   a.max_iters = max_iters;
   a.bigA = w.bigA;
+  if (params) {
+    if (params->solver != BANET_SOLVER_QR && params->solver != BANET_SOLVER_INVERSE) return BANET_ERR_INVALID_ARG;
+    if (!(params->angle_change >= 0.f) || !(params->translation_change >= 0.f) || !(params->residual_ratio > 0.f))
+      return BANET_ERR_INVALID_ARG;   // also rejects NaN
+    a.lm = *params;
+  }
   const bool lm = early_termination && lv->variant == BANET_LEGACY_LM;
   if (lm) {
     // device-side loop control: max_iters + 1 evaluation rounds; the last one only runs the

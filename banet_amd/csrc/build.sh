@@ -5,12 +5,32 @@ cd "$(dirname "$0")"
 OUT=../lib
 mkdir -p "$OUT"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
-for f in gather gather128 gather128p syrk syrk_wide assemble eqcon eqcon_syrk eqcon_grad solve prep sstats api; do
-  if [ ! -f "$OUT/$f.o" ] || [ "$f.hip" -nt "$OUT/$f.o" ] || [ common.hpp -nt "$OUT/$f.o" ] || [ kernels.hpp -nt "$OUT/$f.o" ] || [ gather_common.hpp -nt "$OUT/$f.o" ] || [ syrk_split.hpp -nt "$OUT/$f.o" ] || [ ../../include/banet_hip.h -nt "$OUT/$f.o" ]; then
+SRCS="gather gather128 gather128p syrk syrk_wide assemble eqcon eqcon_syrk eqcon_grad solve prep sstats api"
+pids=()
+names=()
+for f in $SRCS; do
+  stale=0
+  [ -f "$OUT/$f.o" ] || stale=1
+  for dep in "$f.hip" *.hpp ../../include/banet_hip.h; do
+    [ "$stale" = 1 ] || { [ "$dep" -nt "$OUT/$f.o" ] && stale=1; } || true
+  done
+  if [ "$stale" = 1 ]; then
     echo "hipcc $f.hip"
+    rm -f "$OUT/$f.o"      # a failed compile must not leave an older object for the link step
     hipcc $FLAGS ${EXTRA_HIPCC_FLAGS:-} -c "$f.hip" -o "$OUT/$f.o" &
+    pids+=($!)
+    names+=("$f")
   fi
 done
-wait
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libbanet_hip.so" "$OUT/gather.o" "$OUT/gather128.o" "$OUT/gather128p.o" "$OUT/syrk.o" "$OUT/syrk_wide.o" "$OUT/assemble.o" "$OUT/eqcon.o" "$OUT/eqcon_syrk.o" "$OUT/eqcon_grad.o" "$OUT/solve.o" "$OUT/prep.o" "$OUT/sstats.o" "$OUT/api.o"
+fail=0
+for i in "${!pids[@]}"; do
+  if ! wait "${pids[$i]}"; then
+    echo "build.sh: hipcc failed on ${names[$i]}.hip" >&2
+    fail=1
+  fi
+done
+[ "$fail" = 0 ] || exit 1
+OBJS=""
+for f in $SRCS; do OBJS="$OBJS $OUT/$f.o"; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libbanet_hip.so" $OBJS
 echo "built $OUT/libbanet_hip.so"

@@ -120,6 +120,7 @@ struct SolveArgs {
   float* bigA; // workspace for the normal matrix when it does not fit in LDS (solve_big_bytes), else nullptr
   int* queue;  // LM loop: the next gather's tile-queue heads, zeroed by this kernel (saves a memset per iteration)
   int nqueue;  // words per window
+  banet_lm_params_t lm;   // run-time LM configuration (legacy/ba.py:5-9)
 };
 int launch_solve(const SolveArgs& a, hipStream_t s);
 size_t solve_big_bytes(int B, int P, int C);

@@ -32,9 +32,7 @@ constexpr int kGrid = 32;              // 2-D cyclic thread grid of the register
 
 constexpr float kSeluAlpha = 1.6732632423543772848170429916717f;
 constexpr float kSeluScale = 1.0507009873554804934193349852946f;
-constexpr float kAngleChange = (float)(0.002 * (3.14 / 180.0));  // legacy/ba.py:6
-constexpr float kTranslationChange = 0.0002f;                     // legacy/ba.py:7
-constexpr float kResidualRatio = 1.0f;                            // legacy/ba.py:8
+// (the loop thresholds / residual ratio / solver choice of legacy/ba.py:5-9 arrive in SolveArgs::lm)
 
 __device__ __forceinline__ float selu(float x) {
   return kSeluScale * (x > 0.f ? x : kSeluAlpha * (expf(x) - 1.f));
@@ -183,6 +181,45 @@ __device__ void qr_solve_small(float* A, int ld, float* rhs, int n, float* x) {
     float s = rhs[k];
     for (int j = k + 1; j < n; ++j) s -= A[k * ld + j] * x[j];
     x[k] = s / A[k * ld + k];
+  }
+}
+
+// tf.matmul(tf.matrix_inverse(AtA), Atb) for the 6x6 legacy system (legacy/ba.py:203,290, `qr = False`): the explicit
+// inverse by Gauss-Jordan elimination with partial pivoting (the algorithm class of tf.matrix_inverse: LU-PP solves
+// against the identity), then the product.  Thread 0, registers.
+__device__ void inverse_solve_small(const float* A, int ld, const float* rhs, float* x) {
+  float M[6][12];
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) {
+      M[i][j] = A[i * ld + j];
+      M[i][6 + j] = (i == j) ? 1.f : 0.f;
+    }
+  for (int k = 0; k < 6; ++k) {
+    int p = k;
+    float best = fabsf(M[k][k]);
+    for (int i = k + 1; i < 6; ++i)
+      if (fabsf(M[i][k]) > best) {
+        best = fabsf(M[i][k]);
+        p = i;
+      }
+    if (p != k)
+      for (int j = 0; j < 12; ++j) {
+        const float t = M[k][j];
+        M[k][j] = M[p][j];
+        M[p][j] = t;
+      }
+    const float inv = 1.f / M[k][k];
+    for (int j = 0; j < 12; ++j) M[k][j] *= inv;
+    for (int i = 0; i < 6; ++i) {
+      if (i == k) continue;
+      const float f = M[i][k];
+      for (int j = 0; j < 12; ++j) M[i][j] = fmaf(-f, M[k][j], M[i][j]);
+    }
+  }
+  for (int i = 0; i < 6; ++i) {
+    float s = 0.f;
+    for (int j = 0; j < 6; ++j) s = fmaf(M[i][6 + j], rhs[j], s);
+    x[i] = s;
   }
 }
 
@@ -616,7 +653,7 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve_update_kernel(const So
     if (tid == 0) {
       int go = 1;
       if (ctl->pending) {
-        if (!(avg_scalar < kResidualRatio * ctl->avg_prev)) {  // reject: legacy/ba.py:343-345
+        if (!(avg_scalar < a.lm.residual_ratio * ctl->avg_prev)) {  // reject: legacy/ba.py:343-345
           for (int i = 0; i < 9; ++i) a.st.R[b * 9 + i] = ctl->Rprev[i];
           for (int i = 0; i < 3; ++i) a.st.T[b * 3 + i] = ctl->Tprev[i];
           ctl->uw = 0.f;
@@ -625,7 +662,7 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve_update_kernel(const So
         ctl->pending = 0;
       }
       // loop condition, legacy/ba.py:132-133
-      if (!(a.st.iters[b] < a.max_iters && kAngleChange < ctl->uw && kTranslationChange < ctl->ut)) {
+      if (!(a.st.iters[b] < a.max_iters && a.lm.angle_change < ctl->uw && a.lm.translation_change < ctl->ut)) {
         ctl->active = 0;
         go = 0;
       }
@@ -661,7 +698,10 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve_update_kernel(const So
     if (tid == 0) {
       float rhs[6];
       for (int i = 0; i < 6; ++i) rhs[i] = sA[i * ld + P];
-      qr_solve_small(sA, ld, rhs, 6, sX);
+      if (a.lm.solver == BANET_SOLVER_INVERSE)
+        inverse_solve_small(sA, ld, rhs, sX);     // `qr = False`, legacy/ba.py:203,290
+      else
+        qr_solve_small(sA, ld, rhs, 6, sX);
     }
     __syncthreads();
   } else {

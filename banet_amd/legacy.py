@@ -10,12 +10,18 @@ import torch
 
 from . import ops
 
-# module-level switches, as legacy/ba.py:5-9
+# module-level switches, as legacy/ba.py:5-9.  Like the reference's drivers (legacy/example.py:8, legacy/eval.py:9) callers
+# overwrite them (`legacy.early_termination = False`); every Tracker call reads them at call time and hands them to
+# banet_lm_level_ex_f32 as a banet_lm_params_t.
 early_termination = True
-angle_change = 0.002 * (3.14 / 180.0)   # compiled into solve.hip (kAngleChange)
+angle_change = 0.002 * (3.14 / 180.0)
 translation_change = 0.0002
 residual_ratio = 1.0
 qr = True
+
+
+def _params():
+    return ops.lm_params(angle_change, translation_change, residual_ratio, qr)
 
 
 def interpolate2d2(imgs, p):
@@ -30,13 +36,10 @@ class Tracker:
     def __init__(self, lambda_weights=None, iters=(3, 5, 7)):
         self.lambda_weights = dict(lambda_weights or {})
         self.iters = list(iters)
-        self._mlp_cache = {}
+        self._mlp_cache = ops.MlpCache()
 
     def _mlp(self, level, device):
-        key = (str(level), str(device))
-        if key not in self._mlp_cache:
-            self._mlp_cache[key] = ops.MlpWeights(self.lambda_weights[str(level)], device)
-        return self._mlp_cache[key]
+        return self._mlp_cache.get(self.lambda_weights, level, device)
 
     def grad_fixed(self, input, name=None):
         """legacy/ba.py:17-25"""
@@ -86,7 +89,7 @@ class Tracker:
         """legacy/ba.py:148-214 -> (updatedR, updatedT, ratio)"""
         lv = self._level("legacy_fixed", conv1, conv2, fx, fy, ox, oy, p, D)
         st = ops.LmState(R, T, None, 6)
-        ops.lm_level(lv, None, 1.0, 1, False, st)
+        ops.lm_level(lv, None, 1.0, 1, False, st, params=_params())
         return st.R, st.T, st.ratio
 
     def CameraIteration2(self, conv1, conv2, fx, fy, ox, oy, p, D, R, T, level):
@@ -94,7 +97,7 @@ class Tracker:
         its accept/reject test (two evaluation rounds on the device)."""
         lv = self._level("legacy_lm", conv1, conv2, fx, fy, ox, oy, p, D)
         st = ops.LmState(R, T, None, 6)
-        ops.lm_level(lv, self._mlp(level, conv1.device), 1.0, 1, True, st)
+        ops.lm_level(lv, self._mlp(level, conv1.device), 1.0, 1, True, st, params=_params())
         accepted = ((st.R - ops.capi.f32c(R).reshape(-1, 3, 3)).abs().amax(dim=(1, 2)) > 0) | \
                    ((st.T - ops.capi.f32c(T).reshape(-1, 3, 1)).abs().amax(dim=(1, 2)) > 0)
         uw = torch.where(accepted, st.delta[:, 0:3].norm(dim=1), torch.zeros_like(st.ratio))
@@ -121,6 +124,6 @@ class Tracker:
             variant = "legacy_lm" if early_termination else "legacy_fixed"
             lv = self._level(variant, layer1, layer2, fx0 / scale, fy0 / scale, ox0 / scale, oy0 / scale, p, d)
             mlp = self._mlp(level, points.device) if early_termination else None
-            ops.lm_level(lv, mlp, 1.0, level_iters[level - 1], early_termination, st)
+            ops.lm_level(lv, mlp, 1.0, level_iters[level - 1], early_termination, st, params=_params())
             self.level_iters_run.append(st.iters.clone())
         return st.R, st.T, st.ratio

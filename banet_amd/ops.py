@@ -128,15 +128,71 @@ class MlpWeights:
     """Device copies of the five k=1 conv layers lambda_<level>_<i>_{filters,biases}
     (bundlenet.py:102-110,168-172): filters [Cin,Cout] row-major, biases [Cout]."""
 
-    def __init__(self, layers, device):
-        assert len(layers) == 5
+    def __init__(self, layers, device, C=None):
+        if len(layers) != 5:
+            raise capi.BanetError("the lambda predictor has 5 layers, got %d" % len(layers))
         self.w = [torch.as_tensor(w, dtype=torch.float32).reshape(w.shape[-2], w.shape[-1]).contiguous().to(device)
                   for w, _ in layers]
-        self.b = [torch.as_tensor(b, dtype=torch.float32).contiguous().to(device) for _, b in layers]
+        self.b = [torch.as_tensor(b, dtype=torch.float32).reshape(-1).contiguous().to(device) for _, b in layers]
+        self.C = int(self.w[0].shape[0])
+        self.check(self.C if C is None else C)
         self.c = capi.Mlp()
         for i in range(5):
             self.c.w[i] = self.w[i].data_ptr()
             self.c.b[i] = self.b[i].data_ptr()
+
+
+    def check(self, C):
+        """The solve kernel reads the layers with the fixed extents C -> 2C -> 4C -> 2C -> C -> 1
+        (bundlenet.py:168-172): anything else would be an out-of-bounds device read, so refuse it here."""
+        dims = [C, 2 * C, 4 * C, 2 * C, C, 1]
+        for i in range(5):
+            if tuple(self.w[i].shape) != (dims[i], dims[i + 1]) or tuple(self.b[i].shape) != (dims[i + 1],):
+                raise capi.BanetError("lambda MLP layer %d: expected filters [%d,%d] and biases [%d] for C = %d feature "
+                                      "channels, got %s and %s" % (i + 1, dims[i], dims[i + 1], dims[i + 1], C,
+                                                                   tuple(self.w[i].shape), tuple(self.b[i].shape)))
+
+
+class MlpCache:
+    """Device copies of per-level lambda weights, rebuilt whenever a level's weights are replaced or modified in place
+    (checkpoint reload, optimizer step): keyed on the identity and autograd version counter of every weight tensor;
+    weights held as numpy arrays (no version counter) are re-uploaded on every call."""
+
+    def __init__(self):
+        self._d = {}
+
+    def get(self, lambda_weights, level, device):
+        level = str(level)
+        if level not in lambda_weights:
+            raise KeyError("no lambda weights for level %r (set lambda_weights[level])" % (level,))
+        layers = lambda_weights[level]
+        flat = [t for pair in layers for t in pair]
+        versioned = all(torch.is_tensor(t) for t in flat)
+        sig = tuple((id(t), t._version) for t in flat) if versioned else None
+        key = (level, str(device))
+        hit = self._d.get(key)
+        if hit is None or sig is None or hit[0] != sig:
+            hit = (sig, MlpWeights(layers, device))
+            self._d[key] = hit
+        return hit[1]
+
+    def clear(self):
+        self._d.clear()
+
+
+def lm_params(angle_change=None, translation_change=None, residual_ratio=None, qr=None):
+    """banet_lm_params_t: the reference's module globals legacy/ba.py:5-9 as a value (None = the reference's default)."""
+    p = capi.LmParams()
+    capi.lib().banet_lm_params_default(ctypes.byref(p))
+    if angle_change is not None:
+        p.angle_change = float(angle_change)
+    if translation_change is not None:
+        p.translation_change = float(translation_change)
+    if residual_ratio is not None:
+        p.residual_ratio = float(residual_ratio)
+    if qr is not None:
+        p.solver = capi.SOLVER_QR if qr else capi.SOLVER_INVERSE
+    return p
 
 
 class LmState:
@@ -219,22 +275,28 @@ def ba_assemble(level, R, T, Wc=None):
 def ba_solve_update(level, mlp, l2_base, AtA, Atb, absres, nvalid, state):
     """banet_ba_solve_update_f32: lambda, damping, solve, SE(3)/W update (in place on `state`)."""
     L = capi.lib()
+    if mlp is not None:
+        mlp.check(level.C)
     capi.check(L.banet_ba_solve_update_f32(ctypes.byref(level.c), ctypes.byref(mlp.c) if mlp is not None else None,
                                            float(l2_base), capi.ptr(AtA), capi.ptr(Atb), capi.ptr(absres),
                                            capi.ptr(nvalid), ctypes.byref(state.c), capi.stream()))
 
 
-def lm_level(level, mlp, l2_base, max_iters, early_termination, state, ws=None):
-    """banet_lm_level_f32: the whole LM loop of one pyramid level, enqueued without host sync."""
+def lm_level(level, mlp, l2_base, max_iters, early_termination, state, ws=None, params=None):
+    """banet_lm_level_ex_f32: the whole LM loop of one pyramid level, enqueued without host sync.
+    params: an `lm_params(...)` value (None = the reference's defaults, legacy/ba.py:5-9)."""
     L = capi.lib()
+    if mlp is not None:
+        mlp.check(level.C)
     nb = L.banet_lm_level_workspace_bytes(ctypes.byref(level.c))
     if nb == 0:
         raise capi.BanetError("lm_level: unsupported level shape")
     if ws is None or ws.numel() < nb:
         ws = capi.workspace(nb, level.device)
-    capi.check(L.banet_lm_level_f32(ctypes.byref(level.c), ctypes.byref(mlp.c) if mlp is not None else None,
-                                    float(l2_base), int(max_iters), int(bool(early_termination)),
-                                    ctypes.byref(state.c), ctypes.c_void_p(ws.data_ptr()), ws.numel(), capi.stream()))
+    capi.check(L.banet_lm_level_ex_f32(ctypes.byref(level.c), ctypes.byref(mlp.c) if mlp is not None else None,
+                                       float(l2_base), int(max_iters), int(bool(early_termination)),
+                                       ctypes.byref(params) if params is not None else None,
+                                       ctypes.byref(state.c), ctypes.c_void_p(ws.data_ptr()), ws.numel(), capi.stream()))
     return ws
 
 

@@ -4,22 +4,26 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (configs[1], "cfg-2"): 2-frame windows, 640x480, 5-level pyramid (scales 16,8,4,2,1),
-C = 128 feature channels, K = 128 depth-basis coefficients, 10 LM iterations per level,
-8 windows per GPU (weak scaling: every rank solves its own 8 windows; the only collective is
-the all-gather of the per-window result records).  Iteration body = bundlenet.py:193-278
-(BundleIteration), dense points, synthetic features / random-init lambda MLP.
+Headline workload = the configuration BASELINE.json's `metric` is quoted on: 640x480, 5-level pyramid (scales
+16,8,4,2,1), C = 128 feature channels, K = 128 depth-basis coefficients, 10 LM iterations per level, BATCH 32
+two-frame windows per GPU (weak scaling: every rank solves its own 32 windows; the only collective is the all-gather
+of the per-window result records).  Iteration body = bundlenet.py:193-278 (BundleIteration), dense points, synthetic
+features / random-init lambda MLP.
 
-One "step" = one full coarse->fine solve (50 LM iterations) of the rank's 8 windows with the
-inputs already resident in HBM.  value = windows * 50 * steps / time over all ranks.
-The JSON line also carries
-  roofline     : the fused assembly kernel (dominant), algorithmic bytes 4*N_l*(2C+K+1) per
-                 window-iteration vs the kernel time measured with HIP events inside the
-                 timed region (banet_profile_begin/_end), peak 8 TB/s;
-  cpu_baseline : the numpy oracle (a port of the reference's arithmetic) timed on the host
-                 cores for ONE window x ONE iteration at each of the 5 levels.
+One "step" = one full coarse->fine solve (50 LM iterations) of the rank's windows with the inputs already resident in
+HBM.  value = windows * 50 * steps / time over all ranks.  The JSON line also carries (rank 0, N = 1 only)
+  roofline     : the fused assembly (gather) kernel, algorithmic bytes 4*N_l*(C*F + K + 1) per window-iteration vs the
+                 kernel time measured with HIP events inside the timed region (banet_profile_begin/_end), peak 8 TB/s;
+  sweep        : the other batch sizes north_star names (B = 1, 8 two-frame) and cfg-3 = configs[2] (5-frame sliding
+                 window, batch 32), each with its own value / ms_per_solve / roofline, measured in the same process;
+  parity       : window 0 solved on the GPU with a [4]*5 schedule and compared, level by level, with the numpy oracle
+                 chained over the same schedule (max relative error of the last update and of the carried state; the
+                 bench FAILS above 1e-4 = north_star's tolerance);
+  cpu_baseline : that same oracle chain timed on the host cores (numpy port) and the float32 torch port with all
+                 intra-op threads (oracle/torch_port.py) -- 1 window x 4 iterations at each of the 5 levels.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -31,39 +35,199 @@ sys.path.insert(0, ROOT)
 H, W, C, K = 480, 640, 128, 128
 SCALES = [16, 8, 4, 2, 1]
 ITERS = [10, 10, 10, 10, 10]
-WINDOWS_PER_GPU = 8
+WINDOWS_PER_GPU = 32          # BASELINE.json metric: "batch 32"
 HBM_PEAK_GBS = 8000.0
+PARITY_TOL = 1e-4             # BASELINE.json north_star: pose/depth updates within 1e-4 relative
+CHAIN_ITERS = [4, 4, 4, 4, 4]
 
 
-def cpu_baseline(intr, levels, gt, mlps):
-    """Oracle timing on the host: 1 window, CPU_ITERS chained BundleIterations at each of the 5 levels (10-15 s)."""
+def workload_name(frames, B, Hh, Ww, Kk, iters):
+    pairs = frames - 1
+    if (Hh, Ww, Kk, iters) == (H, W, K, ITERS[0]):
+        tag = "cfg-2 shape at the metric's batch" if frames == 2 else ("cfg-3 (configs[2])" if frames == 5 else "custom")
+    else:
+        tag = "custom"
+    if frames == 2:
+        return ("%s: 2-frame %dx%d 5-level pyramid, C=128, K=%d basis, %d LM iters/level, batch %d windows per GPU, "
+                "BundleIteration (bundlenet.py:193-278), dense points" % (tag, Ww, Hh, Kk, iters, B))
+    return ("%s: %d-frame sliding window (key frame + %d target frames sharing depth/basis, P = %d), %dx%d 5-level "
+            "pyramid, C=128, K=%d, %d LM iters/level, batch %d windows per GPU, dense points"
+            % (tag, frames, pairs, 6 * pairs + Kk, Ww, Hh, Kk, iters, B))
+
+
+class Problem:
+    """B synthetic windows resident in HBM + the solver object for them."""
+
+    def __init__(self, B, frames, Hh, Ww, Kk, seed, dev, reserved=0):
+        import torch
+        from banet_amd import dense as bdense, synth as bsynth
+        from banet_amd.bundlenet import he_normal_lambda_weights
+        self.B, self.pairs, self.K = B, frames - 1, Kk
+        torch.manual_seed(seed)
+        self.intr, self.levels, self.gt = bsynth.make_dense_windows(B, Hh, Ww, C, Kk, SCALES, seed + 2, dev, trans_mag=0.06,
+                                                                    pairs=self.pairs)
+        self.mlps = [he_normal_lambda_weights(C, 100 + i) for i in range(len(SCALES))]
+        self.ba = bdense.DenseBA(self.intr, self.levels, self.mlps, "bundle", 1000.0)
+        for prob in self.ba.problems:
+            prob.c.reserved_ = reserved
+        # translation prior: from T = 0 the depth Jacobian is identically zero (depth unobservable) and the reference's
+        # undamped last coefficient diverges (bundlenet.py:266)
+        self.T0 = (self.gt["T"] * 0.7).reshape(B * self.pairs, 3, 1).to(dev)
+
+    def step(self, iters, total_windows):
+        from banet_amd import parallel
+        st = self.ba.new_state(T=self.T0)
+        st, counts = self.ba.solve(iters, st)
+        rec = parallel.pack_results(st.R, st.T, st.Wc, counts)
+        return parallel.gather_results(rec, total_windows), st
+
+    def convergence_check(self, st, dev):
+        import torch
+        n = self.B * self.pairs
+        Tgt = self.gt["T"].reshape(n, 3).to(dev)
+        Rgt = self.gt["R"].reshape(n, 3, 3).to(dev)
+        err0 = float((self.T0.reshape(n, 3) - Tgt).norm(dim=1).mean())
+        err1 = float((st.T.reshape(n, 3) - Tgt).norm(dim=1).mean())
+        rot0 = float((torch.eye(3, device=dev)[None] - Rgt).flatten(1).norm(dim=1).mean())
+        rot1 = float((st.R.reshape(n, 3, 3) - Rgt).flatten(1).norm(dim=1).mean())
+        assert err1 < err0 and rot1 < rot0, "the solve did not move towards the ground truth (%g -> %g, %g -> %g)" % (
+            err0, err1, rot0, rot1)
+        return {"translation_error_prior": round(err0, 6), "translation_error_final": round(err1, 6),
+                "rotation_error_prior": round(rot0, 6), "rotation_error_final": round(rot1, 6),
+                "lambda_last_mean": round(float(st.lambda_out.mean()), 3)}
+
+
+def roofline_record(prob, prof, elapsed_s, traffic=None):
+    """Roofline of the dominant kernel (the gather): algorithmic bytes of the pass it streams / its measured time,
+    summed over every launch of the timed region (all levels), per-level breakdown included."""
+    ba, B = prob.ba, prob.B
+    alg_bytes, kern_ms, nlaunch, per_level, syrk_ms, syrk_n = 0.0, 0.0, 0, {}, 0.0, 0
+    for li, p in enumerate(ba.problems):
+        cnt, ms = prof.get(p.N, (0, 0.0))
+        scnt, sms = prof.get(-p.N, (0, 0.0))
+        by = ba.algorithmic_bytes_per_iteration(li) * B * cnt
+        alg_bytes += by
+        kern_ms += ms
+        nlaunch += cnt
+        syrk_ms += sms
+        syrk_n += scnt
+        per_level["%dx%d" % (p.c.W, p.c.H)] = {"launches": cnt, "gather_avg_us": round(1e3 * ms / max(cnt, 1), 2),
+                                                "syrk_avg_us": round(1e3 * sms / max(scnt, 1), 2),
+                                                "gather_GBps": round(by / max(ms, 1e-9) / 1e6, 1)}
+    achieved = alg_bytes / max(kern_ms, 1e-9) / 1e6            # GB/s
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "kernel": "ba_gather128p_kernel<1> (large levels) + ba_gather128_kernel<1> (small levels)",
+            "launches": nlaunch, "avg_launch_us": round(1e3 * kern_ms / max(nlaunch, 1), 2),
+            "algorithmic_bytes_per_launch": round(alg_bytes / max(nlaunch, 1)),
+            "kernel_time_share": round(kern_ms / (1e3 * elapsed_s), 4),
+            "syrk_kernel": {"launches": syrk_n, "avg_launch_us": round(1e3 * syrk_ms / max(syrk_n, 1), 2),
+                            "time_share": round(syrk_ms / (1e3 * elapsed_s), 4)},
+            "pipeline_GBps": round(alg_bytes / max(kern_ms + syrk_ms, 1e-9) / 1e6, 1),
+            "per_level": per_level}
+
+
+def timed_run(prob, iters, steps, warmup, total_windows, fence, world=1, dev=None):
+    """W warmup steps, then exactly K timed steps bracketed by fence(); returns (elapsed, profile, last state)."""
+    import torch
+    import torch.distributed as dist
+    from banet_amd import ops
+    for _ in range(warmup):
+        prob.step(iters, total_windows)
+    fence()
+    ops.profile_begin(2 * steps * sum(iters) + 8)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        full, st = prob.step(iters, total_windows)
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = ops.profile_end()
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert torch.isfinite(full).all(), "solve produced non-finite results"
+    return elapsed, prof, st
+
+
+def sub_record(frames, B, Hh, Ww, Kk, iters_per_level, steps, warmup, seed, dev, fence, reserved):
+    """One sweep entry measured like the headline (smaller step count)."""
+    import torch
+    prob = Problem(B, frames, Hh, Ww, Kk, seed, dev, reserved)
+    iters = [iters_per_level] * len(SCALES)
+    elapsed, prof, st = timed_run(prob, iters, steps, warmup, B, fence)
+    chk = prob.convergence_check(st, dev)
+    rl = roofline_record(prob, prof, elapsed)
+    step_bytes = sum(prob.ba.algorithmic_bytes_per_iteration(li) for li in range(len(SCALES))) * B * iters_per_level
+    rec = {"workload": workload_name(frames, B, Hh, Ww, Kk, iters_per_level), "windows": B, "frames": frames,
+           "value": round(B * sum(iters) * steps / elapsed, 2), "unit": "LM iterations/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": round(1e3 * elapsed / steps, 3), "ms_per_solve": round(1e3 * elapsed / steps / B, 3),
+           "end_to_end_hbm_frac": round(step_bytes / (elapsed / steps) / 1e9 / HBM_PEAK_GBS, 4),
+           "roofline": {k: rl[k] for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "kernel_time_share",
+                                           "syrk_kernel", "per_level")},
+           "check": chk}
+    del prob, st
+    gc.collect()
+    torch.cuda.empty_cache()
+    return rec
+
+
+def parity_and_cpu_baseline(prob, dev, want_baseline):
+    """Window 0 of the headline problem: the GPU solve with the [4]*5 schedule vs the numpy oracle chained over the same
+    schedule (parity), the chain's wall time = the CPU baseline (numpy port), plus the float32 torch port with all
+    host threads on the same chain."""
     import numpy as np
-    from oracle import banet_oracle as orc, dense as odense
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        threads = os.cpu_count() or 1
-    mlps = [[(np.asarray(w.cpu()), np.asarray(b.cpu())) for w, b in lw] for lw in mlps]
-    R = np.eye(3, dtype=np.float32)[None]
-    T = (gt["T"][0:1].numpy() * 0.7).reshape(1, 3, 1).astype(np.float32)
-    Wc = np.zeros((1, K, 1), np.float32)
-    total = 0.0
-    CPU_ITERS = 4
-    for li, lv in enumerate(levels):
-        d = dict(scale=lv.scale, H=lv.H, W=lv.W, src=lv.src[0:1].cpu().numpy(), tgt=lv.tgt[0:1].cpu().numpy(),
-                 D0=lv.depth[0:1].cpu().numpy(), basis=lv.basis[0:1].cpu().numpy())
-        a = odense.level_inputs(intr[0:1].cpu().numpy(), d, True)          # per-level prep, not timed
-        t0 = time.perf_counter()
-        for _ in range(CPU_ITERS):                                         # a real chain: the state moves
-            R, T, Wc, _ = orc.bundle_iteration(a["conv1"], a["conv2"], a["fx"], a["fy"], a["ox"], a["oy"], a["p"], a["D"], a["Bs"],
-                                               R, T, Wc, mlps[li], 1000.0, eq=orc.equation_construction_gemm)
-        total += time.perf_counter() - t0
-    return {"value": round(CPU_ITERS * len(levels) / total, 4), "unit": "LM iterations/s", "cores": int(threads),
-            "kind": "port", "host_cpus": os.cpu_count(),
-            "sample": "numpy oracle (oracle/banet_oracle.bundle_iteration, GEMM-arranged normal equations, "
-                      "BLAS-threaded matmuls, single-threaded elementwise): 1 window x %d chained LM iterations at each of the "
-                      "5 levels of the same synthetic 640x480 C=128 K=128 workload (%.1f s)" % (CPU_ITERS, total)}
+    import torch
+    from banet_amd import dense as bdense
+    from oracle import dense as odense
+    lv1 = [bdense.DenseLevel(l.scale, l.src[0:1].contiguous(), l.tgt[0:1].contiguous(), l.depth[0:1].contiguous(),
+                             l.basis[0:1].contiguous()) for l in prob.levels]
+    ba1 = bdense.DenseBA(prob.intr[0:1].contiguous(), lv1, prob.mlps, "bundle", 1000.0)
+    st = ba1.new_state(T=prob.T0[0:1].contiguous())
+    snaps = []
+    ba1.solve(CHAIN_ITERS, st, snapshots=snaps)
+    torch.cuda.synchronize()
+    gpu = [{k: v.cpu().numpy() for k, v in s.items()} for s in snaps]
+    intr = prob.intr[0:1].cpu().numpy()
+    nlv = [dict(scale=l.scale, H=l.H, W=l.W, src=l.src.cpu().numpy(), tgt=l.tgt.cpu().numpy(), D0=l.depth.cpu().numpy(),
+                basis=l.basis.cpu().numpy()) for l in lv1]
+    mlps = [[(np.asarray(w.cpu()), np.asarray(b.cpu())) for w, b in lw] for lw in prob.mlps]
+    R0 = np.eye(3, dtype=np.float32)[None]
+    T0 = prob.T0[0:1].cpu().numpy().reshape(1, 3, 1)
+    W0 = np.zeros((1, prob.K, 1), np.float32)
+    ref, sec_np = odense.bundle_chain(intr, nlv, mlps, CHAIN_ITERS, R0, T0, W0, engine="numpy")
+    per_level = odense.chain_parity(gpu, ref)
+    worst = max(max(r[k] for k in ("delta_pose", "delta_depth", "R", "T", "W")) for r in per_level)
+    names = ["%dx%d" % (l.W, l.H) for l in lv1]
+    parity = {"against": "oracle.banet_oracle.bundle_iteration (numpy float32), window 0, schedule %s" % CHAIN_ITERS,
+              "tolerance": PARITY_TOL, "max_rel_err": float("%.3e" % worst), "ok": bool(worst <= PARITY_TOL),
+              "iters": [int(c) for c in CHAIN_ITERS],
+              "per_level": {nm: {k: float("%.3e" % v) for k, v in r.items()} for nm, r in zip(names, per_level)}}
+    base = None
+    if want_baseline:
+        try:
+            from threadpoolctl import threadpool_info
+            blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        except Exception:
+            blas_threads = os.cpu_count() or 1
+        n_it = sum(CHAIN_ITERS)
+        tref, sec_t = odense.bundle_chain(intr, nlv, mlps, CHAIN_ITERS, R0, T0, W0, engine="torch")
+        port_vs_oracle = max(max(r[k] for k in ("R", "T", "W")) for r in odense.chain_parity(tref, ref))
+        v_np, v_t = n_it / sec_np, n_it / sec_t
+        best = "torch" if v_t >= v_np else "numpy"
+        base = {"value": round(max(v_np, v_t), 4), "unit": "LM iterations/s",
+                "cores": int(torch.get_num_threads() if best == "torch" else blas_threads), "kind": "port",
+                "host_cpus": os.cpu_count(), "engine": best,
+                "numpy_port": {"value": round(v_np, 4), "seconds": round(sec_np, 2), "blas_threads": int(blas_threads),
+                               "note": "oracle/banet_oracle.bundle_iteration, GEMM-arranged normal equations, BLAS-threaded "
+                                       "matmuls, single-threaded elementwise"},
+                "torch_port": {"value": round(v_t, 4), "seconds": round(sec_t, 2), "threads": int(torch.get_num_threads()),
+                               "max_rel_diff_vs_numpy_oracle": float("%.3e" % port_vs_oracle),
+                               "note": "oracle/torch_port.bundle_iteration, float32, torch intra-op threads = all host cores, "
+                                       "normal equations from the per-pixel 2x2 M (never materialises J)"},
+                "sample": "1 window x %d chained LM iterations at each of the 5 levels (20 LM iterations) of the same synthetic "
+                          "640x480 C=128 K=128 workload, window 0 of the timed batch" % CHAIN_ITERS[0]}
+    return parity, base
 
 
 def main():
@@ -71,21 +235,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--windows", type=int, default=None, help="windows per GPU (default: 8 for cfg-2, 32 for cfg-3)")
-    ap.add_argument("--frames", type=int, default=2, help="frames per window: 2 = cfg-2 (the default, BASELINE's metric "
-                    "workload); 5 = cfg-3/4, the 5-frame sliding window (key frame + 4 target frames, SURVEY 8(d))")
+    ap.add_argument("--windows", type=int, default=None, help="windows per GPU (default 32 = the metric's batch)")
+    ap.add_argument("--frames", type=int, default=2, help="frames per window: 2 = the metric's two-frame windows; "
+                    "5 = cfg-3/4, the 5-frame sliding window (key frame + 4 target frames, SURVEY 8(d))")
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--width", type=int, default=W)
     ap.add_argument("--basis", type=int, default=K, help="depth-basis coefficients K")
     ap.add_argument("--iters", type=int, default=ITERS[0], help="LM iterations per level")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the B = 1 / 8 / cfg-3 sub-records")
+    ap.add_argument("--no-parity", action="store_true", help="skip the in-line oracle parity record")
+    ap.add_argument("--sweep-large", action="store_true", help="add B = 256 two-frame windows (161 GB of inputs) to the sweep")
     ap.add_argument("--reserved", type=int, default=0, help="development: banet_level_t.reserved_ bits for every level (A/B switches)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from banet_amd import dense as bdense, ops, parallel, synth as bsynth
-    from banet_amd.bundlenet import he_normal_lambda_weights
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -110,21 +275,9 @@ def main():
     Hh, Ww, Kk = args.height, args.width, args.basis
     iters = [args.iters] * len(SCALES)
     default_shape = (Hh, Ww, Kk, args.iters) == (H, W, K, ITERS[0])
-    B = args.windows if args.windows is not None else (WINDOWS_PER_GPU if pairs == 1 else 32)
+    headline = default_shape and pairs == 1 and args.windows in (None, WINDOWS_PER_GPU)
+    B = args.windows if args.windows is not None else WINDOWS_PER_GPU
     total_windows = B * world
-    torch.manual_seed(1234 + rank)
-    intr, levels, gt = bsynth.make_dense_windows(B, Hh, Ww, C, Kk, SCALES, 1234 + 2 + rank, dev, trans_mag=0.06, pairs=pairs)
-    mlps = [he_normal_lambda_weights(C, 100 + i) for i in range(len(SCALES))]
-    ba = bdense.DenseBA(intr, levels, mlps, "bundle", 1000.0)
-    for prob in ba.problems:
-        prob.c.reserved_ = args.reserved
-    T0 = (gt["T"] * 0.7).reshape(B * pairs, 3, 1).to(dev)   # translation prior: depth is unobservable from T = 0
-
-    def step():
-        st = ba.new_state(T=T0)
-        st, counts = ba.solve(iters, st)
-        rec = parallel.pack_results(st.R, st.T, st.Wc, counts)
-        return parallel.gather_results(rec, total_windows), st
 
     def fence():
         torch.cuda.synchronize()
@@ -132,93 +285,62 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    launches = 2 * args.steps * sum(iters) + 8
-    ops.profile_begin(launches)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        full, st = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    prof = ops.profile_end()
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    assert torch.isfinite(full).all(), "solve produced non-finite results"
-    # the timed work is a real solve: it ends closer to the synthetic ground truth than the prior it started from
-    Tgt = gt["T"].reshape(B * pairs, 3).to(dev)
-    err0 = float((T0.reshape(B * pairs, 3) - Tgt).norm(dim=1).mean())
-    err1 = float((st.T.reshape(B * pairs, 3) - Tgt).norm(dim=1).mean())
-    Rgt = gt["R"].reshape(B * pairs, 3, 3).to(dev)
-    rot0 = float((torch.eye(3, device=dev)[None] - Rgt).flatten(1).norm(dim=1).mean())
-    rot1 = float((st.R.reshape(B * pairs, 3, 3) - Rgt).flatten(1).norm(dim=1).mean())
-    assert err1 < err0 and rot1 < rot0, "the solve did not converge towards the ground truth (%g -> %g, %g -> %g)" % (
-        err0, err1, rot0, rot1)
+    prob = Problem(B, args.frames, Hh, Ww, Kk, 1234 + rank, dev, args.reserved)
+    elapsed, prof, st = timed_run(prob, iters, args.steps, args.warmup, total_windows, fence, world, dev)
+    check = prob.convergence_check(st, dev)
 
     if rank == 0:
         iters_per_step = sum(iters)
         value = total_windows * iters_per_step * args.steps / elapsed
-        # roofline of the dominant kernel (ba_gather128_kernel): algorithmic bytes of the pass it streams
-        # / its measured time, summed over every launch of the timed region (all levels)
-        alg_bytes, kern_ms, nlaunch, per_level, syrk_ms, syrk_n = 0.0, 0.0, 0, {}, 0.0, 0
-        for li, p in enumerate(ba.problems):
-            cnt, ms = prof.get(p.N, (0, 0.0))
-            scnt, sms = prof.get(-p.N, (0, 0.0))
-            by = ba.algorithmic_bytes_per_iteration(li) * B * cnt
-            alg_bytes += by
-            kern_ms += ms
-            nlaunch += cnt
-            syrk_ms += sms
-            syrk_n += scnt
-            per_level["%dx%d" % (p.c.W, p.c.H)] = {"launches": cnt, "gather_avg_us": round(1e3 * ms / max(cnt, 1), 2),
-                                                    "syrk_avg_us": round(1e3 * sms / max(scnt, 1), 2),
-                                                    "gather_GBps": round(by / max(ms, 1e-9) / 1e6, 1)}
-        achieved = alg_bytes / max(kern_ms, 1e-9) / 1e6            # GB/s
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc) and pairs == 1 and default_shape:   # the PMC pass was taken on cfg-2
+        if os.path.exists(pmc) and headline:    # the PMC pass is taken on the headline workload
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                traffic = pj.get("hbm_bytes_per_launch") if pj.get("windows") == B else None
             except Exception:
                 traffic = None
+        rl = roofline_record(prob, prof, elapsed, traffic)
+        step_bytes = sum(prob.ba.algorithmic_bytes_per_iteration(li) for li in range(len(SCALES))) * B * args.iters
         out = {
-            "metric": "LM iterations/sec (%d-frame %dx%d 5-level dense BA, %d-coeff depth basis)" % (args.frames, Ww, Hh, Kk),
+            "metric": "LM iterations/sec (%d-frame %dx%d 5-level dense BA, %d-coeff depth basis, batch %d)" % (
+                args.frames, Ww, Hh, Kk, B),
             "value": round(value, 2), "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "ms_per_solve": round(1e3 * elapsed / args.steps / B, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("cfg-2: 2-frame 640x480 5-level pyramid, C=128, K=128 basis, 10 LM iters/level, "
-                                    "batch %d windows per GPU, BundleIteration (bundlenet.py:193-278), dense points" % B)
-                       if pairs == 1 and default_shape else
-                       ("%s: %d-frame window (key frame + %d target frames sharing depth/basis, P = %d), "
-                        "%dx%d 5-level pyramid, C=128, K=%d, %d LM iters/level, batch %d windows per GPU, dense points"
-                        % ("cfg-3" if default_shape else "custom", args.frames, pairs, 6 * pairs + Kk, Ww, Hh, Kk, args.iters, B)),
-                       "windows_total": total_windows, "iters_per_level": iters, "scales": SCALES,
+            "config": {"workload": workload_name(args.frames, B, Hh, Ww, Kk, args.iters),
+                       "windows_per_gpu": B, "windows_total": total_windows, "iters_per_level": iters, "scales": SCALES,
                        "shape": {"H": Hh, "W": Ww, "C": C, "K": Kk, "frames": args.frames},
                        "parallelism": "windows sharded, dp%d" % world},
-            "check": {"translation_error_prior": round(err0, 6), "translation_error_final": round(err1, 6),
-                      "rotation_error_prior": round(rot0, 6), "rotation_error_final": round(rot1, 6),
-                      "lambda_last_mean": round(float(st.lambda_out.mean()), 3),
-                      "note": "random-init lambda MLP and l2_regularizer_base = 1000 (bundlenet.py:393) damp every step "
-                              "heavily, so 50 iterations move the estimate only slightly; the cost per iteration does not "
-                              "depend on it"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "ba_gather128p_kernel<1> (640x480 and 320x240 levels) + ba_gather128_kernel<1> (coarser levels)",
-                         "launches": nlaunch, "avg_launch_us": round(1e3 * kern_ms / max(nlaunch, 1), 2),
-                         "algorithmic_bytes_per_launch": round(alg_bytes / max(nlaunch, 1)),
-                         "kernel_time_share": round(kern_ms / (1e3 * elapsed), 4),
-                         "syrk_kernel": {"launches": syrk_n, "avg_launch_us": round(1e3 * syrk_ms / max(syrk_n, 1), 2),
-                                         "time_share": round(syrk_ms / (1e3 * elapsed), 4)},
-                         "pipeline_GBps": round(alg_bytes / max(kern_ms + syrk_ms, 1e-9) / 1e6, 1),
-                         "per_level": per_level},
+            "check": dict(check, note="random-init lambda MLP and l2_regularizer_base = 1000 (bundlenet.py:393) damp every step "
+                                      "heavily, so 50 iterations move the estimate only slightly; correctness is the `parity` "
+                                      "record, not this"),
+            "end_to_end_hbm_frac": round(step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+            "roofline": rl,
         }
-        if world == 1 and not args.no_cpu_baseline and pairs == 1 and default_shape:
-            out["cpu_baseline"] = cpu_baseline(intr, levels, gt, mlps)
+        if world == 1:
+            if headline and not args.no_parity:
+                parity, base = parity_and_cpu_baseline(prob, dev, not args.no_cpu_baseline)
+                out["parity"] = parity
+                if base is not None:
+                    out["cpu_baseline"] = base
+            del prob, st
+            gc.collect()
+            torch.cuda.empty_cache()
+            if headline and not args.no_sweep:
+                sweep = {}
+                for name, fr, bb, stp in (("B1_2frame", 2, 1, 4), ("B8_2frame", 2, 8, 4), ("cfg3_5frame_B32", 5, 32, 2)):
+                    sweep[name] = sub_record(fr, bb, H, W, K, ITERS[0], stp, 1, 4321, dev, fence, args.reserved)
+                if args.sweep_large:
+                    sweep["B256_2frame"] = sub_record(2, 256, H, W, K, ITERS[0], 1, 1, 4321, dev, fence, args.reserved)
+                out["sweep"] = sweep
         print(json.dumps(out), flush=True)
+        if "parity" in out and not out["parity"]["ok"]:
+            print("bench.py: parity against the oracle FAILED: %s" % json.dumps(out["parity"]), file=sys.stderr, flush=True)
+            if world > 1:
+                dist.destroy_process_group()
+            sys.exit(3)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -31,7 +31,7 @@ extern "C" {
 typedef void* banet_stream_t; /* a hipStream_t (NULL = default stream) */
 #endif
 
-#define BANET_VERSION 120 /* 0.1.2: banet_sample_stats[_grad]_f32 (0.1.1: banet_level_t.pairs) */
+#define BANET_VERSION 130 /* 0.1.3: banet_lm_params_t / banet_lm_level_ex_f32 (0.1.2: banet_sample_stats[_grad]_f32; 0.1.1: banet_level_t.pairs) */
 
 enum {
   BANET_OK = 0,
@@ -171,6 +171,33 @@ size_t banet_lm_level_workspace_bytes(const banet_level_t* lv);
 int banet_lm_level_f32(const banet_level_t* lv, const banet_mlp_t* mlp, float l2_base,
                        int max_iters, int early_termination, banet_state_t* st, void* ws,
                        size_t ws_bytes, banet_stream_t stream);
+
+/* (5b) the same loop with the reference's run-time LM configuration.  legacy/ba.py:5-9 keeps
+ *     early_termination / angle_change / translation_change / residual_ratio / qr as module
+ *     globals that its drivers overwrite (legacy/example.py:8, legacy/eval.py:9); here they are
+ *     arguments.  banet_lm_level_f32 == banet_lm_level_ex_f32 with params = NULL (the
+ *     reference's defaults, banet_lm_params_default).
+ *       angle_change, translation_change : loop continues while both update norms exceed them
+ *                                          (legacy/ba.py:133); only read with early_termination
+ *       residual_ratio                   : accept iff avg' < residual_ratio * avg (ba.py:343)
+ *       solver (legacy variants only)    : BANET_SOLVER_QR  = tf.qr + triangular solve
+ *                                          (ba.py:205-206,292-293, `qr = True`);
+ *                                          BANET_SOLVER_INVERSE = tf.matrix_inverse (LU with
+ *                                          partial pivoting) then a product (ba.py:203,290,
+ *                                          `qr = False`).  The bundlenet variants always use
+ *                                          tf.matrix_solve's algorithm class (bundlenet.py:183,
+ *                                          267) and ignore this field.                        */
+enum { BANET_SOLVER_QR = 0, BANET_SOLVER_INVERSE = 1 };
+typedef struct banet_lm_params {
+  float angle_change;       /* legacy/ba.py:6  default 0.002 * (3.14 / 180)                   */
+  float translation_change; /* legacy/ba.py:7  default 0.0002                                 */
+  float residual_ratio;     /* legacy/ba.py:8  default 1.0                                    */
+  int32_t solver;           /* legacy/ba.py:9  default BANET_SOLVER_QR                        */
+} banet_lm_params_t;
+void banet_lm_params_default(banet_lm_params_t* params);
+int banet_lm_level_ex_f32(const banet_level_t* lv, const banet_mlp_t* mlp, float l2_base,
+                          int max_iters, int early_termination, const banet_lm_params_t* params,
+                          banet_state_t* st, void* ws, size_t ws_bytes, banet_stream_t stream);
 
 /* (6) per-level preparation -- the step immediately before the LM loop.
  *   banet_resample_f32   data [B,H,W,C], warp [B,N,2] (x,y) -> out [B,N,C]

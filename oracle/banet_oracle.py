@@ -617,6 +617,43 @@ def bundle_window_iteration(conv1, conv2s, fx, fy, ox, oy, p, D, Bs, Rs, Ts, W, 
     return Rn, Tn, Wn, dict(AtA=AtA0, Atb=Atb, lam=lam, avg=avg, solution=sol, mask=masks)
 
 
+# --------------------------------------------------------------------------------------
+# losses                                                          bundlenet.py:401-463
+# --------------------------------------------------------------------------------------
+def loss_r(predQ, gtQ):
+    """bundlenet.py:401-404: tf.losses.cosine_distance(predQ, gtQ, axis=1) = mean_b (1 - <predQ_b, gtQ_b>)."""
+    dt = predQ.dtype.type
+    return np.mean(dt(1.0) - np.sum(predQ * gtQ, axis=1))
+
+
+def loss_t(predT, gtT):
+    """bundlenet.py:410-412 (the second `lossT` definition overrides the cosine one at :405-408)."""
+    return np.mean(np.abs(predT - gtT))
+
+
+def loss_f(intrisic, depth, mask, predR, predT, gtR, gtT):
+    """bundlenet.py:414-463: masked mean absolute flow difference between the predicted and the ground-truth pose,
+    crop-adjusted intrinsics (:441-445), unit rays of the integer pixel grid (:447-452), BOTH terms divided by the
+    width (:462-463, as the reference has it), scaled by total / valid pixel count."""
+    dt = depth.dtype.type
+    nb, H, W = depth.shape[0], depth.shape[1], depth.shape[2]
+    N = H * W
+    m = mask.reshape(nb, N)
+    fx, fy, ox, oy = _crop_intrinsics(intrisic, N)
+    xs, ys = np.meshgrid(np.arange(W), np.arange(H))
+    pts = np.tile(np.stack([xs.reshape(-1), ys.reshape(-1)], -1).astype(depth.dtype)[None], (nb, 1, 1))
+    p = compute_coordinates(pts, fx, fy, ox, oy, normalize=True)
+
+    def flow(R, T):
+        X = np.matmul(R, p) * depth.reshape(nb, 1, N) + T.reshape(nb, 3, 1)
+        return fx * (X[:, 0] / X[:, 2]) + ox, fy * (X[:, 1] / X[:, 2]) + oy
+
+    fxp, fyp = flow(predR, predT)
+    fxg, fyg = flow(gtR, gtT)
+    valid, total = np.sum(m), dt(N * nb)
+    return (total / valid) * (np.mean(np.abs(fxp - fxg) * m) / dt(W) + np.mean(np.abs(fyp - fyg) * m) / dt(W))
+
+
 def _crop_intrinsics(intrisic, N):
     """bundlenet.py:298-302 / :354-357 (crop 4 px, rescale to 320x256)."""
     dt = intrisic.dtype.type

@@ -71,10 +71,11 @@ def solve_bundle(intr, levels, mlps, iters, l2_base=1000.0, dtype=np.float32, po
     return R, T, W, hist
 
 
-def solve_legacy(intr, levels, mlps, iters, early_termination=True, dtype=np.float32):
+def solve_legacy(intr, levels, mlps, iters, early_termination=True, dtype=np.float32, use_qr=True):
     """Dense legacy tracker (legacy/ba.py CameraIteration2 / CameraIteration), one window at a
     time (the reference's accept/reject is scalar).  Returns R [B,3,3], T [B,3,1], ratio [B],
-    counts [levels][B]."""
+    counts [levels][B].  The loop thresholds / residual ratio are the module constants of banet_oracle
+    (legacy/ba.py:6-8), read at call time; use_qr = legacy/ba.py:9."""
     B = levels[0]["src"].shape[0]
     Rs, Ts, ratios, counts = [], [], [], [[0] * B for _ in levels]
     for b in range(B):
@@ -89,12 +90,12 @@ def solve_legacy(intr, levels, mlps, iters, early_termination=True, dtype=np.flo
                 uw = ut = dtype(1.0)
                 while it < n_it and orc.ANGLE_CHANGE < uw and orc.TRANSLATION_CHANGE < ut:
                     R, T, uw, ut, ratio, _ = orc.legacy_camera_iteration2(a["conv1"], a["conv2"], a["fx"], a["fy"],
-                                                                          a["ox"], a["oy"], a["p"], a["D"], R, T, mlps[li])
+                                                                          a["ox"], a["oy"], a["p"], a["D"], R, T, mlps[li], use_qr)
                     it += 1
             else:
                 for _ in range(n_it):
                     R, T, ratio = orc.legacy_camera_iteration(a["conv1"], a["conv2"], a["fx"], a["fy"], a["ox"],
-                                                              a["oy"], a["p"], a["D"], R, T)
+                                                              a["oy"], a["p"], a["D"], R, T, use_qr)
                     it += 1
             counts[li][b] = it
         Rs.append(R[0])
@@ -108,7 +109,7 @@ def batch_window_scene(scenes):
     return batch_scene(scenes)
 
 
-def solve_bundle_window(intr, levels, mlps, iters, l2_base=1000.0, dtype=np.float32, R0=None, T0=None):
+def solve_bundle_window(intr, levels, mlps, iters, l2_base=1000.0, dtype=np.float32, R0=None, T0=None, eq=None):
     """Fixed-count dense multi-frame window BA (banet_oracle.bundle_window_iteration).  levels[i]["tgt"] is
     [B,pairs,H,W,C].  Returns (Rs [pairs][B,3,3], Ts [pairs][B,3,1], W, hist)."""
     B, pairs = levels[0]["tgt"].shape[:2]
@@ -124,7 +125,57 @@ def solve_bundle_window(intr, levels, mlps, iters, l2_base=1000.0, dtype=np.floa
         conv2s = [orc.target_map(lv["tgt"][:, i].astype(dtype)) for i in range(pairs)]
         for _ in range(n_it):
             Rs, Ts, W, dbg = orc.bundle_window_iteration(a["conv1"], conv2s, a["fx"], a["fy"], a["ox"], a["oy"], a["p"],
-                                                         a["D"], a["Bs"], Rs, Ts, W, mlps[li], l2_base)
+                                                         a["D"], a["Bs"], Rs, Ts, W, mlps[li], l2_base, eq=eq)
             hist.append(dict(level=li, delta=dbg["solution"][:, :, 0], lam=dbg["lam"], AtA=dbg["AtA"], Atb=dbg["Atb"],
                              avg=dbg["avg"]))
     return Rs, Ts, W, hist
+
+
+def bundle_chain(intr, levels, mlps, iters, R0, T0, W0, l2_base=1000.0, dtype=np.float32, engine="numpy"):
+    """A chained coarse->fine dense bundle solve that records the state after every level -- the sequence bench.py
+    times as the CPU baseline AND compares the GPU solve with (parity at BASELINE's full size).
+    engine "numpy": oracle.banet_oracle.bundle_iteration (GEMM-arranged normal equations);
+    engine "torch": oracle.torch_port.bundle_iteration (float32, all host threads).
+    Returns (snaps, seconds): snaps[l] = dict(R, T, W, delta, lam) after level l's last iteration (delta / lam of that
+    iteration); seconds = time spent inside the iterations (per-level preparation excluded)."""
+    import time
+    R, T, W = R0.astype(dtype), T0.astype(dtype), W0.astype(dtype)
+    snaps, total = [], 0.0
+    for li, (lv, n_it) in enumerate(zip(levels, iters)):
+        if engine == "numpy":
+            a = level_inputs(intr, lv, True, dtype)
+            t0 = time.perf_counter()
+            for _ in range(n_it):
+                R, T, W, dbg = orc.bundle_iteration(a["conv1"], a["conv2"], a["fx"], a["fy"], a["ox"], a["oy"], a["p"], a["D"],
+                                                    a["Bs"], R, T, W, mlps[li], l2_base, eq=orc.equation_construction_gemm)
+            total += time.perf_counter() - t0
+            snaps.append(dict(R=R.copy(), T=T.copy(), W=W.copy(), delta=dbg["solution"][:, :, 0].copy(),
+                              lam=np.asarray(dbg["lam"]).reshape(-1).copy()))
+        else:
+            import torch
+            from . import torch_port
+            f = lambda x: torch.from_numpy(np.ascontiguousarray(x))  # noqa: E731
+            ti, src, tgt, dep, bas = f(intr), f(lv["src"]), f(lv["tgt"]), f(lv["D0"]), f(lv["basis"])
+            Rt, Tt, Wt = f(R), f(T), f(W)
+            t0 = time.perf_counter()
+            for _ in range(n_it):
+                Rt, Tt, Wt, dbg = torch_port.bundle_iteration(ti, float(lv["scale"]), src, tgt, dep, bas, Rt, Tt, Wt, mlps[li],
+                                                              l2_base)
+            total += time.perf_counter() - t0
+            R, T, W = Rt.numpy(), Tt.numpy(), Wt.numpy()
+            snaps.append(dict(R=R.copy(), T=T.copy(), W=W.copy(), delta=dbg["solution"][:, :, 0].numpy().copy(),
+                              lam=dbg["lam"].numpy().copy()))
+    return snaps, total
+
+
+def chain_parity(gpu_snaps, ref_snaps):
+    """Per-level parity record of a GPU chain against bundle_chain's snapshots: relative errors (max-abs difference over
+    the max-abs of the reference quantity) of the level's last solved update (pose / depth part) and of the carried state."""
+    def rel(a, b):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    out = []
+    for g, r in zip(gpu_snaps, ref_snaps):
+        out.append(dict(delta_pose=rel(g["delta"][:, :6], r["delta"][:, :6]), delta_depth=rel(g["delta"][:, 6:], r["delta"][:, 6:]),
+                        R=rel(g["R"], r["R"]), T=rel(g["T"], r["T"]), W=rel(g["W"], r["W"]), lam=rel(g["lam"], r["lam"])))
+    return out

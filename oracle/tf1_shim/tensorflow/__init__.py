@@ -294,6 +294,24 @@ nn = types.SimpleNamespace(selu=_selu, elu=_elu, tanh=lambda x: _t(np.tanh(x)), 
                            l2_normalize=_l2_normalize)
 
 
+# ---- tf.losses / tf.meshgrid (bundlenet.py:401-463) ---------------------------------------
+def _cosine_distance(labels, predictions, axis=None, dim=None):
+    """tf.losses.cosine_distance (TF 1.x): losses = 1 - sum(labels * predictions, axis, keepdims), reduced with the
+    default Reduction.SUM_BY_NONZERO_WEIGHTS and weights = 1, i.e. the mean over the elements of `losses`."""
+    axis = axis if axis is not None else dim
+    l = np.float32(1.0) - np.sum(np.asarray(labels) * np.asarray(predictions), axis=axis, keepdims=True)
+    return _t(np.sum(l, dtype=np.float32) / np.float32(l.size))
+
+
+losses = types.SimpleNamespace(cosine_distance=_cosine_distance)
+
+
+def meshgrid(x, y):
+    """tf.meshgrid with the default indexing='xy'"""
+    X, Y = np.meshgrid(np.asarray(x), np.asarray(y))
+    return _t(X), _t(Y)
+
+
 # ---- tf.contrib.resampler -------------------------------------------------------------
 def _resampler(data, warp, name=None):
     """Bilinear resampling with ZERO padding outside the image (published semantics of

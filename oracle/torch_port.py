@@ -1,0 +1,148 @@
+"""torch-CPU restatement of the dense BundleIteration (bundlenet.py:193-278 on every pixel of a level)  --  TEST
+INFRASTRUCTURE ONLY (the product path never imports it).
+
+Two uses:
+  * `dense_assemble(..., dtype=torch.float64)`: the float64 twin that lets the 640x480 / K=128 sizes of BASELINE.json be
+    checked on the GPU box in seconds (tests/test_gpu_parity.py); validated against the numpy oracle on CPU at small
+    sizes (tests/test_torch_ref_cpu.py);
+  * `bundle_iteration(..., dtype=torch.float32)`: the same iteration in the reference's float32 with torch's intra-op
+    thread pool = all host cores -- the "honest" CPU baseline of SURVEY.md 8(d) that bench.py times next to the numpy
+    port (whose elementwise work is single-threaded).  It never materialises J [B,N,2,P] (the normal equations are
+    formed from the per-pixel 2x2 M = G^T G like utils.cu's result, not like its 22 GB scratch), so it is an
+    OPTIMISED port: the fair comparison for a GPU number.
+Citations as in oracle/banet_oracle.py (same statements, torch instead of numpy).
+"""
+import math
+
+import torch
+
+
+def grad_fixed(img):
+    """bundlenet.py:92-100; img [B,H,W,C]"""
+    H, W = img.shape[1], img.shape[2]
+    p = torch.nn.functional.pad(img.permute(0, 3, 1, 2), (1, 1, 1, 1), mode="reflect").permute(0, 2, 3, 1)
+    gx = 0.5 * (p[:, 1:H + 1, 2:W + 2, :] - p[:, 1:H + 1, 0:W, :])
+    gy = 0.5 * (p[:, 2:H + 2, 1:W + 1, :] - p[:, 0:H, 1:W + 1, :])
+    return gx, gy
+
+
+def _gather(flat, W, yy, xx):
+    C = flat.shape[-1]
+    return torch.gather(flat, 1, (yy * W + xx).unsqueeze(-1).expand(-1, -1, C))
+
+
+def dense_assemble(intr, scale, src, tgt, depth, basis, R, T, Wc, bundle, normalize_rays, dtype=torch.float64):
+    """-> AtA [B,P,P], Atb [B,P], absres [B,C], nvalid [B]   (P = 6 + K)."""
+    B, H, W, C = tgt.shape
+    N = H * W
+    dev = tgt.device
+    f = lambda x: x.to(dtype)  # noqa: E731
+    src, tgt, depth, R, T, intr = f(src), f(tgt), f(depth).reshape(B, N), f(R).reshape(B, 3, 3), f(T).reshape(B, 3, 1), f(intr)
+    K = 0 if basis is None else basis.shape[-1]
+    vv, uu = torch.meshgrid(torch.arange(H, dtype=dtype, device=dev), torch.arange(W, dtype=dtype, device=dev),
+                            indexing="ij")
+    fx0, fy0, ox0, oy0 = [intr[:, i:i + 1] for i in range(4)]
+    u, v = (uu.reshape(1, N) * scale), (vv.reshape(1, N) * scale)
+    p = torch.stack([(u - ox0) / fx0, (v - oy0) / fy0, torch.ones(B, N, dtype=dtype, device=dev)], dim=1)
+    if normalize_rays:
+        p = p / torch.sqrt(torch.clamp((p * p).sum(1, keepdim=True), min=1e-12))
+    fx, fy, ox, oy = fx0 / scale, fy0 / scale, ox0 / scale, oy0 / scale
+    D = depth
+    if K > 0:
+        Bs = f(basis).reshape(B, N, K)
+        D = D + torch.matmul(Bs, f(Wc).reshape(B, K, 1))[..., 0]
+    Rp = torch.matmul(R, p)
+    X = Rp * D.unsqueeze(1) + T
+    x, y, Z = X[:, 0] / X[:, 2], X[:, 1] / X[:, 2], X[:, 2]
+    px, py = fx * x + ox, fy * y + oy
+    mask = ((px >= 0) & (px <= W - 1) & (py >= 0) & (py <= H - 1)).to(dtype)
+    pxs = torch.where(mask > 0, px, torch.zeros_like(px))
+    pys = torch.where(mask > 0, py, torch.zeros_like(py))
+    x0f, y0f = torch.floor(pxs), torch.floor(pys)
+    dx, dy = pxs - x0f, pys - y0f
+    x0, y0 = x0f.long(), y0f.long()
+    x1, y1 = (x0 + 1).clamp(0, W - 1), (y0 + 1).clamp(0, H - 1)
+    x0, y0 = x0.clamp(0, W - 1), y0.clamp(0, H - 1)
+    gxm, gym = grad_fixed(tgt)
+    w00, w01, w10, w11 = (1 - dx) * (1 - dy), dx * (1 - dy), (1 - dx) * dy, dx * dy
+
+    def samp(m):
+        fl = m.reshape(B, N, C)
+        return (_gather(fl, W, y0, x0) * w00.unsqueeze(-1) + _gather(fl, W, y0, x1) * w01.unsqueeze(-1)
+                + _gather(fl, W, y1, x0) * w10.unsqueeze(-1) + _gather(fl, W, y1, x1) * w11.unsqueeze(-1))
+
+    mk = mask.unsqueeze(-1)
+    F2w, gx, gy = samp(tgt), samp(gxm) * mk, samp(gym) * mk
+    d = (F2w - src.reshape(B, N, C)) * mk                     # legacy sign
+    zero = torch.zeros_like(x)
+    iz = 1.0 / Z
+    Jx = fx.unsqueeze(-1) * torch.stack([x * y, -1 - x * x, y, -iz, zero, x / Z], dim=-1)
+    Jy = fy.unsqueeze(-1) * torch.stack([1 + y * y, -x * y, -x, zero, -iz, y / Z], dim=-1)
+    Jx, Jy = Jx * mk, Jy * mk
+    if bundle:                                               # bundlenet.py:60,234: J = [-Jc | jd b], d = F1 - F2w
+        d = -d
+        Jx, Jy = -Jx, -Jy
+        if K > 0:
+            jd0 = fx * ((Rp[:, 0] - Rp[:, 2] * x) / Z) * mask
+            jd1 = fy * ((Rp[:, 1] - Rp[:, 2] * y) / Z) * mask
+            Jx = torch.cat([Jx, jd0.unsqueeze(-1) * Bs], dim=-1)
+            Jy = torch.cat([Jy, jd1.unsqueeze(-1) * Bs], dim=-1)
+    Jx = torch.nan_to_num(Jx)
+    Jy = torch.nan_to_num(Jy)
+    m11, m12, m22 = (gx * gx).sum(-1), (gx * gy).sum(-1), (gy * gy).sum(-1)
+    g1, g2 = (gx * d).sum(-1), (gy * d).sum(-1)
+    Zx = m11.unsqueeze(-1) * Jx + m12.unsqueeze(-1) * Jy
+    Zy = m12.unsqueeze(-1) * Jx + m22.unsqueeze(-1) * Jy
+    AtA = torch.matmul(Zx.transpose(1, 2), Jx) + torch.matmul(Zy.transpose(1, 2), Jy)
+    Atb = (Jx * g1.unsqueeze(-1) + Jy * g2.unsqueeze(-1)).sum(1)
+    return AtA, Atb, d.abs().sum(1), mask.sum(1)
+
+
+_SELU_A, _SELU_S = 1.6732632423543772848170429916717, 1.0507009873554804934193349852946
+
+
+def lambda_mlp(avg, weights):
+    """bundlenet.py:168-172,245-248: five k=1 conv layers, selu x4 then tanh.  avg [B,1,C]"""
+    h = avg
+    for i, (w, b) in enumerate(weights):
+        z = torch.matmul(h, torch.as_tensor(w, dtype=h.dtype)) + torch.as_tensor(b, dtype=h.dtype)
+        h = torch.tanh(z) if i == 4 else _SELU_S * torch.where(z > 0, z, _SELU_A * (torch.exp(z) - 1))
+    return h
+
+
+def _rodrigues(w):
+    """bundlenet.py:17-37 (theta clamped at 1e-6) and VMatrix :39-46 per item; w [B,3]"""
+    th = torch.sqrt((w * w).sum(-1))
+    thc = torch.clamp(th, min=1e-6)
+    k = w / thc[:, None]
+    c, s = torch.cos(thc)[:, None, None], torch.sin(thc)[:, None, None]
+    z = torch.zeros_like(th)
+    Kn = torch.stack([z, -k[:, 2], k[:, 1], k[:, 2], z, -k[:, 0], -k[:, 1], k[:, 0], z], -1).reshape(-1, 3, 3)
+    eye = torch.eye(3, dtype=w.dtype)[None]
+    Rw = c * eye + (1 - c) * k[:, :, None] * k[:, None, :] + s * Kn
+    Kw = torch.stack([z, -w[:, 2], w[:, 1], w[:, 2], z, -w[:, 0], -w[:, 1], w[:, 0], z], -1).reshape(-1, 3, 3)
+    a = ((1 - torch.cos(th)) / (th * th))[:, None, None]
+    bq = ((th - torch.sin(th)) / (th * th * th))[:, None, None]
+    V = eye + a * Kw + bq * torch.matmul(Kw, Kw)
+    return Rw, V
+
+
+def bundle_iteration(intr, scale, src, tgt, depth, basis, R, T, Wc, mlp, l2_base=1000.0, dtype=torch.float32):
+    """One dense BundleIteration -> (R', T', W', dict(lam, solution)).  Shapes as dense_assemble; Wc [B,K,1]."""
+    B, H, W, C = tgt.shape
+    N = H * W
+    AtA, Atb, absres, _nv = dense_assemble(intr, scale, src, tgt, depth, basis, R, T, Wc, True, True, dtype)
+    avg = (absres / N).unsqueeze(1)                                              # :243
+    y = lambda_mlp(avg, mlp)
+    lam = torch.sqrt((avg * avg).sum(-1, keepdim=True)) ** (2.0 + y)             # :249
+    lam = l2_base * lam                                                          # :252-253
+    diag = torch.diagonal(AtA, dim1=1, dim2=2)
+    damp = torch.cat([(diag[:, :-1] + 1e-5) * lam[:, 0], torch.zeros(B, 1, dtype=dtype)], dim=-1)   # :264-266
+    sol = torch.linalg.solve(AtA + torch.diag_embed(damp), Atb.unsqueeze(-1))    # :267
+    Rw, V = _rodrigues(sol[:, 0:3, 0])
+    R = R.to(dtype).reshape(B, 3, 3)
+    T = T.to(dtype).reshape(B, 3, 1)
+    Rn = torch.matmul(Rw, R)
+    Tn = torch.matmul(V, sol[:, 3:6]) + torch.matmul(Rw, T)
+    Wn = Wc.to(dtype).reshape(B, -1, 1) + sol[:, 6:]
+    return Rn, Tn, Wn, dict(lam=lam.reshape(-1), solution=sol)

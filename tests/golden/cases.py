@@ -131,3 +131,21 @@ def case_resize(seed=505, C=4, K=3, N=256):
     intr = np.tile(raw.reshape(1, 4, 1), (2, 1, 1))
     return dict(layers=layers, basis=basis, depth=depth, points=pts, intr=intr,
                 mlp=mlp_weights(C, ["0", "1", "2", "3"], seed))
+
+
+def case_losses(seed=606):
+    """BundleNet.lossR / lossT / lossF (bundlenet.py:401-463): B = 2, a 12 x 16 depth map with a partial mask."""
+    rng = np.random.RandomState(seed)
+    B, H, W = 2, 12, 16
+    q = rng.standard_normal((B, 4)).astype(F32)
+    predQ = q / np.linalg.norm(q, axis=1, keepdims=True)
+    q2 = q + 0.05 * rng.standard_normal((B, 4)).astype(F32)
+    gtQ = (q2 / np.linalg.norm(q2, axis=1, keepdims=True)).astype(F32)
+    predT = (rng.uniform(-1, 1, (B, 3)) * 0.1).astype(F32)
+    gtT = (predT + rng.uniform(-1, 1, (B, 3)) * 0.01).astype(F32)
+    predR = np.concatenate([small_rotation(rng, 0.03) for _ in range(B)], 0)
+    gtR = np.concatenate([small_rotation(rng, 0.03) for _ in range(B)], 0)
+    depth = rng.uniform(1.5, 3.0, (B, H, W, 1)).astype(F32)
+    mask = (rng.uniform(0, 1, (B, H, W, 1)) > 0.3).astype(F32)
+    intr = np.tile(np.array([0.8 * W, 0.8 * W, W / 2.0, H / 2.0], F32).reshape(1, 4, 1), (B, 1, 1))
+    return dict(predQ=predQ.astype(F32), gtQ=gtQ, predT=predT, gtT=gtT, predR=predR, gtR=gtR, depth=depth, mask=mask, intr=intr)

@@ -191,6 +191,18 @@ def gen_resize(bn):
     print("resize ok")
 
 
+def gen_losses(bn):
+    c = cases.case_losses()
+    net = bn.BundleNet()
+    cv = tf.convert
+    lr = net.lossR(cv(c["predQ"]), cv(c["gtQ"]))
+    lt = net.lossT(cv(c["predT"]), cv(c["gtT"]))          # the second definition (bundlenet.py:410-412) is the live one
+    lf = net.lossF(cv(c["intr"]), cv(c["depth"]), cv(c["mask"]), cv(c["predR"]), cv(c["predT"]), cv(c["gtR"]),
+                   cv(c["gtT"]))
+    np.savez(os.path.join(HERE, "golden_losses.npz"), lossR=A(lr), lossT=A(lt), lossF=A(lf))
+    print("losses: R %.6g  T %.6g  F %.6g" % (A(lr), A(lt), A(lf)))
+
+
 if __name__ == "__main__":
     ba, bn = load_all()
     gen_legacy_ci2(ba)
@@ -198,3 +210,4 @@ if __name__ == "__main__":
     gen_bundle_fns(ba, bn)
     gen_bundle_iter(bn)
     gen_resize(bn)
+    gen_losses(bn)

@@ -40,7 +40,7 @@ def test_every_declared_symbol_is_exported(capi):
 
 def test_version_and_error_strings(capi):
     L = capi.lib()
-    assert L.banet_version() == 120
+    assert L.banet_version() == 130
     assert L.banet_error_string(0) == b"ok"
     assert b"workspace" in L.banet_error_string(-2)
 
@@ -59,6 +59,70 @@ def test_struct_layouts_match_the_header(capi, tmp_path):
     want = [ctypes.sizeof(capi.Level), capi.Level.scale.offset, capi.Level.src.offset, capi.Level.intr.offset,
             ctypes.sizeof(capi.Mlp), ctypes.sizeof(capi.State), capi.State.iters.offset, capi.Level.variant.offset, capi.Level.pairs.offset]
     assert got == want
+    prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "banet_hip.h"\n'
+                    'int main(){printf("%zu %zu %zu\\n", sizeof(banet_lm_params_t), offsetof(banet_lm_params_t, residual_ratio), '
+                    'offsetof(banet_lm_params_t, solver));return 0;}\n')
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert got == [ctypes.sizeof(capi.LmParams), capi.LmParams.residual_ratio.offset, capi.LmParams.solver.offset]
+
+
+def test_lm_params_defaults_are_the_reference_globals(capi):
+    """banet_lm_params_default == legacy/ba.py:5-9; banet_lm_level_ex_f32 validates the struct before touching the GPU"""
+    from banet_amd import ops, legacy
+    p = ops.lm_params()
+    assert abs(p.angle_change - 0.002 * (3.14 / 180.0)) < 1e-12 and abs(p.translation_change - 0.0002) < 1e-10
+    assert p.residual_ratio == 1.0 and p.solver == capi.SOLVER_QR
+    assert ops.lm_params(qr=False).solver == capi.SOLVER_INVERSE
+    # the module globals of banet_amd.legacy are read at call time (the reference's drivers overwrite them)
+    old = legacy.angle_change, legacy.qr
+    try:
+        legacy.angle_change, legacy.qr = 0.5, False
+        q = legacy._params()
+        assert q.angle_change == 0.5 and q.solver == capi.SOLVER_INVERSE
+    finally:
+        legacy.angle_change, legacy.qr = old
+    L = capi.lib()
+    lv = capi.Level()
+    lv.B, lv.N, lv.C, lv.K, lv.H, lv.W = 1, 64, 8, 0, 8, 8
+    lv.variant, lv.dense = capi.LEGACY_LM, 0
+    assert L.banet_lm_level_ex_f32(ctypes.byref(lv), None, 1.0, 1, 1, ctypes.byref(p), None, None, 0, None) == -1
+
+
+def test_lambda_mlp_shapes_are_checked_before_launch(capi):
+    """the solve kernel reads the MLP with fixed extents C -> 2C -> 4C -> 2C -> C -> 1; weights for another C
+    must be refused on the host, not read out of bounds on the device."""
+    import torch
+    from banet_amd import ops
+    from banet_amd.bundlenet import he_normal_lambda_weights
+    good = ops.MlpWeights(he_normal_lambda_weights(8, 1), "cpu")
+    good.check(8)
+    with pytest.raises(capi.BanetError):
+        good.check(16)                                      # weights of a C = 8 level offered to a C = 16 level
+    bad = he_normal_lambda_weights(8, 1)
+    bad[2] = (torch.zeros(32, 8), torch.zeros(8))           # chains (32 -> 8 -> ...) but is not 4C -> 2C
+    bad[3] = (torch.zeros(8, 8), torch.zeros(8))
+    with pytest.raises(capi.BanetError):
+        ops.MlpWeights(bad, "cpu")
+
+
+def test_mlp_cache_follows_weight_updates():
+    """reassigned or in-place-updated lambda weights must not leave a stale device copy behind"""
+    import torch
+    from banet_amd import ops
+    from banet_amd.bundlenet import he_normal_lambda_weights
+    lw = {"0": he_normal_lambda_weights(4, 3)}
+    cache = ops.MlpCache()
+    m1 = cache.get(lw, 0, "cpu")
+    assert cache.get(lw, "0", "cpu") is m1                  # unchanged -> cached
+    lw["0"][0][0].mul_(2.0)                                 # in-place update (optimizer step)
+    m2 = cache.get(lw, 0, "cpu")
+    assert m2 is not m1 and torch.equal(m2.w[0], lw["0"][0][0])
+    lw["0"] = he_normal_lambda_weights(4, 9)                # checkpoint reload
+    m3 = cache.get(lw, 0, "cpu")
+    assert m3 is not m2 and torch.equal(m3.w[4], lw["0"][4][0])
+    with pytest.raises(KeyError):
+        cache.get(lw, 7, "cpu")
 
 
 def test_argument_validation_without_gpu(capi):
@@ -137,4 +201,4 @@ def test_plain_c_program_links_against_the_library(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
                            "-L", libdir, "-lbanet_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.check_output([str(exe)]).decode()
-    assert out.startswith("c-abi ok 120")
+    assert out.startswith("c-abi ok 130")
