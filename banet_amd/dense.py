@@ -73,6 +73,13 @@ class DenseBA:
                                       delta=st.delta.clone(), lam=st.lambda_out.clone()))
         return st, counts
 
+    def step_from(self, level_index, R, T, Wc=None):
+        """ONE iteration of level `level_index` from the given state -> (state after it; .delta / .lambda_out hold the
+        solved update and lambda).  Used by the parity checks to compare single updates from identical states."""
+        st = self.new_state(R, T, Wc)
+        ops.lm_level(self.problems[level_index], self.mlps[level_index], self.l2_base, 1, False, st, ws=self.ws)
+        return st
+
     def algorithmic_bytes_per_iteration(self, level_index):
         """4*N_l*(C*F + K + 1) per window-iteration (F = 1 + pairs frames)."""
         p = self.problems[level_index]

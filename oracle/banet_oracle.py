@@ -700,11 +700,14 @@ def camera_resize(intrisic, layers, points, depths, mlps):
 
 
 def bundle_resize(intrisic, layers, points, basis, init_depth, mlps, init_rotation=None,
-                  init_translation=None):
-    """BundleNet.BundleResize, bundlenet.py:332-399: levels 2,3 (scale 2,1) x 1 iter."""
+                  init_translation=None, stop_gradient_depth=None):
+    """BundleNet.BundleResize, bundlenet.py:332-399: levels 2,3 (scale 2,1) x 1 iter.
+    stop_gradient_depth: the value `depths = tf.stop_gradient(init_depth)` (bundlenet.py:341) holds -- numerically
+    init_depth, but a finite-difference gradient check must keep it fixed while init_depth is perturbed (default:
+    init_depth itself, i.e. the forward value)."""
     dt = points.dtype
     _pts = _crop_points(points)
-    d = resampler(init_depth, _pts / dt.type(2))
+    d = resampler(init_depth if stop_gradient_depth is None else stop_gradient_depth, _pts / dt.type(2))
     b = resampler(basis, _pts / dt.type(2))
     B = layers[-1].shape[0]
     N = points.shape[1]

@@ -12,8 +12,6 @@ Two uses:
     OPTIMISED port: the fair comparison for a GPU number.
 Citations as in oracle/banet_oracle.py (same statements, torch instead of numpy).
 """
-import math
-
 import torch
 
 
@@ -26,31 +24,37 @@ def grad_fixed(img):
     return gx, gy
 
 
-def _gather(flat, W, yy, xx):
-    C = flat.shape[-1]
-    return torch.gather(flat, 1, (yy * W + xx).unsqueeze(-1).expand(-1, -1, C))
-
-
-def dense_assemble(intr, scale, src, tgt, depth, basis, R, T, Wc, bundle, normalize_rays, dtype=torch.float64):
-    """-> AtA [B,P,P], Atb [B,P], absres [B,C], nvalid [B]   (P = 6 + K)."""
+def prepare_level(intr, scale, src, tgt, depth, basis, normalize_rays=True, dtype=torch.float32):
+    """Everything about a level that does not change between iterations (the reference builds these once per level too:
+    bundlenet.py:376-385): rays, level intrinsics, the [f|gx|gy] target map as rows [B,N,3C], flat source / basis."""
     B, H, W, C = tgt.shape
     N = H * W
     dev = tgt.device
     f = lambda x: x.to(dtype)  # noqa: E731
-    src, tgt, depth, R, T, intr = f(src), f(tgt), f(depth).reshape(B, N), f(R).reshape(B, 3, 3), f(T).reshape(B, 3, 1), f(intr)
-    K = 0 if basis is None else basis.shape[-1]
-    vv, uu = torch.meshgrid(torch.arange(H, dtype=dtype, device=dev), torch.arange(W, dtype=dtype, device=dev),
-                            indexing="ij")
+    src, tgt, depth, intr = f(src), f(tgt), f(depth).reshape(B, N), f(intr)
+    vv, uu = torch.meshgrid(torch.arange(H, dtype=dtype, device=dev), torch.arange(W, dtype=dtype, device=dev), indexing="ij")
     fx0, fy0, ox0, oy0 = [intr[:, i:i + 1] for i in range(4)]
     u, v = (uu.reshape(1, N) * scale), (vv.reshape(1, N) * scale)
     p = torch.stack([(u - ox0) / fx0, (v - oy0) / fy0, torch.ones(B, N, dtype=dtype, device=dev)], dim=1)
     if normalize_rays:
         p = p / torch.sqrt(torch.clamp((p * p).sum(1, keepdim=True), min=1e-12))
-    fx, fy, ox, oy = fx0 / scale, fy0 / scale, ox0 / scale, oy0 / scale
-    D = depth
+    gxm, gym = grad_fixed(tgt)
+    tmap = torch.cat([tgt, gxm, gym], dim=-1).reshape(B, N, 3 * C)
+    K = 0 if basis is None else basis.shape[-1]
+    return dict(B=B, H=H, W=W, C=C, N=N, K=K, p=p, fx=fx0 / scale, fy=fy0 / scale, ox=ox0 / scale, oy=oy0 / scale,
+                tmap=tmap, src=src.reshape(B, N, C), depth=depth, basis=f(basis).reshape(B, N, K) if K > 0 else None)
+
+
+def assemble_prepared(L, R, T, Wc, bundle):
+    """-> AtA [B,P,P], Atb [B,P], absres [B,C], nvalid [B] at the pose (R, T, Wc); L = prepare_level(...)"""
+    B, H, W, C, N, K = L["B"], L["H"], L["W"], L["C"], L["N"], L["K"]
+    dtype = L["tmap"].dtype
+    p, fx, fy, ox, oy = L["p"], L["fx"], L["fy"], L["ox"], L["oy"]
+    R, T = R.to(dtype).reshape(B, 3, 3), T.to(dtype).reshape(B, 3, 1)
+    D = L["depth"]
+    Bs = L["basis"]
     if K > 0:
-        Bs = f(basis).reshape(B, N, K)
-        D = D + torch.matmul(Bs, f(Wc).reshape(B, K, 1))[..., 0]
+        D = D + torch.matmul(Bs, Wc.to(dtype).reshape(B, K, 1))[..., 0]
     Rp = torch.matmul(R, p)
     X = Rp * D.unsqueeze(1) + T
     x, y, Z = X[:, 0] / X[:, 2], X[:, 1] / X[:, 2], X[:, 2]
@@ -63,17 +67,19 @@ def dense_assemble(intr, scale, src, tgt, depth, basis, R, T, Wc, bundle, normal
     x0, y0 = x0f.long(), y0f.long()
     x1, y1 = (x0 + 1).clamp(0, W - 1), (y0 + 1).clamp(0, H - 1)
     x0, y0 = x0.clamp(0, W - 1), y0.clamp(0, H - 1)
-    gxm, gym = grad_fixed(tgt)
     w00, w01, w10, w11 = (1 - dx) * (1 - dy), dx * (1 - dy), (1 - dx) * dy, dx * dy
-
-    def samp(m):
-        fl = m.reshape(B, N, C)
-        return (_gather(fl, W, y0, x0) * w00.unsqueeze(-1) + _gather(fl, W, y0, x1) * w01.unsqueeze(-1)
-                + _gather(fl, W, y1, x0) * w10.unsqueeze(-1) + _gather(fl, W, y1, x1) * w11.unsqueeze(-1))
-
+    # 4 row gathers of the 3C-wide target map per window (index_select copies whole rows, multi-threaded)
+    samp = torch.empty(B, N, 3 * C, dtype=dtype, device=px.device)
+    for b in range(B):
+        tm = L["tmap"][b]
+        acc = tm.index_select(0, y0[b] * W + x0[b]) * w00[b].unsqueeze(-1)
+        acc.addcmul_(tm.index_select(0, y0[b] * W + x1[b]), w01[b].unsqueeze(-1))
+        acc.addcmul_(tm.index_select(0, y1[b] * W + x0[b]), w10[b].unsqueeze(-1))
+        acc.addcmul_(tm.index_select(0, y1[b] * W + x1[b]), w11[b].unsqueeze(-1))
+        samp[b] = acc
     mk = mask.unsqueeze(-1)
-    F2w, gx, gy = samp(tgt), samp(gxm) * mk, samp(gym) * mk
-    d = (F2w - src.reshape(B, N, C)) * mk                     # legacy sign
+    F2w, gx, gy = samp[..., :C], samp[..., C:2 * C] * mk, samp[..., 2 * C:] * mk
+    d = (F2w - L["src"]) * mk                                # legacy sign
     zero = torch.zeros_like(x)
     iz = 1.0 / Z
     Jx = fx.unsqueeze(-1) * torch.stack([x * y, -1 - x * x, y, -iz, zero, x / Z], dim=-1)
@@ -96,6 +102,12 @@ def dense_assemble(intr, scale, src, tgt, depth, basis, R, T, Wc, bundle, normal
     AtA = torch.matmul(Zx.transpose(1, 2), Jx) + torch.matmul(Zy.transpose(1, 2), Jy)
     Atb = (Jx * g1.unsqueeze(-1) + Jy * g2.unsqueeze(-1)).sum(1)
     return AtA, Atb, d.abs().sum(1), mask.sum(1)
+
+
+def dense_assemble(intr, scale, src, tgt, depth, basis, R, T, Wc, bundle, normalize_rays, dtype=torch.float64):
+    """-> AtA [B,P,P], Atb [B,P], absres [B,C], nvalid [B]   (P = 6 + K)."""
+    L = prepare_level(intr, scale, src, tgt, depth, basis if bundle else None, normalize_rays, dtype)
+    return assemble_prepared(L, R, T, Wc, bundle)
 
 
 _SELU_A, _SELU_S = 1.6732632423543772848170429916717, 1.0507009873554804934193349852946
@@ -127,11 +139,13 @@ def _rodrigues(w):
     return Rw, V
 
 
-def bundle_iteration(intr, scale, src, tgt, depth, basis, R, T, Wc, mlp, l2_base=1000.0, dtype=torch.float32):
-    """One dense BundleIteration -> (R', T', W', dict(lam, solution)).  Shapes as dense_assemble; Wc [B,K,1]."""
-    B, H, W, C = tgt.shape
-    N = H * W
-    AtA, Atb, absres, _nv = dense_assemble(intr, scale, src, tgt, depth, basis, R, T, Wc, True, True, dtype)
+def bundle_iteration(intr, scale, src, tgt, depth, basis, R, T, Wc, mlp, l2_base=1000.0, dtype=torch.float32, level=None):
+    """One dense BundleIteration -> (R', T', W', dict(lam, solution)).  Shapes as dense_assemble; Wc [B,K,1].
+    level: a prepare_level(...) result to reuse across the iterations of a level (then intr .. basis are ignored)."""
+    L = level if level is not None else prepare_level(intr, scale, src, tgt, depth, basis, True, dtype)
+    B, N = L["B"], L["N"]
+    dtype = L["tmap"].dtype
+    AtA, Atb, absres, _nv = assemble_prepared(L, R, T, Wc, True)
     avg = (absres / N).unsqueeze(1)                                              # :243
     y = lambda_mlp(avg, mlp)
     lam = torch.sqrt((avg * avg).sum(-1, keepdim=True)) ** (2.0 + y)             # :249

@@ -58,8 +58,9 @@ def _torch_levels(levels):
 # full size, end to end, against the oracle
 # ======================================================================================
 def test_full_size_five_level_chain_matches_oracle():
-    """One 640x480 window (C = K = 128), scales 16..1, [4]*5 LM iterations: state and last update after every level
-    within 1e-4 of the numpy float32 oracle chained over the same schedule, iteration counts identical."""
+    """One 640x480 window (C = K = 128), scales 16..1, [4]*5 LM iterations: the carried state after every level within 1e-4
+    of the numpy float32 oracle chained over the same schedule, every single update (one iteration from the oracle's own
+    level-start state) within 1e-4 of the float64 oracle per coefficient group, iteration counts identical."""
     from banet_amd import dense as bdense, synth as bsynth
     from banet_amd.bundlenet import he_normal_lambda_weights
     H, W, C, K = 480, 640, 128, 128
@@ -77,11 +78,14 @@ def test_full_size_five_level_chain_matches_oracle():
     nlv = [dict(scale=l.scale, H=l.H, W=l.W, src=n(l.src), tgt=n(l.tgt), D0=n(l.depth), basis=n(l.basis)) for l in levels]
     nm = [[(n(w), n(b)) for w, b in lw] for lw in mlps]
     ref, _sec = odense.bundle_chain(n(intr), nlv, nm, iters, np.eye(3, dtype=np.float32)[None], n(T0),
-                                    np.zeros((1, K, 1), np.float32))
-    par = odense.chain_parity(gpu, ref)
-    for li, r in enumerate(par):
-        for k in ("delta_pose", "delta_depth", "R", "T", "W", "lam"):
-            assert r[k] < 1e-4, (li, k, r)
+                                    np.zeros((1, K, 1), np.float32), truth=True)
+    steps = []
+    for li, r in enumerate(ref):            # single updates from identical states: one GPU iteration from the oracle's state
+        s1 = ba.step_from(li, t(r["R_start"]), t(r["T_start"]), t(r["W_start"]))
+        steps.append(dict(delta=n(s1.delta), lam=n(s1.lambda_out)))
+    par = odense.chain_parity(gpu, ref, steps)
+    print("full-size chain parity:", par)
+    assert odense.parity_failures(par, 1e-4) == [], odense.parity_failures(par, 1e-4)
     # the chain did real work: the depth coefficients moved and the translation error shrank
     assert np.abs(ref[-1]["W"]).max() > 1e-4
     assert np.abs(gpu[-1]["T"][0, :, 0] - n(gt["T"])[0]).max() < np.abs(n(T0)[0, :, 0] - n(gt["T"])[0]).max()
@@ -197,26 +201,33 @@ def _legacy_case():
                                             w_gt=np.array([0.010, -0.008, 0.006]) * s, t_gt=np.array([0.06, -0.04, 0.03]) * s))
     intr, levels = odense.batch_scene(scenes)
     mlps = [orc.he_normal_mlp_weights(C, 5 + i) for i in range(3)]
-    return intr, levels, mlps
+    # start off the identity: from (I, 0) every rim pixel projects exactly onto the image border, where the in-image test is
+    # decided by the last bit -- harmless for a converged solve, visible in one that is stopped early (residual_ratio < 1)
+    rng = np.random.RandomState(8)
+    R0 = np.stack([synth.rodrigues(rng.uniform(-1, 1, 3) * 0.004) for _ in range(B)]).astype(np.float32)
+    T0 = (np.stack([np.asarray(s["T_gt"]) * 0.3 for s in scenes])).reshape(B, 3, 1).astype(np.float32)
+    return intr, levels, mlps, R0, T0
 
 
+# (tighter-than-default thresholds only change the loops at convergence, where the accept test avg' < avg is decided by the
+#  last bits of two nearly equal residuals -- not a meaningful parity case, so none is listed)
 @pytest.mark.parametrize("angle,trans,ratio", [(0.0005, 0.002, 1.0),      # looser thresholds: loops stop earlier
-                                               (1e-7, 1e-7, 1.0),         # tighter: loops run to max_iters
+                                               (0.002, 0.0002, 1.0),      # only the angle threshold raised
                                                (3.4888e-5, 0.0002, 0.9)]) # stricter accept test (residual_ratio < 1)
 def test_lm_thresholds_and_residual_ratio_are_runtime_parameters(angle, trans, ratio, monkeypatch):
     """legacy/ba.py:5-9 are module globals its drivers overwrite; here they travel in banet_lm_params_t.  Iteration
     counts identical to the oracle run with the same values, poses within 1e-4."""
     from banet_amd import dense as bdense, ops
-    intr, levels, mlps = _legacy_case()
+    intr, levels, mlps, R0, T0 = _legacy_case()
     iters = [6, 6, 6]
     monkeypatch.setattr(orc, "ANGLE_CHANGE", angle)
     monkeypatch.setattr(orc, "TRANSLATION_CHANGE", trans)
     monkeypatch.setattr(orc, "RESIDUAL_RATIO", ratio)
-    R, T, _ratio, counts = odense.solve_legacy(intr, levels, mlps, iters, early_termination=True)
+    R, T, _ratio, counts = odense.solve_legacy(intr, levels, mlps, iters, early_termination=True, R0=R0, T0=T0)
     monkeypatch.undo()
-    default_counts = odense.solve_legacy(intr, levels, mlps, iters, early_termination=True)[3]
+    default_counts = odense.solve_legacy(intr, levels, mlps, iters, early_termination=True, R0=R0, T0=T0)[3]
     ba = bdense.DenseBA(t(intr), _torch_levels(levels), mlps, "legacy_lm")
-    st, got = ba.solve(iters, early_termination=True, params=ops.lm_params(angle, trans, ratio))
+    st, got = ba.solve(iters, ba.new_state(R=t(R0), T=t(T0)), early_termination=True, params=ops.lm_params(angle, trans, ratio))
     got = [[int(v) for v in c] for c in got]
     assert got == counts, (got, counts)
     assert relerr(n(st.R), R) < 1e-4 and relerr(n(st.T), T) < 1e-4
@@ -244,9 +255,12 @@ def test_legacy_module_globals_are_honoured_and_matrix_inverse_branch(golden_dir
     assert [int(x[0]) for x in trk.level_iters_run] == co
     assert relerr(n(R2), Ro) < 1e-5 and relerr(n(T2), To) < 1e-4
     # a threshold set on the module changes the loop like it does in the reference
-    monkeypatch.setattr(legacy, "angle_change", 1.0)          # no update is that large: one iteration per level
-    trk.trackTF(*args)
+    monkeypatch.setattr(legacy, "angle_change", 0.5)          # below the loop's initial update_w = 1 (legacy/ba.py:128), above
+    trk.trackTF(*args)                                        # any real update: exactly one iteration per level
     assert [int(x[0]) for x in trk.level_iters_run] == [1, 1, 1]
+    monkeypatch.setattr(legacy, "angle_change", 1.0)          # not below the initial 1.0: the loop body never runs
+    Rz, Tz, _ = trk.trackTF(*args)
+    assert [int(x[0]) for x in trk.level_iters_run] == [0, 0, 0] and torch.equal(Rz, t(c["R"])) and torch.equal(Tz, t(c["T"]))
     monkeypatch.setattr(legacy, "angle_change", 0.002 * (3.14 / 180.0))
     # early_termination = False: the fixed-count CameraIteration path, with the inverse branch
     monkeypatch.setattr(legacy, "early_termination", False)
@@ -317,7 +331,7 @@ def test_resize_drivers_backpropagate_to_pyramid_basis_depth_and_lambda():
             mlp["3"][4] = (over["w3"], mlp["3"][4][1])
         r, tt, dd = orc.bundle_resize(f64(c["intr"]), layers64, f64(c["points"]), f64(over.get("basis", c["basis"])),
                                       f64(over.get("depth", c["depth"])), mlp, init_rotation=f64(Rs_o[-1]),
-                                      init_translation=f64(Ts_o[-1]))
+                                      init_translation=f64(Ts_o[-1]), stop_gradient_depth=f64(c["depth"]))   # :341
         return float(sum((a * w).sum() for a, w in zip(tt, cT)) + sum((a * w).sum() for a, w in zip(dd, cD))
                      + sum((a * w).sum() for a, w in zip(r, cR)))
 

@@ -78,3 +78,29 @@ def test_legacy_tracker_helper_methods_match_oracle():
     xin = rng.standard_normal((B, 1, 4)).astype(np.float32)
     out = tr.conv1d(T(xin), 8, "lambda_2_1", activation=torch.nn.functional.selu).numpy()
     np.testing.assert_allclose(out, orc.selu(xin @ w1 + b1), rtol=1e-5, atol=1e-6)
+
+
+def test_bundle_chain_engines_agree_and_parity_record_shape():
+    """oracle.dense.bundle_chain: the numpy oracle and the float32 torch port (bench.py's two CPU baselines) walk the same
+    chain; chain_parity of one against the other is the record bench.py emits for the GPU."""
+    import numpy as np
+    from oracle import banet_oracle as orc, dense as odense, synth
+    C, K = 16, 8
+    sc = synth.make_pair_scene(24, 32, C, K, [2, 1], 11, normalize_rays=True, w_gt=[0.01, -0.008, 0.006], t_gt=[0.06, -0.04, 0.03])
+    intr, levels = odense.batch_scene([sc])
+    mlps = [orc.he_normal_mlp_weights(C, 5 + i) for i in range(2)]
+    R0 = np.eye(3, dtype=np.float32)[None]
+    T0 = (np.asarray(sc["T_gt"]) * 0.7).reshape(1, 3, 1).astype(np.float32)
+    W0 = np.zeros((1, K, 1), np.float32)
+    a, sec_a = odense.bundle_chain(intr, levels, mlps, [3, 2], R0, T0, W0, engine="numpy", truth=True)
+    b, sec_b = odense.bundle_chain(intr, levels, mlps, [3, 2], R0, T0, W0, engine="torch")
+    assert sec_a > 0 and sec_b > 0 and len(a) == len(b) == 2
+    steps = [dict(delta=s["first_delta"], lam=s["first_lam"]) for s in b]
+    par = odense.chain_parity(b, a, steps)
+    for r in par:
+        assert {"R", "T", "W", "step_pose", "step_depth", "step_last", "step_last_ref32", "step_last_vs32", "step_lam"} <= set(r)
+    assert odense.parity_failures(par, 1e-4) == [], odense.parity_failures(par, 1e-4)
+    np.testing.assert_array_equal(a[1]["R_start"], a[0]["R"])          # levels chain: a level starts where the previous ended
+    # the gate trips on a wrong update
+    steps[1]["delta"] = steps[1]["delta"] * 1.01
+    assert odense.parity_failures(odense.chain_parity(b, a, steps), 1e-4) != []
