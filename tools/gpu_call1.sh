@@ -13,8 +13,6 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 
 tail -3 $OUT/smoke.log
 ( time timeout 900 python bench.py --gpus 1 --steps 5 --warmup 2 ) > $OUT/bench.log 2>&1; echo "bench exit $?" >> $OUT/bench.log
 tail -c 3000 $OUT/bench.log
-( time timeout 900 python bench.py --gpus 1 --steps 2 --warmup 1 --windows 256 --no-sweep ) > $OUT/bench_b256.log 2>&1; echo "bench256 exit $?" >> $OUT/bench_b256.log
-tail -c 1500 $OUT/bench_b256.log
 timeout 600 python tools/bench_sparse.py > $OUT/bench_sparse.log 2>&1; echo "sparse exit $?" >> $OUT/bench_sparse.log
 tail -5 $OUT/bench_sparse.log
 timeout 600 python tools/bench_sparse.py --lm > $OUT/bench_sparse_lm.log 2>&1; echo "sparse-lm exit $?" >> $OUT/bench_sparse_lm.log
