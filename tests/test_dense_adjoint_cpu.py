@@ -1,0 +1,79 @@
+"""The hand-derived adjoint of the dense bundle assembly (oracle/dense_adjoint.py) -- the statement the fused HIP backward
+is checked against -- validated on the CPU: its forward equals the oracle's BundleIteration assembly, and its gradients
+equal central finite differences of that forward in float64."""
+import numpy as np
+import pytest
+
+from oracle import banet_oracle as orc, dense as odense, dense_adjoint as adj, synth
+
+
+def _scene(H=24, W=32, C=6, K=5, seed=3, B=2):
+    scenes = [synth.make_pair_scene(H, W, C, K, [1], seed + b, normalize_rays=True, w_gt=[0.01, -0.008, 0.006],
+                                    t_gt=[0.06, -0.04, 0.03]) for b in range(B)]
+    intr, levels = odense.batch_scene(scenes)
+    lv = levels[0]
+    rng = np.random.RandomState(seed)
+    R = np.stack([synth.rodrigues(0.004 * rng.standard_normal(3)) for _ in range(B)]).astype(np.float64)
+    T = np.stack([np.asarray(s["T_gt"]) * 0.7 for s in scenes]).reshape(B, 3, 1).astype(np.float64)
+    Wc = 0.02 * rng.standard_normal((B, K, 1))
+    return intr, lv, R, T, Wc, rng
+
+
+def _phi(intr, lv, R, T, Wc, G, gb, gavg):
+    a = odense.level_inputs(intr, lv, True, np.float64)
+    F = adj.forward_lean(a, lv["tgt"], R, T, Wc)
+    return float((G * F["AtA"]).sum() + (gb * F["Atb"]).sum() + (gavg * F["avg"]).sum())
+
+
+def test_forward_lean_equals_the_oracle_iteration_assembly():
+    intr, lv, R, T, Wc, rng = _scene()
+    a = odense.level_inputs(intr, lv, True, np.float64)
+    mlp = orc.he_normal_mlp_weights(lv["src"].shape[-1], 5, np.float64)
+    _, _, _, dbg = orc.bundle_iteration(a["conv1"], a["conv2"], a["fx"], a["fy"], a["ox"], a["oy"], a["p"], a["D"], a["Bs"],
+                                        R, T, Wc, mlp, 1000.0)
+    F = adj.forward_lean(a, lv["tgt"], R, T, Wc)
+    for k in ("AtA", "Atb", "avg"):
+        np.testing.assert_allclose(F[k], dbg[k], rtol=1e-10, atol=1e-10 * np.abs(dbg[k]).max())
+
+
+@pytest.mark.parametrize("seed", [3, 11])
+def test_assembly_adjoint_matches_finite_differences(seed):
+    intr, lv, R, T, Wc, rng = _scene(seed=seed)
+    B, H, W, C = lv["src"].shape
+    K = lv["basis"].shape[-1]
+    P = 6 + K
+    G = rng.standard_normal((B, P, P))            # deliberately NOT symmetric
+    gb = rng.standard_normal((B, P, 1))
+    gavg = rng.standard_normal((B, 1, C))
+    lv = {k: (np.asarray(v, np.float64) if isinstance(v, np.ndarray) else v) for k, v in lv.items()}
+    a = odense.level_inputs(intr, lv, True, np.float64)
+    out = adj.assembly_adjoint(a, lv["tgt"], R, T, Wc, G, gb, gavg)
+    assert out["fwd"]["mask"].mean() > 0.5
+
+    def fd(apply, shape, eps):
+        """central differences at three steps; the one closest to the median is returned (phi is a sum of ~1e3 terms of
+        mixed sign: the smallest steps are round-off limited, the largest see the bilinear kinks)"""
+        d = rng.standard_normal(shape)
+        d /= np.linalg.norm(d)
+        vals = sorted((apply(e * d) - apply(-e * d)) / (2 * e) for e in (eps, 3 * eps, 10 * eps))
+        return d, vals[1]
+
+    def with_level(key, delta):
+        l2 = dict(lv)
+        l2[key] = lv[key] + delta
+        return _phi(intr, l2, R, T, Wc, G, gb, gavg)
+
+    checks = []
+    for key, gname, shape in (("src", "dsrc", (B, H, W, C)), ("tgt", "dtgt", (B, H, W, C)), ("D0", "dD0", (B, H, W)),
+                              ("basis", "dbasis", (B, H, W, K))):
+        for _ in range(2):
+            d, num = fd(lambda dl: with_level(key, dl), shape, 3e-6)
+            checks.append((key, num, float((out[gname].reshape(shape) * d).sum())))
+    d, num = fd(lambda dl: _phi(intr, lv, R + dl, T, Wc, G, gb, gavg), (B, 3, 3), 1e-7)
+    checks.append(("R", num, float((out["dR"] * d).sum())))
+    d, num = fd(lambda dl: _phi(intr, lv, R, T + dl, Wc, G, gb, gavg), (B, 3, 1), 1e-7)
+    checks.append(("T", num, float((out["dT"] * d).sum())))
+    d, num = fd(lambda dl: _phi(intr, lv, R, T, Wc + dl, G, gb, gavg), (B, K, 1), 1e-7)
+    checks.append(("W", num, float((out["dW"] * d).sum())))
+    for name, num, ana in checks:
+        assert abs(num - ana) <= 1e-4 * max(abs(num), abs(ana)) + 1e-7, (name, num, ana)
