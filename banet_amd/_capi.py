@@ -74,6 +74,9 @@ EXPORTS = {
     "banet_lm_level_ex_f32": (ctypes.c_int, [ctypes.POINTER(Level), ctypes.POINTER(Mlp), ctypes.c_float, ctypes.c_int,
                                              ctypes.c_int, ctypes.POINTER(LmParams), ctypes.POINTER(State), _FP,
                                              ctypes.c_size_t, _FP]),
+    "banet_dense_adjoint_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Level)]),
+    "banet_dense_adjoint_f32": (ctypes.c_int, [ctypes.POINTER(Level)] + [_FP] * 11 + [_FP, ctypes.c_size_t, _FP]),
+    "banet_target_map_adjoint_f32": (ctypes.c_int, [_FP] * 2 + [ctypes.c_int] * 4 + [_FP]),
     "banet_profile_begin": (ctypes.c_int, [ctypes.c_int]),
     "banet_profile_end": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),
                                          ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]),

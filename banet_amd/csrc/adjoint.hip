@@ -1,0 +1,689 @@
+// Backward of the fused dense bundle assembly: given the upstream gradients of one assembly pass,
+//   gAtA [B,P,P], gAtb [B,P], gabs [B,C] = dL / d(AtA, Atb, sum_n |d|),
+// the gradients with respect to everything the pass read -- source map, target map, depth, depth basis, pose (R, T)
+// and depth coefficients Wc.  It is what TF autodiff + the registered EquationConstructionGrad (bundlenet.py:79-82,
+// utils.cu:465-694) compute for the statements bundlenet.py:206-263, restated per pixel without J, G or d in memory
+// (derivation and float64 statement: oracle/dense_adjoint.py, validated there against finite differences).
+//
+// With S = (gAtA + gAtA^T)/2, b = the pixel's basis row, J = [Jc | jd b^T], M = G^T G, g = G^T d:
+//   q = S_cd b, z = S_dd b, zeta = b.z, e = gAtb_d.b, t = Jc q + jd zeta
+//   dM = (Jc S_cc + jd q^T) Jc^T + t jd^T,  dg = Jc gAtb_c + jd e          -> channel adjoints of (gx, gy, d)
+//   dJc = 2 M (Jc S_cc + jd q^T) + g gAtb_c^T,  djd = 2 M t + g e          -> geometry adjoint -> dD, dR, dT
+//   dbasis = 2 s z + 2 S_cd^T u + r gAtb_d + dD Wc   (u, s, r = the forward's per-pixel records)
+// Kernels, in launch order:
+//   adj_sym_kernel      S = (gAtA + gAtA^T)/2
+//   adj_basis_kernel    the one GEMM-shaped piece, [N x K] . [K x (K+7)] per window on v_mfma_f32_16x16x4_f32 (exact fp32):
+//                       z2 = 2 S_dd b (written), per-pixel records (q, zeta, e)
+//   adj_pixel_kernel    one wave per pixel, lane = channel / coefficient: recomputes depth, warp, taps, M, g; writes
+//                       dsrc, ddepth, dbasis (+=: every pixel is owned by one wave), the pixel's 3C adjoint row of the sampled
+//                       [f|gx|gy] vector, its target cell + bilinear fractions; per-wave partial sums of dR, dT, dWc
+//   adj_scan / adj_fill target cell -> list of the source pixels whose bilinear footprint starts there (integer atomics only)
+//   adj_map_kernel      one wave per target texel: GATHERS the (<= 4 cells) contributions in ascending pixel order into the
+//                       [f|gx|gy] map adjoint -- no float atomics, bit-reproducible (the sparse-layout ba_sample_stats_grad_kernel
+//                       scatters with atomics instead)
+//   adj_fold_kernel     per-wave partials -> dpose [B, 12 + K] in fixed order
+// and, once per level after all iterations, target_map_adjoint_kernel: d tgt += dmap_f + grad_fixed^T (dmap_gx, dmap_gy)
+// (REFLECT rim: bundlenet.py:92-100).
+#include <algorithm>
+
+#include "kernels.hpp"
+
+namespace banet {
+
+namespace {
+
+constexpr int kAdjMaxCJ = 4;    // C <= 256
+constexpr int kAdjMaxKJ = 2;    // K <= 128 (adj_basis_kernel keeps the K x (K+16) seed block in LDS)
+constexpr int kAdjHdr = 16;     // partial row: dR (9), dT (3), pad, then dWc (K)
+constexpr int kScanThreads = 1024;
+
+struct AdjArgs {
+  banet_level_t lv;
+  const float* R;
+  const float* T;
+  const float* Wc;
+  const float* S;     // [B][P][P]
+  const float* gb;    // [B][P]
+  const float* gabs;  // [B][C]
+  float* z2;          // [B][N][K]
+  float* arec;        // [B][N][8]   q0..q5, zeta, e
+  float* arow;        // [B][N][3C]
+  float* frac;        // [B][N][4]   key (int), ax, ay, -
+  int* cnt;           // [B][HW]
+  int* start;         // [B][HW]
+  int* cursor;        // [B][HW]
+  int* list;          // [B][N]
+  float* part;        // [B][G * 4][kAdjHdr + K]
+  int G;
+  float* dsrc;
+  float* ddepth;
+  float* dbasis;
+  float* dmap3;
+  float* dpose;
+};
+
+__global__ void adj_sym_kernel(const float* __restrict__ g, float* __restrict__ S, int P, size_t total) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const size_t b = e / ((size_t)P * P);
+  const int r = (int)(e - b * P * P);
+  const int i = r / P, j = r - i * P;
+  S[e] = 0.5f * (g[e] + g[b * P * P + (size_t)j * P + i]);
+}
+
+// ---- the GEMM-shaped piece --------------------------------------------------------------------------------------------
+template <int NK>   // KP = 16 NK >= K
+__global__ __launch_bounds__(kBlock) void adj_basis_kernel(const AdjArgs a) {
+  extern __shared__ float Wl[];
+  constexpr int KP = 16 * NK, LS = KP + 20, NB = NK + 1;   // LS: 4 kq groups 4 LS floats apart -> 16 banks apart
+  const int b = blockIdx.y, K = a.lv.K, N = a.lv.N, P = 6 + K;
+  {
+    const float* __restrict__ S = a.S + (size_t)b * P * P;
+    const float* __restrict__ gb = a.gb + (size_t)b * P;
+    for (int idx = threadIdx.x; idx < KP * LS; idx += kBlock) {
+      const int k = idx / LS, j = idx - k * LS;
+      float v = 0.f;
+      if (k < K) {
+        if (j < K)
+          v = S[(size_t)(6 + k) * P + 6 + j];
+        else if (j >= KP && j < KP + 6)
+          v = S[(size_t)(j - KP) * P + 6 + k];
+        else if (j == KP + 6)
+          v = gb[6 + k];
+      }
+      Wl[idx] = v;
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = wave_id(), i = lane & 15, kq = lane >> 4;
+  const float* __restrict__ bas = a.lv.basis + (size_t)b * N * K;
+  float* __restrict__ z2 = a.z2 + (size_t)b * N * K;
+  float* __restrict__ arec = a.arec + (size_t)b * N * 8;
+  const int nrb = (N + 15) >> 4;
+  for (int rb = blockIdx.x * kNumWaves + w; rb < nrb; rb += gridDim.x * kNumWaves) {
+    const int n = rb * 16 + i;
+    const bool okn = n < N;
+    const float* __restrict__ row = bas + (size_t)(okn ? n : 0) * K;
+    float av[NK][4];
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = 16 * kk + 4 * kq + e;
+        const float v = row[k < K ? k : 0];
+        av[kk][e] = (okn && k < K) ? v : 0.f;
+      }
+    f32x4 acc[NB];
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb) acc[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float* wl = Wl + (16 * kk + 4 * kq + e) * LS + i;
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk][e], wl[16 * jb], acc[jb], 0, 0, 0);
+      }
+    // accumulator layout: lane (j = lane & 15, rq = lane >> 4) holds rows 4 rq + v, column 16 jb + j
+    float zeta[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int nn = rb * 16 + 4 * kq + v;
+      const bool ok = nn < N;
+#pragma unroll
+      for (int jb = 0; jb < NK; ++jb) {
+        const int j = 16 * jb + i;
+        if (ok && j < K) {
+          zeta[v] = fmaf(acc[jb][v], bas[(size_t)nn * K + j], zeta[v]);
+          z2[(size_t)nn * K + j] = 2.f * acc[jb][v];
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const float zt = row16_sum(zeta[v]);
+      const int nn = rb * 16 + 4 * kq + v;
+      if (nn < N) {
+        if (i < 6) arec[(size_t)nn * 8 + i] = acc[NK][v];
+        if (i == 6) arec[(size_t)nn * 8 + 7] = acc[NK][v];
+        if (i == 7) arec[(size_t)nn * 8 + 6] = zt;
+      }
+    }
+  }
+}
+
+// ---- per-pixel adjoint ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void adj_pixel_kernel(const AdjArgs a) {
+  const banet_level_t& lv = a.lv;
+  const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x & 63, w = wave_id();
+  const int N = lv.N, C = lv.C, K = lv.K, H = lv.H, W = lv.W, P = 6 + K;
+  const int CJ = (C + 63) >> 6, KJ = (K + 63) >> 6;
+  const float* __restrict__ src_b = lv.src + (size_t)b * N * C;
+  const float* __restrict__ tgt_b = lv.tgt + (size_t)b * N * C;
+  const float* __restrict__ bas_b = lv.basis + (size_t)b * N * K;
+  const float* __restrict__ S = a.S + (size_t)b * P * P;
+  const float* __restrict__ gb = a.gb + (size_t)b * P;
+  float Scc[6][6], gbc[6], Rm[9], Tv[3];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    gbc[i] = gb[i];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) Scc[i][j] = S[i * P + j];
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Rm[i] = a.R[b * 9 + i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) Tv[i] = a.T[b * 3 + i];
+  const float fx0 = lv.intr[b * 4 + 0], fy0 = lv.intr[b * 4 + 1], ox0 = lv.intr[b * 4 + 2], oy0 = lv.intr[b * 4 + 3];
+  const float fx = fx0 / lv.scale, fy = fy0 / lv.scale, ox = ox0 / lv.scale, oy = oy0 / lv.scale;
+  float wc[kAdjMaxKJ], scd[kAdjMaxKJ][6], gbd[kAdjMaxKJ], dwc[kAdjMaxKJ];
+#pragma unroll
+  for (int j = 0; j < kAdjMaxKJ; ++j) {
+    const int k = lane + 64 * j;
+    const bool ok = k < K;
+    wc[j] = ok ? a.Wc[(size_t)b * K + k] : 0.f;
+    gbd[j] = ok ? gb[6 + k] : 0.f;
+    dwc[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) scd[j][i] = ok ? S[i * P + 6 + k] : 0.f;
+  }
+  float ga[kAdjMaxCJ];
+#pragma unroll
+  for (int j = 0; j < kAdjMaxCJ; ++j) {
+    const int c = lane + 64 * j;
+    ga[j] = c < C ? a.gabs[(size_t)b * C + c] : 0.f;
+  }
+  float accR[9], accT[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) accR[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) accT[i] = 0.f;
+
+  const int nw = a.G * kNumWaves, chunk = (N + nw - 1) / nw;
+  const int n_lo = (g * kNumWaves + w) * chunk, n_hi = min(N, n_lo + chunk);
+  for (int n = n_lo; n < n_hi; ++n) {
+    // ---- depth and warp (bundlenet.py:206-224), every lane the same values
+    const int qy = n / W, qx = n - qy * W;
+    float p0 = ((float)qx * lv.scale - ox0) / fx0, p1 = ((float)qy * lv.scale - oy0) / fy0, p2 = 1.f;
+    if (lv.normalize_rays) {
+      const float inv = 1.f / sqrtf(fmaxf(p0 * p0 + p1 * p1 + p2 * p2, 1e-12f));
+      p0 *= inv;
+      p1 *= inv;
+      p2 *= inv;
+    }
+    float bv[kAdjMaxKJ], bsum = 0.f;
+#pragma unroll
+    for (int j = 0; j < kAdjMaxKJ; ++j) {
+      const int k = lane + 64 * j;
+      bv[j] = (j < KJ && k < K) ? bas_b[(size_t)n * K + k] : 0.f;
+      bsum = fmaf(bv[j], wc[j], bsum);
+    }
+    const float D = lv.depth[(size_t)b * N + n] + wave_sum(bsum);
+    const float rx = Rm[0] * p0 + Rm[1] * p1 + Rm[2] * p2;
+    const float ry = Rm[3] * p0 + Rm[4] * p1 + Rm[5] * p2;
+    const float rz = Rm[6] * p0 + Rm[7] * p1 + Rm[8] * p2;
+    const float X = rx * D + Tv[0], Y = ry * D + Tv[1], Z = rz * D + Tv[2];
+    const float x = X / Z, y = Y / Z;
+    const float px = fx * x + ox, py = fy * y + oy;
+    const bool m = (px >= 0.f) && (px <= (float)(W - 1)) && (py >= 0.f) && (py <= (float)(H - 1));
+    float* __restrict__ fr = a.frac + ((size_t)b * N + n) * 4;
+    if (!m) {   // wave-uniform: no contribution to anything (M = g = 0)
+      if (lane == 0) fr[0] = __int_as_float(-1);
+      continue;
+    }
+    const float xf = floorf(px), yf = floorf(py);
+    const int x0 = (int)xf, y0 = (int)yf;
+    const float ax = px - xf, ay = py - yf;
+    // ---- taps of the [f|gx|gy] map, gradient on the fly (grad_fixed, REFLECT rim -> 0), zero outside the image
+    float Sf[kAdjMaxCJ], Sgx[kAdjMaxCJ], Sgy[kAdjMaxCJ], Ax[kAdjMaxCJ][3], Ay[kAdjMaxCJ][3], dif[kAdjMaxCJ];
+#pragma unroll
+    for (int j = 0; j < kAdjMaxCJ; ++j) {
+      Sf[j] = Sgx[j] = Sgy[j] = dif[j] = 0.f;
+#pragma unroll
+      for (int e = 0; e < 3; ++e) Ax[j][e] = Ay[j][e] = 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int tx = x0 + (t & 1), ty = y0 + (t >> 1);
+      const bool in = tx <= W - 1 && ty <= H - 1;
+      const int txc = min(tx, W - 1), tyc = min(ty, H - 1);
+      const float hx = (in && txc > 0 && txc < W - 1) ? 0.5f : 0.f, hy = (in && tyc > 0 && tyc < H - 1) ? 0.5f : 0.f;
+      const float fin = in ? 1.f : 0.f;
+      const int xm = max(txc - 1, 0), xp = min(txc + 1, W - 1), ym = max(tyc - 1, 0), yp = min(tyc + 1, H - 1);
+      const float wx = (t & 1) ? ax : 1.f - ax, wy = (t >> 1) ? ay : 1.f - ay;
+      const float wt = wx * wy, sx = ((t & 1) ? 1.f : -1.f) * wy, sy = ((t >> 1) ? 1.f : -1.f) * wx;
+      const float* __restrict__ rc = tgt_b + (size_t)(tyc * W + txc) * C;
+      const float* __restrict__ rl = tgt_b + (size_t)(tyc * W + xm) * C;
+      const float* __restrict__ rr = tgt_b + (size_t)(tyc * W + xp) * C;
+      const float* __restrict__ ru = tgt_b + (size_t)(ym * W + txc) * C;
+      const float* __restrict__ rd = tgt_b + (size_t)(yp * W + txc) * C;
+#pragma unroll
+      for (int j = 0; j < kAdjMaxCJ; ++j) {
+        const int c = lane + 64 * j;
+        if (j < CJ && c < C) {
+          const float F = fin * rc[c], GX = hx * (rr[c] - rl[c]), GY = hy * (rd[c] - ru[c]);
+          Sf[j] = fmaf(wt, F, Sf[j]);
+          Sgx[j] = fmaf(wt, GX, Sgx[j]);
+          Sgy[j] = fmaf(wt, GY, Sgy[j]);
+          Ax[j][0] = fmaf(sx, F, Ax[j][0]);
+          Ax[j][1] = fmaf(sx, GX, Ax[j][1]);
+          Ax[j][2] = fmaf(sx, GY, Ax[j][2]);
+          Ay[j][0] = fmaf(sy, F, Ay[j][0]);
+          Ay[j][1] = fmaf(sy, GX, Ay[j][1]);
+          Ay[j][2] = fmaf(sy, GY, Ay[j][2]);
+        }
+      }
+    }
+    float M11 = 0.f, M12 = 0.f, M22 = 0.f, g1 = 0.f, g2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < kAdjMaxCJ; ++j) {
+      const int c = lane + 64 * j;
+      if (j < CJ && c < C) {
+        dif[j] = src_b[(size_t)n * C + c] - Sf[j];       // bundlenet.py:234
+        M11 = fmaf(Sgx[j], Sgx[j], M11);
+        M12 = fmaf(Sgx[j], Sgy[j], M12);
+        M22 = fmaf(Sgy[j], Sgy[j], M22);
+        g1 = fmaf(Sgx[j], dif[j], g1);
+        g2 = fmaf(Sgy[j], dif[j], g2);
+      }
+    }
+    M11 = wave_sum(M11);
+    M12 = wave_sum(M12);
+    M22 = wave_sum(M22);
+    g1 = wave_sum(g1);
+    g2 = wave_sum(g2);
+    // ---- per-pixel algebra (bundlenet.py:49-74 Jacobians with the bundle sign, J = [-Jc | jd b])
+    const float iz = 1.f / Z;
+    float J0[6], J1[6];
+    J0[0] = fx * (-(x * y));
+    J0[1] = fx * (1.f + x * x);
+    J0[2] = fx * (-y);
+    J0[3] = fx * iz;
+    J0[4] = 0.f;
+    J0[5] = fx * (-(x * iz));
+    J1[0] = fy * (-1.f - y * y);
+    J1[1] = fy * (x * y);
+    J1[2] = fy * x;
+    J1[3] = 0.f;
+    J1[4] = fy * iz;
+    J1[5] = fy * (-(y * iz));
+    const float jd0 = fx * ((rx - rz * x) * iz), jd1 = fy * ((ry - rz * y) * iz);
+    const float* __restrict__ ar = a.arec + ((size_t)b * N + n) * 8;
+    float q[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) q[i] = ar[i];
+    const float zeta = ar[6], ee = ar[7];
+    float JS0[6], JS1[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float s0 = jd0 * q[j], s1 = jd1 * q[j];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        s0 = fmaf(J0[i], Scc[i][j], s0);
+        s1 = fmaf(J1[i], Scc[i][j], s1);
+      }
+      JS0[j] = s0;
+      JS1[j] = s1;
+    }
+    float t0 = jd0 * zeta, t1 = jd1 * zeta, dM11 = 0.f, dM12 = 0.f, dM22 = 0.f, dg1 = jd0 * ee, dg2 = jd1 * ee;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      t0 = fmaf(J0[i], q[i], t0);
+      t1 = fmaf(J1[i], q[i], t1);
+      dM11 = fmaf(JS0[i], J0[i], dM11);
+      dM12 = fmaf(JS0[i], J1[i], dM12);
+      dM22 = fmaf(JS1[i], J1[i], dM22);
+      dg1 = fmaf(J0[i], gbc[i], dg1);
+      dg2 = fmaf(J1[i], gbc[i], dg2);
+    }
+    dM11 = fmaf(t0, jd0, dM11);
+    dM12 = fmaf(t0, jd1, dM12);
+    dM22 = fmaf(t1, jd1, dM22);
+    float dJ0[6], dJ1[6], u[6];
+    const float Mjd0 = M11 * jd0 + M12 * jd1, Mjd1 = M12 * jd0 + M22 * jd1;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      dJ0[i] = 2.f * (M11 * JS0[i] + M12 * JS1[i]) + g1 * gbc[i];
+      dJ1[i] = 2.f * (M12 * JS0[i] + M22 * JS1[i]) + g2 * gbc[i];
+      u[i] = J0[i] * Mjd0 + J1[i] * Mjd1;
+    }
+    const float djd0 = 2.f * (M11 * t0 + M12 * t1) + g1 * ee, djd1 = 2.f * (M12 * t0 + M22 * t1) + g2 * ee;
+    const float s_n = jd0 * Mjd0 + jd1 * Mjd1, r_n = jd0 * g1 + jd1 * g2;
+    // ---- channel adjoints: dsrc, the 3C adjoint row, d(px, py)
+    float dpx = 0.f, dpy = 0.f;
+    float* __restrict__ dsrc_n = a.dsrc + ((size_t)b * N + n) * C;
+    float* __restrict__ arow_n = a.arow + ((size_t)b * N + n) * 3 * C;
+#pragma unroll
+    for (int j = 0; j < kAdjMaxCJ; ++j) {
+      const int c = lane + 64 * j;
+      if (j < CJ && c < C) {
+        const float d = dif[j], gx = Sgx[j], gy = Sgy[j];
+        const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        const float dd = dg1 * gx + dg2 * gy + sgn * ga[j];
+        const float dgx = 2.f * (dM11 * gx + dM12 * gy) + dg1 * d;
+        const float dgy = 2.f * (dM12 * gx + dM22 * gy) + dg2 * d;
+        dsrc_n[c] += dd;
+        arow_n[c] = -dd;
+        arow_n[C + c] = dgx;
+        arow_n[2 * C + c] = dgy;
+        dpx += -dd * Ax[j][0] + dgx * Ax[j][1] + dgy * Ax[j][2];
+        dpy += -dd * Ay[j][0] + dgx * Ay[j][1] + dgy * Ay[j][2];
+      }
+    }
+    dpx = wave_sum(dpx);
+    dpy = wave_sum(dpy);
+    // ---- geometry adjoint
+    float dx_ = fx * dpx + fx * (-y * dJ0[0] + 2.f * x * dJ0[1] - dJ0[5] * iz) + fy * (y * dJ1[1] + dJ1[2]);
+    float dy_ = fy * dpy + fx * (-x * dJ0[0] - dJ0[2]) + fy * (-2.f * y * dJ1[0] + x * dJ1[1] - dJ1[5] * iz);
+    float dZ_ = (fx * (-dJ0[3] + x * dJ0[5]) + fy * (-dJ1[4] + y * dJ1[5])) * iz * iz;
+    float drx = fx * djd0 * iz, dry = fy * djd1 * iz, drz = -(fx * x * djd0 + fy * y * djd1) * iz;
+    dx_ -= fx * rz * djd0 * iz;
+    dy_ -= fy * rz * djd1 * iz;
+    dZ_ -= (jd0 * djd0 + jd1 * djd1) * iz;
+    const float dX = dx_ * iz, dY = dy_ * iz, dZt = dZ_ - (x * dx_ + y * dy_) * iz;
+    drx = fmaf(dX, D, drx);
+    dry = fmaf(dY, D, dry);
+    drz = fmaf(dZt, D, drz);
+    const float dD = dX * rx + dY * ry + dZt * rz;
+    accT[0] += dX;
+    accT[1] += dY;
+    accT[2] += dZt;
+    accR[0] = fmaf(drx, p0, accR[0]);
+    accR[1] = fmaf(drx, p1, accR[1]);
+    accR[2] = fmaf(drx, p2, accR[2]);
+    accR[3] = fmaf(dry, p0, accR[3]);
+    accR[4] = fmaf(dry, p1, accR[4]);
+    accR[5] = fmaf(dry, p2, accR[5]);
+    accR[6] = fmaf(drz, p0, accR[6]);
+    accR[7] = fmaf(drz, p1, accR[7]);
+    accR[8] = fmaf(drz, p2, accR[8]);
+    // ---- depth, basis, coefficients
+    float* __restrict__ dbas_n = a.dbasis + ((size_t)b * N + n) * K;
+    const float* __restrict__ z2_n = a.z2 + ((size_t)b * N + n) * K;
+#pragma unroll
+    for (int j = 0; j < kAdjMaxKJ; ++j) {
+      const int k = lane + 64 * j;
+      if (j < KJ && k < K) {
+        float v = s_n * z2_n[k] + r_n * gbd[j] + dD * wc[j];
+        float su = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) su = fmaf(u[i], scd[j][i], su);
+        v = fmaf(2.f, su, v);
+        dbas_n[k] += v;
+        dwc[j] = fmaf(dD, bv[j], dwc[j]);
+      }
+    }
+    if (lane == 0) {
+      a.ddepth[(size_t)b * N + n] += dD;
+      const int key = y0 * W + x0;
+      fr[0] = __int_as_float(key);
+      fr[1] = ax;
+      fr[2] = ay;
+      atomicAdd(&a.cnt[(size_t)b * H * W + key], 1);
+    }
+  }
+  float* __restrict__ prow = a.part + ((size_t)b * a.G * kNumWaves + g * kNumWaves + w) * (kAdjHdr + K);
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+    if (lane == i) prow[i] = accR[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    if (lane == 9 + i) prow[9 + i] = accT[i];
+#pragma unroll
+  for (int j = 0; j < kAdjMaxKJ; ++j) {
+    const int k = lane + 64 * j;
+    if (k < K) prow[kAdjHdr + k] = dwc[j];
+  }
+}
+
+__global__ void adj_fold_kernel(const float* __restrict__ part, int rows, int K, float* __restrict__ dpose) {
+  const int b = blockIdx.y, e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 12 + K) return;
+  const int off = e < 12 ? e : kAdjHdr + (e - 12);
+  const float* p = part + (size_t)b * rows * (kAdjHdr + K) + off;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int i = 0;
+  for (; i + 3 < rows; i += 4) {
+    s0 += p[(size_t)(i + 0) * (kAdjHdr + K)];
+    s1 += p[(size_t)(i + 1) * (kAdjHdr + K)];
+    s2 += p[(size_t)(i + 2) * (kAdjHdr + K)];
+    s3 += p[(size_t)(i + 3) * (kAdjHdr + K)];
+  }
+  for (; i < rows; ++i) s0 += p[(size_t)i * (kAdjHdr + K)];
+  dpose[(size_t)b * (12 + K) + e] = (s0 + s1) + (s2 + s3);
+}
+
+// ---- target cell lists ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kScanThreads) void adj_scan_kernel(const int* __restrict__ cnt, int* __restrict__ start,
+                                                                int* __restrict__ cursor, int HW) {
+  __shared__ int sSum[kScanThreads];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int chunk = (HW + kScanThreads - 1) / kScanThreads;
+  const int lo = min(HW, tid * chunk), hi = min(HW, lo + chunk);
+  const int* __restrict__ c = cnt + (size_t)b * HW;
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += c[i];
+  sSum[tid] = s;
+  __syncthreads();
+  for (int d = 1; d < kScanThreads; d <<= 1) {   // inclusive Hillis-Steele scan of the chunk sums
+    const int v = tid >= d ? sSum[tid - d] : 0;
+    __syncthreads();
+    sSum[tid] += v;
+    __syncthreads();
+  }
+  int run = sSum[tid] - s;
+  for (int i = lo; i < hi; ++i) {
+    start[(size_t)b * HW + i] = run;
+    cursor[(size_t)b * HW + i] = run;
+    run += c[i];
+  }
+}
+
+__global__ void adj_fill_kernel(const float* __restrict__ frac, int* __restrict__ cursor, int* __restrict__ list, int N, int HW) {
+  const int b = blockIdx.y, n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int key = __float_as_int(frac[((size_t)b * N + n) * 4]);
+  if (key < 0) return;
+  const int slot = atomicAdd(&cursor[(size_t)b * HW + key], 1);   // the consumer orders each cell's entries itself
+  list[(size_t)b * N + slot] = n;
+}
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) v = min(v, __shfl_xor(v, s, 64));
+  return v;
+}
+
+// One wave per target texel: the adjoint of the bilinear sampling as a GATHER over the source pixels whose footprint
+// covers the texel, in a fixed order (cells row-major, ascending pixel index inside a cell).
+__global__ __launch_bounds__(kBlock) void adj_map_kernel(const AdjArgs a) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63, w = wave_id();
+  const int N = a.lv.N, C = a.lv.C, H = a.lv.H, W = a.lv.W, HW = H * W, C3 = 3 * C;
+  const int J3 = (C3 + 63) >> 6;   // <= 12
+  const int* __restrict__ cnt = a.cnt + (size_t)b * HW;
+  const int* __restrict__ start = a.start + (size_t)b * HW;
+  const int* __restrict__ list = a.list + (size_t)b * N;
+  for (int t = blockIdx.x * kNumWaves + w; t < HW; t += gridDim.x * kNumWaves) {
+    const int ty = t / W, tx = t - ty * W;
+    float acc[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) acc[j] = 0.f;
+    bool any = false;
+#pragma unroll
+    for (int cell = 0; cell < 4; ++cell) {
+      const int cy = ty - 1 + (cell >> 1), cx = tx - 1 + (cell & 1);
+      if (cy < 0 || cx < 0) continue;   // wave-uniform (cy <= H-1, cx <= W-1 by construction)
+      const int ci = cy * W + cx;
+      const int L = cnt[ci], s0 = start[ci];
+      int last = -1;
+      for (int it = 0; it < L; ++it) {
+        int mn = 0x7fffffff;
+        for (int e = lane; e < L; e += 64) {
+          const int v = list[s0 + e];
+          if (v > last) mn = min(mn, v);
+        }
+        const int n = wave_min_i(mn);
+        last = n;
+        const float* __restrict__ fr = a.frac + ((size_t)b * N + n) * 4;
+        const float ax = fr[1], ay = fr[2];
+        const float wt = ((cell & 1) ? 1.f - ax : ax) * ((cell >> 1) ? 1.f - ay : ay);   // cell == texel - (1,1) ... texel
+        if (wt != 0.f) {
+          any = true;
+          const float* __restrict__ ar = a.arow + ((size_t)b * N + n) * C3;
+#pragma unroll
+          for (int j = 0; j < 12; ++j) {
+            const int c = lane + 64 * j;
+            if (j < J3 && c < C3) acc[j] = fmaf(wt, ar[c], acc[j]);
+          }
+        }
+      }
+    }
+    if (any) {
+      float* __restrict__ o = a.dmap3 + ((size_t)b * HW + t) * C3;
+#pragma unroll
+      for (int j = 0; j < 12; ++j) {
+        const int c = lane + 64 * j;
+        if (j < J3 && c < C3) o[c] += acc[j];
+      }
+    }
+  }
+}
+
+// d img += dmap_f + grad_fixed^T (dmap_gx, dmap_gy): gx[x] = 0.5 (img[x+1] - img[x-1]) for 1 <= x <= W-2, 0 on the rim
+__global__ void target_map_adjoint_kernel(const float* __restrict__ dmap3, float* __restrict__ dimg, int H, int W, int C,
+                                          size_t total) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int c = (int)(e % C);
+  const size_t tix = e / C;
+  const int x = (int)(tix % W);
+  const size_t r = tix / W;
+  const int y = (int)(r % H);
+  const size_t C3 = 3 * (size_t)C;
+  const float* m = dmap3 + tix * C3;
+  float v = m[c];
+  if (x - 1 >= 1 && x - 1 <= W - 2) v += 0.5f * (m - C3)[C + c];
+  if (x + 1 >= 1 && x + 1 <= W - 2) v -= 0.5f * (m + C3)[C + c];
+  if (y - 1 >= 1 && y - 1 <= H - 2) v += 0.5f * (m - (size_t)W * C3)[2 * C + c];
+  if (y + 1 >= 1 && y + 1 <= H - 2) v -= 0.5f * (m + (size_t)W * C3)[2 * C + c];
+  dimg[e] += v;
+}
+
+struct AdjPlan {
+  int G, Ga, Gm;
+  size_t off_S, off_z2, off_arec, off_arow, off_frac, off_cnt, off_start, off_cursor, off_list, off_part, bytes;
+};
+
+bool adj_supported(const banet_level_t* lv) {
+  return lv->variant == BANET_BUNDLE && lv->dense == 1 && lv->tgt_has_grad == 0 && lv->pairs <= 1 && lv->K >= 1 &&
+         lv->K <= 64 * kAdjMaxKJ && lv->C >= 1 && lv->C <= 64 * kAdjMaxCJ && lv->N == lv->H * lv->W;
+}
+
+void adj_plan(const banet_level_t* lv, AdjPlan* pl) {
+  const size_t B = lv->B, N = lv->N, C = lv->C, K = lv->K, P = 6 + K;
+  const int per = (int)((2048 + B - 1) / B);                         // ~8 waves per CU over the whole chip
+  pl->G = (int)std::max<size_t>(1, std::min<size_t>((N + 63) / 64, (size_t)(per + kNumWaves - 1) / kNumWaves));
+  pl->Ga = (int)std::max<size_t>(1, std::min<size_t>((N + 63) / 64, (size_t)((512 + B - 1) / B)));
+  pl->Gm = (int)std::max<size_t>(1, std::min<size_t>((N + 3) / 4, (size_t)((4096 + B - 1) / B)));
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    const size_t at = o;
+    o = align_up(o + bytes, 256);
+    return at;
+  };
+  pl->off_S = take(B * P * P * 4);
+  pl->off_z2 = take(B * N * K * 4);
+  pl->off_arec = take(B * N * 8 * 4);
+  pl->off_arow = take(B * N * 3 * C * 4);
+  pl->off_frac = take(B * N * 4 * 4);
+  pl->off_cnt = take(B * N * 4);
+  pl->off_start = take(B * N * 4);
+  pl->off_cursor = take(B * N * 4);
+  pl->off_list = take(B * N * 4);
+  pl->off_part = take(B * (size_t)pl->G * kNumWaves * (kAdjHdr + K) * 4);
+  pl->bytes = o;
+}
+
+template <int NK>
+void launch_adj_basis(const AdjArgs& a, int Ga, hipStream_t s) {
+  constexpr int KP = 16 * NK, LS = KP + 20;
+  const size_t shm = (size_t)KP * LS * sizeof(float);
+  static bool attr_set = false;   // > 64 KB of dynamic LDS needs the attribute once per process
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&adj_basis_kernel<NK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((adj_basis_kernel<NK>), dim3(Ga, a.lv.B), dim3(kBlock), shm, s, a);
+}
+
+}  // namespace
+
+size_t dense_adjoint_workspace_bytes(const banet_level_t* lv) {
+  if (!adj_supported(lv)) return 0;
+  AdjPlan pl;
+  adj_plan(lv, &pl);
+  return pl.bytes;
+}
+
+int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T, const float* Wc, const float* gAtA,
+                         const float* gAtb, const float* gabs, float* dsrc, float* dmap3, float* ddepth, float* dbasis,
+                         float* dpose, void* ws, hipStream_t s) {
+  if (!adj_supported(lv)) return BANET_ERR_UNSUPPORTED;
+  AdjPlan pl;
+  adj_plan(lv, &pl);
+  char* base = static_cast<char*>(ws);
+  const int B = lv->B, N = lv->N, K = lv->K, P = 6 + K, HW = lv->H * lv->W;
+  AdjArgs a;
+  a.lv = *lv;
+  a.R = R;
+  a.T = T;
+  a.Wc = Wc;
+  float* S = reinterpret_cast<float*>(base + pl.off_S);
+  a.S = S;
+  a.gb = gAtb;
+  a.gabs = gabs;
+  a.z2 = reinterpret_cast<float*>(base + pl.off_z2);
+  a.arec = reinterpret_cast<float*>(base + pl.off_arec);
+  a.arow = reinterpret_cast<float*>(base + pl.off_arow);
+  a.frac = reinterpret_cast<float*>(base + pl.off_frac);
+  a.cnt = reinterpret_cast<int*>(base + pl.off_cnt);
+  a.start = reinterpret_cast<int*>(base + pl.off_start);
+  a.cursor = reinterpret_cast<int*>(base + pl.off_cursor);
+  a.list = reinterpret_cast<int*>(base + pl.off_list);
+  a.part = reinterpret_cast<float*>(base + pl.off_part);
+  a.G = pl.G;
+  a.dsrc = dsrc;
+  a.ddepth = ddepth;
+  a.dbasis = dbasis;
+  a.dmap3 = dmap3;
+  a.dpose = dpose;
+  const size_t tot = (size_t)B * P * P;
+  hipLaunchKernelGGL(adj_sym_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, gAtA, S, P, tot);
+  if (hipMemsetAsync(a.cnt, 0, (size_t)B * HW * sizeof(int), s) != hipSuccess) return BANET_ERR_LAUNCH;
+  switch ((K + 15) / 16) {
+    case 1: launch_adj_basis<1>(a, pl.Ga, s); break;
+    case 2: launch_adj_basis<2>(a, pl.Ga, s); break;
+    case 3: launch_adj_basis<3>(a, pl.Ga, s); break;
+    case 4: launch_adj_basis<4>(a, pl.Ga, s); break;
+    case 5: launch_adj_basis<5>(a, pl.Ga, s); break;
+    case 6: launch_adj_basis<6>(a, pl.Ga, s); break;
+    case 7: launch_adj_basis<7>(a, pl.Ga, s); break;
+    case 8: launch_adj_basis<8>(a, pl.Ga, s); break;
+    default: return BANET_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(adj_pixel_kernel, dim3(pl.G, B), dim3(kBlock), 0, s, a);
+  hipLaunchKernelGGL(adj_scan_kernel, dim3(B), dim3(kScanThreads), 0, s, a.cnt, a.start, a.cursor, HW);
+  hipLaunchKernelGGL(adj_fill_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, a.frac, a.cursor, a.list, N, HW);
+  hipLaunchKernelGGL(adj_map_kernel, dim3(pl.Gm, B), dim3(kBlock), 0, s, a);
+  hipLaunchKernelGGL(adj_fold_kernel, dim3((12 + K + 127) / 128, B), dim3(128), 0, s, a.part, pl.G * kNumWaves, K, dpose);
+  return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;
+}
+
+int launch_target_map_adjoint(const float* dmap3, float* dimg, int B, int H, int W, int C, hipStream_t s) {
+  const size_t total = (size_t)B * H * W * C;
+  if (total == 0) return BANET_OK;
+  hipLaunchKernelGGL(target_map_adjoint_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dmap3, dimg, H, W, C, total);
+  return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;
+}
+
+}  // namespace banet

@@ -290,6 +290,29 @@ int banet_sample_stats_grad_f32(const float* conv1, const float* conv2, const fl
                                   static_cast<hipStream_t>(stream));
 }
 
+size_t banet_dense_adjoint_workspace_bytes(const banet_level_t* lv) {
+  if (!lv || lv->B <= 0 || lv->N <= 0) return 0;
+  return dense_adjoint_workspace_bytes(lv);
+}
+
+int banet_dense_adjoint_f32(const banet_level_t* lv, const float* R, const float* T, const float* Wc, const float* gAtA,
+                            const float* gAtb, const float* gabs, float* dsrc, float* dmap3, float* ddepth, float* dbasis,
+                            float* dpose, void* ws, size_t ws_bytes, banet_stream_t stream) {
+  if (!lv || !R || !T || !Wc || !gAtA || !gAtb || !gabs || !dsrc || !dmap3 || !ddepth || !dbasis || !dpose || !ws)
+    return BANET_ERR_INVALID_ARG;
+  if (lv->B <= 0 || lv->N <= 0 || !lv->src || !lv->tgt || !lv->depth || !lv->basis || !lv->intr) return BANET_ERR_INVALID_ARG;
+  const size_t need = dense_adjoint_workspace_bytes(lv);
+  if (need == 0) return BANET_ERR_UNSUPPORTED;
+  if (ws_bytes < need || (reinterpret_cast<uintptr_t>(ws) & 255) != 0) return BANET_ERR_WORKSPACE;
+  return launch_dense_adjoint(lv, R, T, Wc, gAtA, gAtb, gabs, dsrc, dmap3, ddepth, dbasis, dpose, ws,
+                              static_cast<hipStream_t>(stream));
+}
+
+int banet_target_map_adjoint_f32(const float* dmap3, float* dimg, int B, int H, int W, int C, banet_stream_t stream) {
+  if (!dmap3 || !dimg || B <= 0 || H <= 0 || W <= 0 || C <= 0) return BANET_ERR_INVALID_ARG;
+  return launch_target_map_adjoint(dmap3, dimg, B, H, W, C, static_cast<hipStream_t>(stream));
+}
+
 int banet_profile_begin(int max_launches) { return profile_begin(max_launches); }
 
 int banet_profile_end(int max_tags, int32_t* tag_points, int32_t* tag_launches, double* tag_ms, int32_t* ntags) {

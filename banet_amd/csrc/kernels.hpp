@@ -135,4 +135,11 @@ int launch_sample_stats_grad(const float* conv1, const float* conv2, const float
                              int H, int W, const float* dstats, const float* dabs, float* dconv1, float* dconv2, float* dpos,
                              hipStream_t s);
 
+// ---- adjoint.hip: backward of the fused dense bundle assembly ----
+size_t dense_adjoint_workspace_bytes(const banet_level_t* lv);
+int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T, const float* Wc, const float* gAtA,
+                         const float* gAtb, const float* gabs, float* dsrc, float* dmap3, float* ddepth, float* dbasis,
+                         float* dpose, void* ws, hipStream_t s);
+int launch_target_map_adjoint(const float* dmap3, float* dimg, int B, int H, int W, int C, hipStream_t s);
+
 }  // namespace banet

@@ -27,6 +27,7 @@ class DenseBA:
         """intr [B,4] full-resolution (fx,fy,ox,oy); levels: list of DenseLevel coarse->fine;
         lambda_weights: list (one per level) of 5 (filters, biases) pairs."""
         self.variant = variant
+        self.levels, self.lambda_weights = list(levels), list(lambda_weights)
         self.l2_base = float(l2_base) if variant == "bundle" else 1.0
         self.intr = intr.contiguous().float()
         dev = self.intr.device
@@ -72,6 +73,14 @@ class DenseBA:
                 snapshots.append(dict(R=st.R.clone(), T=st.T.clone(), W=None if st.Wc is None else st.Wc.clone(),
                                       delta=st.delta.clone(), lam=st.lambda_out.clone()))
         return st, counts
+
+    def solve_differentiable(self, iters_per_level, R=None, T=None, Wc=None):
+        """The same fixed-count schedule attached to the autograd graph: gradients flow to the levels' src / tgt / depth /
+        basis tensors, to the initial (R, T, Wc) and to the lambda weights through the fused backward kernels
+        (banet_amd/dense_train.py, csrc/adjoint.hip; the reference differentiates bundlenet.py:376-397 with tf.gradients +
+        EquationConstructionGrad).  Bundle variant, two-frame windows, K <= 128."""
+        from . import dense_train
+        return dense_train.solve_differentiable(self, self.levels, self.lambda_weights, iters_per_level, R, T, Wc)
 
     def step_from(self, level_index, R, T, Wc=None):
         """ONE iteration of level `level_index` from the given state -> (state after it; .delta / .lambda_out hold the

@@ -1,0 +1,151 @@
+"""Differentiable dense BA: the fused forward kernels plus the fused backward of banet_amd/csrc/adjoint.hip
+(reference: the TF graph of bundlenet.py:193-278 differentiated by tf.gradients + the registered
+EquationConstructionGrad, bundlenet.py:79-82, utils.cu:465-694).
+
+One autograd node per pyramid LEVEL (all of its fixed-count iterations, as bundlenet.py:376-397 unrolls them):
+  forward   iteration by iteration with the product kernels (banet_ba_assemble_f32 + banet_ba_solve_update_f32), keeping the
+            per-iteration state (R, T, Wc) and the small outputs of the assembly (AtA, Atb, sum |d|);
+  backward  iterations in reverse: (a) the small part -- lambda MLP, damping, solve, SE(3)/W update -- is re-evaluated as
+            a torch graph on the saved [B,P,P] / [B,P] / [B,C] tensors (implicit differentiation of the damped solve is
+            torch.linalg.solve's backward), giving dL/d(AtA, Atb, sum|d|), the direct dL/d(R, T, Wc) and the lambda-weight
+            gradients; (b) banet_dense_adjoint_f32 turns the former into gradients of the feature maps, depth, basis and
+            pose, accumulated over the iterations in place; (c) once per level banet_target_map_adjoint_f32 folds the
+            [f|gx|gy] map adjoint into the target map's gradient.
+No J / G / d / samp tensors exist in either direction and nothing is scattered with float atomics: gradients are
+bit-reproducible.  Supported: the `bundle` variant, two-frame windows, K <= 128, C <= 256.
+"""
+import ctypes
+
+import torch
+
+from . import _capi as capi
+from . import ops
+from .bundlenet import AngleaAxisRotation, VMatrix
+
+
+def _to_param(t, dev):
+    return t.to(dev) if torch.is_tensor(t) else torch.as_tensor(t, dtype=torch.float32, device=dev)
+
+
+def solve_update_graph(AtA, Atb, absres, N, R, T, Wc, layers, l2_base):
+    """bundlenet.py:241-276 after the EquationConstruction op, as differentiable torch statements on the small tensors:
+    avg -> lambda MLP -> damping (last coefficient undamped) -> matrix_solve -> SE(3) / W update."""
+    nb = AtA.shape[0]
+    avg = (absres / float(N)).unsqueeze(1)                                           # :243
+    h = avg
+    for i, (w, b) in enumerate(layers):
+        z = torch.matmul(h, w) + b
+        h = torch.tanh(z) if i == 4 else torch.nn.functional.selu(z)
+    lam = torch.linalg.vector_norm(avg, dim=-1, keepdim=True) ** (2.0 + h)           # :249
+    lam = l2_base * lam                                                              # :252-253
+    diag = torch.diagonal(AtA, dim1=1, dim2=2)
+    damp = torch.cat([diag[:, :-1] + 1e-5, torch.zeros(nb, 1, device=diag.device, dtype=diag.dtype)], dim=-1)   # :266
+    A = AtA + torch.diag_embed(damp * lam.squeeze(-1))
+    sol = torch.linalg.solve(A, Atb.unsqueeze(-1))                                   # :267
+    wx, wy, wz = sol[:, 0], sol[:, 1], sol[:, 2]
+    dr = AngleaAxisRotation(wx, wy, wz)
+    dv = VMatrix(wx.reshape(-1), wy.reshape(-1), wz.reshape(-1))
+    return torch.matmul(dr, R), torch.matmul(dv, sol[:, 3:6]) + torch.matmul(dr, T), Wc + sol[:, 6:]
+
+
+def dense_adjoint(problem, R, T, Wc, gAtA, gAtb, gabs, dsrc, dmap3, ddepth, dbasis, ws=None):
+    """banet_dense_adjoint_f32 -> dpose [B, 12 + K]; dsrc / dmap3 / ddepth / dbasis are accumulated in place."""
+    L = capi.lib()
+    nb = L.banet_dense_adjoint_workspace_bytes(ctypes.byref(problem.c))
+    if nb == 0:
+        raise capi.BanetError("dense_adjoint: unsupported level (bundle variant, dense two-frame windows, K <= 128, C <= 256)")
+    if ws is None or ws.numel() < nb:
+        ws = capi.workspace(nb, problem.device)
+    dpose = torch.empty((problem.B, 12 + problem.K), dtype=torch.float32, device=problem.device)
+    args = [capi.f32c(x) for x in (R, T, Wc, gAtA, gAtb, gabs)]
+    capi.check(L.banet_dense_adjoint_f32(ctypes.byref(problem.c), *[capi.ptr(x) for x in args], capi.ptr(dsrc), capi.ptr(dmap3),
+                                         capi.ptr(ddepth), capi.ptr(dbasis), capi.ptr(dpose), ctypes.c_void_p(ws.data_ptr()),
+                                         ws.numel(), capi.stream()))
+    return dpose, ws
+
+
+def target_map_adjoint(dmap3, dimg):
+    """banet_target_map_adjoint_f32: dimg [B,H,W,C] += the adjoint of banet_target_map_f32 applied to dmap3 [B,H,W,3C]."""
+    B, H, W, C = dimg.shape
+    capi.check(capi.lib().banet_target_map_adjoint_f32(capi.ptr(dmap3), capi.ptr(dimg), B, H, W, C, capi.stream()))
+    return dimg
+
+
+class _LevelSolve(torch.autograd.Function):
+    """All fixed-count iterations of one pyramid level."""
+
+    @staticmethod
+    def forward(ctx, ba, li, n_iter, src, tgt, depth, basis, R, T, Wc, *flat_layers):
+        prob, mlp = ba.problems[li], ba.mlps[li]
+        st = ops.LmState(R.detach(), T.detach(), Wc.detach(), P=6 + ba.K)
+        saved = []
+        for _ in range(n_iter):
+            Ri, Ti, Wi = st.R.clone(), st.T.clone(), st.Wc.clone()
+            AtA, Atb, absres, nvalid = ops.ba_assemble(prob, st.R, st.T, st.Wc)
+            ops.ba_solve_update(prob, mlp, ba.l2_base, AtA, Atb, absres, nvalid, st)
+            saved.append((Ri, Ti, Wi, AtA, Atb, absres))
+        ctx.ba, ctx.li, ctx.saved = ba, li, saved
+        ctx.layers = flat_layers
+        ctx.shapes = (src.shape, tgt.shape, depth.shape, basis.shape)
+        return st.R.clone(), st.T.clone(), st.Wc.clone()
+
+    @staticmethod
+    def backward(ctx, gR, gT, gW):
+        ba, li = ctx.ba, ctx.li
+        prob = ba.problems[li]
+        dev = prob.device
+        B, N, C, K, H, W = prob.B, prob.N, prob.C, prob.K, prob.c.H, prob.c.W
+        dsrc = torch.zeros((B, N, C), dtype=torch.float32, device=dev)
+        dmap3 = torch.zeros((B, H, W, 3 * C), dtype=torch.float32, device=dev)
+        ddepth = torch.zeros((B, N), dtype=torch.float32, device=dev)
+        dbasis = torch.zeros((B, N, K), dtype=torch.float32, device=dev)
+        flat = ctx.layers
+        layers = [(flat[2 * i], flat[2 * i + 1]) for i in range(5)]
+        glayers = [torch.zeros_like(t) for t in flat]
+        gR = torch.zeros(B, 3, 3, device=dev) if gR is None else gR.reshape(B, 3, 3)
+        gT = torch.zeros(B, 3, 1, device=dev) if gT is None else gT.reshape(B, 3, 1)
+        gW = torch.zeros(B, K, 1, device=dev) if gW is None else gW.reshape(B, K, 1)
+        ws = None
+        for Ri, Ti, Wi, AtA, Atb, absres in reversed(ctx.saved):
+            with torch.enable_grad():
+                leaves = [t.detach().requires_grad_(True) for t in (AtA, Atb, absres, Ri, Ti, Wi)]
+                lw = [t.detach().requires_grad_(True) for t in flat]
+                R2, T2, W2 = solve_update_graph(leaves[0], leaves[1], leaves[2], N, leaves[3], leaves[4], leaves[5],
+                                                [(lw[2 * i], lw[2 * i + 1]) for i in range(5)], ba.l2_base)
+                grads = torch.autograd.grad([R2, T2, W2], leaves + lw, [gR, gT, gW], allow_unused=True)
+            gAtA, gAtb, gabs_avg, dR, dT, dW = grads[:6]
+            for acc, g in zip(glayers, grads[6:]):
+                if g is not None:
+                    acc += g
+            dpose, ws = dense_adjoint(prob, Ri, Ti, Wi, gAtA, gAtb, gabs_avg, dsrc, dmap3, ddepth, dbasis, ws)
+            gR = dR + dpose[:, 0:9].reshape(B, 3, 3)
+            gT = dT + dpose[:, 9:12].reshape(B, 3, 1)
+            gW = dW + dpose[:, 12:].reshape(B, K, 1)
+        dtgt = torch.zeros((B, H, W, C), dtype=torch.float32, device=dev)
+        target_map_adjoint(dmap3, dtgt)
+        s_src, s_tgt, s_dep, s_bas = ctx.shapes
+        return (None, None, None, dsrc.reshape(s_src), dtgt.reshape(s_tgt), ddepth.reshape(s_dep), dbasis.reshape(s_bas),
+                gR, gT, gW) + tuple(glayers)
+
+
+def solve_differentiable(ba, levels, lambda_weights, iters_per_level, R=None, T=None, Wc=None):
+    """Differentiable DenseBA.solve with fixed iteration counts: `levels` = the DenseLevel objects `ba` was built from (their
+    src / tgt / depth / basis tensors may require grad), `lambda_weights` = per level five (filters, biases) pairs (tensors
+    that may require grad, or arrays).  Returns (R [B,3,3], T [B,3,1], Wc [B,K,1]) attached to the autograd graph."""
+    if ba.variant != "bundle" or ba.pairs != 1:
+        raise capi.BanetError("solve_differentiable: bundle variant with two-frame windows only")
+    dev = ba.intr.device
+    B, K = ba.B, ba.K
+    R = torch.eye(3, device=dev).repeat(B, 1, 1) if R is None else R
+    T = torch.zeros(B, 3, 1, device=dev) if T is None else T
+    Wc = torch.zeros(B, K, 1, device=dev) if Wc is None else Wc
+    for li, (lv, lw, n_it) in enumerate(zip(levels, lambda_weights, iters_per_level)):
+        if int(n_it) <= 0:
+            continue
+        flat = []
+        for w, b in lw:
+            w = _to_param(w, dev)
+            flat += [w.reshape(w.shape[-2], w.shape[-1]), _to_param(b, dev).reshape(-1)]
+        ba.mlps[li] = ops.MlpWeights([(flat[2 * i].detach(), flat[2 * i + 1].detach()) for i in range(5)], dev)
+        R, T, Wc = _LevelSolve.apply(ba, li, int(n_it), lv.src, lv.tgt, lv.depth, lv.basis, R, T, Wc, *flat)
+    return R, T, Wc

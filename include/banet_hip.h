@@ -31,7 +31,7 @@ extern "C" {
 typedef void* banet_stream_t; /* a hipStream_t (NULL = default stream) */
 #endif
 
-#define BANET_VERSION 130 /* 0.1.3: banet_lm_params_t / banet_lm_level_ex_f32 (0.1.2: banet_sample_stats[_grad]_f32; 0.1.1: banet_level_t.pairs) */
+#define BANET_VERSION 140 /* 0.1.4: banet_dense_adjoint_f32 / banet_target_map_adjoint_f32; 0.1.3: banet_lm_params_t / banet_lm_level_ex_f32 (0.1.2: banet_sample_stats[_grad]_f32; 0.1.1: banet_level_t.pairs) */
 
 enum {
   BANET_OK = 0,
@@ -234,6 +234,27 @@ int banet_sample_stats_f32(const float* conv1, const float* conv2, const float* 
 int banet_sample_stats_grad_f32(const float* conv1, const float* conv2, const float* px, const float* py, int B, int N,
                                 int C, int H, int W, const float* dstats, const float* dabs, float* dconv1,
                                 float* dconv2, float* dpos, banet_stream_t stream);
+
+/* (7b) backward of the fused dense assembly (3) -- SURVEY.md 8(f1).  Given the upstream gradients of ONE assembly pass at
+ *     the state (R, T, Wc),
+ *       gAtA [B,P,P] (any matrix: symmetrised internally, utils.cu:648-657 assumes symmetry), gAtb [B,P],
+ *       gabs [B,C] = dL/d(sum_n |d_nc|)  (= dL/d avg / N for bundlenet.py:243),
+ *     it ACCUMULATES (+=, so that the iterations of a level share one buffer; zero them first)
+ *       dsrc [B,N,C], dmap3 [B,H,W,3C] = adjoint of the target's [f|gx|gy] map (bundlenet.py:323-324), ddepth [B,N],
+ *       dbasis [B,N,K]
+ *     and WRITES dpose [B, 12 + K] = (dL/dR [9], dL/dT [3], dL/dWc [K]) through the assembly (the caller adds the
+ *     direct dependence of the update step on R, T, Wc).  What TF autodiff + EquationConstructionGrad (bundlenet.py:79-82,
+ *     utils.cu:465-694) compute for bundlenet.py:206-263, per pixel, without J / G / d in memory.  Bit-reproducible:
+ *     the target-map adjoint is gathered per texel in a fixed order (integer atomics only build the cell lists).
+ *     Supported: BANET_BUNDLE, dense = 1, tgt_has_grad = 0, pairs <= 1, 1 <= K <= 128, C <= 256 (else workspace_bytes = 0
+ *     and BANET_ERR_UNSUPPORTED).
+ *   banet_target_map_adjoint_f32: dimg [B,H,W,C] += dmap3_f + grad_fixed^T (dmap3_gx, dmap3_gy) -- the adjoint of
+ *     banet_target_map_f32 (REFLECT rim: zero gradient on the 1-px border, bundlenet.py:92-100); once per level.      */
+size_t banet_dense_adjoint_workspace_bytes(const banet_level_t* lv);
+int banet_dense_adjoint_f32(const banet_level_t* lv, const float* R, const float* T, const float* Wc, const float* gAtA,
+                            const float* gAtb, const float* gabs, float* dsrc, float* dmap3, float* ddepth,
+                            float* dbasis, float* dpose, void* ws, size_t ws_bytes, banet_stream_t stream);
+int banet_target_map_adjoint_f32(const float* dmap3, float* dimg, int B, int H, int W, int C, banet_stream_t stream);
 
 /* (8) optional kernel timing, used by bench.py for the roofline figure.  Between
  *     banet_profile_begin and banet_profile_end every launch of the fused assembly kernel

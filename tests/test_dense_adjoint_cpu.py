@@ -77,3 +77,23 @@ def test_assembly_adjoint_matches_finite_differences(seed):
     checks.append(("W", num, float((out["dW"] * d).sum())))
     for name, num, ana in checks:
         assert abs(num - ana) <= 1e-4 * max(abs(num), abs(ana)) + 1e-7, (name, num, ana)
+
+
+def test_solve_update_graph_equals_the_oracle_iteration_tail():
+    """banet_amd.dense_train.solve_update_graph (the small differentiable part of the fused backward: lambda MLP, damping,
+    solve, SE(3) / W update on the saved normal equations) reproduces oracle.bundle_iteration from its own AtA / Atb / avg."""
+    import torch
+    from banet_amd import dense_train
+    intr, lv, R, T, Wc, rng = _scene()
+    C = lv["src"].shape[-1]
+    N = lv["src"].shape[1] * lv["src"].shape[2]
+    a = odense.level_inputs(intr, lv, True, np.float64)
+    mlp = orc.he_normal_mlp_weights(C, 5, np.float64)
+    Rn, Tn, Wn, dbg = orc.bundle_iteration(a["conv1"], a["conv2"], a["fx"], a["fy"], a["ox"], a["oy"], a["p"], a["D"], a["Bs"],
+                                           R, T, Wc, mlp, 1000.0)
+    tt = lambda v: torch.from_numpy(np.asarray(v, np.float64))
+    layers = [(tt(w), tt(b)) for w, b in mlp]
+    R2, T2, W2 = dense_train.solve_update_graph(tt(dbg["AtA"]), tt(dbg["Atb"][..., 0]), tt(dbg["avg"][:, 0] * N), N, tt(R), tt(T),
+                                                tt(Wc), layers, 1000.0)
+    for got, want in ((R2, Rn), (T2, Tn), (W2, Wn)):
+        np.testing.assert_allclose(got.numpy(), want, rtol=1e-9, atol=1e-12)

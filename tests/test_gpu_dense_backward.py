@@ -1,0 +1,166 @@
+"""Fused backward of the dense BA path (`-m gpu`, through the C ABI): banet_dense_adjoint_f32 / banet_target_map_adjoint_f32
+against the float64 statement of the same adjoint (oracle/dense_adjoint.py, itself validated against finite differences
+on the CPU), bit-reproducibility, and DenseBA.solve_differentiable end to end against finite differences of the float64
+ORACLE chain (oracle.dense.solve_bundle)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import banet_oracle as orc, dense as odense, dense_adjoint as oadj, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from banet_amd import _capi
+    _capi.lib()
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(x, np.float32))).to(DEV)
+
+
+def n(x):
+    return x.detach().cpu().numpy().astype(np.float64)
+
+
+def _scene(H, W, C, K, seed, B=2, scales=(1,)):
+    scenes = [synth.make_pair_scene(H, W, C, K, list(scales), seed + b, normalize_rays=True, w_gt=[0.01, -0.008, 0.006],
+                                    t_gt=[0.06, -0.04, 0.03]) for b in range(B)]
+    intr, levels = odense.batch_scene(scenes)
+    rng = np.random.RandomState(seed)
+    R = np.stack([synth.rodrigues(0.004 * rng.standard_normal(3)) for _ in range(B)])
+    T = np.stack([np.asarray(s["T_gt"]) * 0.7 for s in scenes]).reshape(B, 3, 1)
+    Wc = 0.02 * rng.standard_normal((B, K, 1))
+    return intr, levels, R, T, Wc, rng
+
+
+def _run_adjoint(intr, lv, R, T, Wc, G, gb, gabs):
+    from banet_amd import dense as bdense, dense_train
+    B, H, W, C = lv["src"].shape
+    K = lv["basis"].shape[-1]
+    level = bdense.DenseLevel(lv["scale"], t(lv["src"]), t(lv["tgt"]), t(lv["D0"]), t(lv["basis"]))
+    ba = bdense.DenseBA(t(intr), [level], [orc.he_normal_mlp_weights(C, 5)], "bundle", 1000.0)
+    prob = ba.problems[0]
+    out = dict(dsrc=torch.zeros(B, H * W, C, device=DEV), dmap3=torch.zeros(B, H, W, 3 * C, device=DEV),
+               ddepth=torch.zeros(B, H * W, device=DEV), dbasis=torch.zeros(B, H * W, K, device=DEV))
+    dpose, _ = dense_train.dense_adjoint(prob, t(R), t(T), t(Wc), t(G), t(gb).reshape(B, -1), t(gabs).reshape(B, -1),
+                                        out["dsrc"], out["dmap3"], out["ddepth"], out["dbasis"])
+    dtgt = torch.zeros(B, H, W, C, device=DEV)
+    dense_train.target_map_adjoint(out["dmap3"], dtgt)
+    torch.cuda.synchronize()
+    return dict(dsrc=out["dsrc"], dmap3=out["dmap3"], ddepth=out["ddepth"], dbasis=out["dbasis"], dpose=dpose, dtgt=dtgt)
+
+
+@pytest.mark.parametrize("H,W,C,K,seed", [(24, 32, 6, 5, 3), (48, 64, 128, 128, 7), (30, 41, 70, 33, 11)])
+def test_dense_adjoint_kernels_match_the_float64_statement(H, W, C, K, seed):
+    intr, levels, R, T, Wc, rng = _scene(H, W, C, K, seed)
+    lv = levels[0]
+    B, P = 2, 6 + K
+    G = rng.standard_normal((B, P, P))             # not symmetric on purpose
+    gb = rng.standard_normal((B, P, 1))
+    gabs = rng.standard_normal((B, 1, C)) * 0.1
+    # float32-rounded inputs on both sides
+    f32 = lambda v: np.asarray(v, np.float32).astype(np.float64)
+    lv64 = {k: (f32(v) if isinstance(v, np.ndarray) else v) for k, v in lv.items()}
+    a = odense.level_inputs(intr, lv64, True, np.float64)
+    N = H * W
+    want = oadj.assembly_adjoint(a, lv64["tgt"], f32(R), f32(T), f32(Wc), f32(G), f32(gb), f32(gabs) * N)   # gavg = N gabs
+    got = _run_adjoint(intr, lv, R, T, Wc, G, gb, gabs)
+    assert want["fwd"]["mask"].mean() > 0.5
+    pairs = [("dsrc", want["dsrc"]), ("dmap3", want["dmap"]), ("dtgt", want["dtgt"]), ("ddepth", want["dD0"]),
+             ("dbasis", want["dbasis"])]
+    for name, w in pairs:
+        g = n(got[name]).reshape(w.shape)
+        err = np.abs(g - w).max() / max(np.abs(w).max(), 1e-30)
+        assert err < 2e-4, (name, err)
+    dpose = n(got["dpose"])
+    for name, sl, w in (("dR", slice(0, 9), want["dR"].reshape(B, 9)), ("dT", slice(9, 12), want["dT"].reshape(B, 3)),
+                        ("dW", slice(12, None), want["dW"].reshape(B, K))):
+        err = np.abs(dpose[:, sl] - w).max() / max(np.abs(w).max(), 1e-30)
+        assert err < 5e-4, (name, err)
+
+
+def test_dense_adjoint_is_bit_reproducible():
+    intr, levels, R, T, Wc, rng = _scene(48, 64, 128, 32, 5)
+    B, K, C = 2, 32, 128
+    G = rng.standard_normal((B, 6 + K, 6 + K))
+    gb = rng.standard_normal((B, 6 + K, 1))
+    gabs = rng.standard_normal((B, 1, C)) * 0.1
+    a = _run_adjoint(intr, levels[0], R, T, Wc, G, gb, gabs)
+    for _ in range(2):
+        b = _run_adjoint(intr, levels[0], R, T, Wc, G, gb, gabs)
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+
+
+def test_solve_differentiable_matches_the_fused_forward_and_oracle_finite_differences():
+    from banet_amd import dense as bdense
+    H, W, C, K, B = 48, 64, 16, 8, 2
+    iters = [2, 2]
+    intr, levels, _, T0, _, rng = _scene(H, W, C, K, 21, B=B, scales=(2, 1))
+    mlps = [orc.he_normal_mlp_weights(C, 40 + i, np.float64) for i in range(2)]
+    cR, cT, cW = rng.standard_normal((B, 3, 3)), rng.standard_normal((B, 3, 1)), rng.standard_normal((B, K, 1))
+
+    def oracle_loss(levels_, mlps_):
+        R, T, Wn, _ = _oracle_chain(levels_, mlps_)
+        return float((cR * R).sum() + (cT * T).sum() + (cW * Wn).sum())
+
+    def _oracle_chain(levels_, mlps_):
+        R = np.tile(np.eye(3)[None], (B, 1, 1))
+        T = T0.astype(np.float64).copy()
+        Wn = np.zeros((B, K, 1))
+        for li, lv in enumerate(levels_):
+            a = odense.level_inputs(np.asarray(intr, np.float64), lv, True, np.float64)
+            for _ in range(iters[li]):
+                R, T, Wn, _ = orc.bundle_iteration(a["conv1"], a["conv2"], a["fx"], a["fy"], a["ox"], a["oy"], a["p"], a["D"],
+                                                   a["Bs"], R, T, Wn, mlps_[li], 1000.0)
+        return R, T, Wn, None
+
+    lv64 = [{k: (np.asarray(v, np.float32).astype(np.float64) if isinstance(v, np.ndarray) else v) for k, v in lv.items()}
+            for lv in levels]
+    # ---- GPU: forward values equal the fused solve, gradients by the fused backward
+    tl = [bdense.DenseLevel(lv["scale"], t(lv["src"]).requires_grad_(True), t(lv["tgt"]).requires_grad_(True),
+                            t(lv["D0"]).requires_grad_(True), t(lv["basis"]).requires_grad_(True)) for lv in levels]
+    tm = [[(t(w).requires_grad_(True), t(b).requires_grad_(True)) for w, b in lw] for lw in mlps]
+    ba = bdense.DenseBA(t(intr), tl, tm, "bundle", 1000.0)
+    R, T, Wn = ba.solve_differentiable(iters, T=t(T0))
+    st = ba.new_state(T=t(T0))
+    ba.solve(iters, st)
+    assert torch.allclose(R, st.R, atol=1e-6) and torch.allclose(T, st.T, atol=1e-6) and torch.allclose(Wn, st.Wc, atol=1e-6)
+    Ro, To, Wo, _ = _oracle_chain(lv64, mlps)
+    for got, want in ((R, Ro), (T, To), (Wn, Wo)):
+        assert np.abs(n(got) - want).max() <= 1e-4 * max(np.abs(want).max(), 1e-6)
+    loss = (t(cR) * R).sum() + (t(cT) * T).sum() + (t(cW) * Wn).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+
+    # ---- float64 oracle: central differences along random directions
+    def fd(apply, shape, eps):
+        d = rng.standard_normal(shape)
+        d /= np.linalg.norm(d)
+        vals = sorted((apply(e * d) - apply(-e * d)) / (2 * e) for e in (eps, 3 * eps, 10 * eps))
+        return d, vals[1]
+
+    checks = []
+    for li in range(2):
+        for key, tens in (("src", tl[li].src), ("tgt", tl[li].tgt), ("D0", tl[li].depth), ("basis", tl[li].basis)):
+            def apply(dl, li=li, key=key):
+                l2 = [dict(x) for x in lv64]
+                l2[li][key] = lv64[li][key] + dl
+                return oracle_loss(l2, mlps)
+            d, num = fd(apply, lv64[li][key].shape, 1e-5)
+            checks.append(("%s[%d]" % (key, li), num, float((n(tens.grad) * d).sum())))
+        for wi in (0, 4):
+            def apply(dl, li=li, wi=wi):
+                m2 = [[(w.copy(), b.copy()) for w, b in lw] for lw in mlps]
+                m2[li][wi] = (m2[li][wi][0] + dl, m2[li][wi][1])
+                return oracle_loss(lv64, m2)
+            d, num = fd(apply, mlps[li][wi][0].shape, 1e-4)
+            checks.append(("mlp[%d][%d]" % (li, wi), num, float((n(tm[li][wi][0].grad) * d).sum())))
+    scale = max(abs(c[1]) for c in checks)
+    for name, num, ana in checks:
+        assert abs(num - ana) <= 2e-2 * max(abs(num), abs(ana)) + 1e-4 * scale, (name, num, ana)
