@@ -107,6 +107,11 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
   const int grp = lane >> 4, sub = lane & 15;
   const int half = lane >> 5, li = lane & 31;
 
+#ifdef BANET_ABLATE   // development aid (tools/prof_assemble.py): reserved_ bits 0..3 switch phases of this kernel off
+  const int abl = lv.reserved_;
+#else
+  constexpr int abl = 0;
+#endif
   float wreg[KV4 ? KV4 : 1][4];  // this lane's slice of the depth coefficients
   // The waves of a workgroup start 7 us apart (s_sleep 127 = 8128 cycles): launched together they stay in lock-step through
   // the first tiles (depth-dot burst, then every unit's loads at the same time); measured 320x240 x 8: 39.0 -> 37.6
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
     // (16 B per lane); 32 row pairs go through a 5-level transposing butterfly inside each half,
     // leaf t of half h carrying pixel h*32 + brev5p(t), so that pixel j's sum lands on lane j.
     float D = valid ? dep_b[pt] : 0.f;
-    if constexpr (KV4 > 0) {
+    if (KV4 > 0 && !(abl & 4)) {
       float pend[6];
       float part[32];   // all 32 row loads of the half wave in flight together (2 waves per SIMD: 256 VGPRs)
 #pragma unroll
@@ -336,7 +341,8 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
       int row = 0, col = lane >> 4;                       // texel (lane >> 4) + 4 i of the box, pw_ >= 4
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
-        const unsigned off = (unsigned)gb + (unsigned)((min(row, ph_ - 1) * W + col) * C) + 4u * (unsigned)sub + 64u * (unsigned)h_;
+        unsigned off = (unsigned)gb + (unsigned)((min(row, ph_ - 1) * W + col) * C) + 4u * (unsigned)sub + 64u * (unsigned)h_;
+        if (abl & 1) off = 4u * (unsigned)sub + 64u * (unsigned)h_ + (unsigned)((lane >> 4) * C);   // every box = texels 0..3
         pst[i] = *reinterpret_cast<const f32x4*>(tgt_b + (size_t)off);
         col += 4;
         if (col >= pw_) {
@@ -346,7 +352,8 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
       }
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const unsigned osrc = (unsigned)__float_as_int(sPar[w][4 * (2 * sp_ + t) + grp][0]);
+        unsigned osrc = (unsigned)__float_as_int(sPar[w][4 * (2 * sp_ + t) + grp][0]);
+        if (abl & 2) osrc = (unsigned)(grp * C);                                                        // every source row = pixels 0..3
         pf1[t] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src_b + (size_t)(osrc + 64u * (unsigned)h_ + 4u * sub)));
       }
     };
@@ -378,6 +385,7 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
             if (pre) issue(nsp, nh);
           }
           const int rs = pw * 64;
+          if (!(abl & 8))
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
             const float* l = &sPatch[w][0] + __float_as_int(pb[t].w) + 4 * sub;

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""profiles/pmc_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over `bench.py --steps 1 --warmup 0`:
+mean HBM-side bytes per gather launch (all levels), corrected as MI355X_MICROARCH.md's HBM section prescribes (FETCH_SIZE
+x 2 on gfx950; WRITE_SIZE taken at face value).   python tools/make_pmc_traffic.py <fetch_dir> <write_dir> <windows> <out.json>"""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+
+def per_kernel(d, counter):
+    acc = defaultdict(list)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if row.get("Counter_Name") == counter:
+                    acc[row.get("Kernel_Name", "?")].append(float(row.get("Counter_Value", 0)))
+    return acc
+
+
+def main(fetch_dir, write_dir, windows, out):
+    fe, wr = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
+    g = lambda acc: [(k, v) for k, v in acc.items() if "ba_gather128" in k]
+    nl = sum(len(v) for _, v in g(fe))
+    fetch_kb = sum(sum(v) for _, v in g(fe)) / max(nl, 1)
+    nw = sum(len(v) for _, v in g(wr))
+    write_kb = sum(sum(v) for _, v in g(wr)) / max(nw, 1)
+    C = K = 128
+    alg = sum(4 * (480 // s) * (640 // s) * (2 * C + K + 1) for s in (16, 8, 4, 2, 1)) * int(windows) * 10 / 50.0
+    hbm = 2.0 * fetch_kb * 1024 + write_kb * 1024
+    rec = {"kernel": "; ".join("%s x %d" % (k.split("(")[0].replace("void ", ""), len(v)) for k, v in g(fe)),
+           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 0 --no-sweep "
+                     "--no-parity --no-cpu-baseline` (headline workload): mean over its %d gather launches, all 5 levels" % nl,
+           "windows": int(windows), "fetch_size_kb_per_launch": round(fetch_kb, 1), "write_size_kb_per_launch": round(write_kb, 1),
+           "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B -> x2 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE "
+                         "uncalibrated, taken at face value",
+           "hbm_bytes_per_launch": int(round(hbm)), "algorithmic_bytes_per_launch": int(round(alg)),
+           "overfetch": round(hbm / alg, 4),
+           "syrk_fetch_kb_per_launch": round(sum(sum(v) for k, v in fe.items() if "ba_syrk" in k) /
+                                             max(sum(len(v) for k, v in fe.items() if "ba_syrk" in k), 1), 1)}
+    json.dump(rec, open(out, "w"), indent=1)
+    print(json.dumps(rec))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:5])
