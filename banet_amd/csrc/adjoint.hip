@@ -50,7 +50,7 @@ struct AdjArgs {
   float* arow;        // [B][N][3C]
   float* frac;        // [B][N][4]   key (int), ax, ay, -
   int* cnt;           // [B][HW]
-  int* start;         // [B][HW]
+  int* start;         // [B][HW][2]  (start, count)
   int* cursor;        // [B][HW]
   int* list;          // [B][N]
   float* part;        // [B][G * 4][kAdjHdr + K]
@@ -73,7 +73,7 @@ __global__ void adj_sym_kernel(const float* __restrict__ g, float* __restrict__ 
 
 // ---- the GEMM-shaped piece --------------------------------------------------------------------------------------------
 template <int NK>   // KP = 16 NK >= K
-__global__ __launch_bounds__(kBlock) void adj_basis_kernel(const AdjArgs a) {
+__global__ __launch_bounds__(kBlock, 2) void adj_basis_kernel(const AdjArgs a) {
   extern __shared__ float Wl[];
   constexpr int KP = 16 * NK, LS = KP + 20, NB = NK + 1;   // LS: 4 kq groups 4 LS floats apart -> 16 banks apart
   const int b = blockIdx.y, K = a.lv.K, N = a.lv.N, P = 6 + K;
@@ -117,13 +117,15 @@ __global__ __launch_bounds__(kBlock) void adj_basis_kernel(const AdjArgs a) {
 #pragma unroll
     for (int jb = 0; jb < NB; ++jb) acc[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kk = 0; kk < NK; ++kk)
+    for (int kk = 0; kk < NK; ++kk) {
+      asm volatile("" ::: "memory");   // keeps the LDS operand reads inside the row-block loop (LICM would hoist all 36 NK of them)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float* wl = Wl + (16 * kk + 4 * kq + e) * LS + i;
 #pragma unroll
         for (int jb = 0; jb < NB; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk][e], wl[16 * jb], acc[jb], 0, 0, 0);
       }
+    }
     // accumulator layout: lane (j = lane & 15, rq = lane >> 4) holds rows 4 rq + v, column 16 jb + j
     float zeta[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -153,11 +155,22 @@ __global__ __launch_bounds__(kBlock) void adj_basis_kernel(const AdjArgs a) {
 }
 
 // ---- per-pixel adjoint ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void adj_pixel_kernel(const AdjArgs a) {
+// sum over the wave, every lane gets it: DPP row sums + 4 v_readlane (the ds_bpermute butterfly of wave_sum costs ~6 LDS
+// round trips per value; this kernel needs 8 sums per pixel).  Fixed order -> deterministic.
+__device__ __forceinline__ float wsum(float v) {
+  v = row16_sum(v);
+  const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float a2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float a3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return (a0 + a1) + (a2 + a3);
+}
+
+template <int CJ, int KJ>   // C <= 64 CJ, K <= 64 KJ
+__global__ __launch_bounds__(kBlock, 3) void adj_pixel_kernel(const AdjArgs a) {
   const banet_level_t& lv = a.lv;
   const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x & 63, w = wave_id();
   const int N = lv.N, C = lv.C, K = lv.K, H = lv.H, W = lv.W, P = 6 + K;
-  const int CJ = (C + 63) >> 6, KJ = (K + 63) >> 6;
   const float* __restrict__ src_b = lv.src + (size_t)b * N * C;
   const float* __restrict__ tgt_b = lv.tgt + (size_t)b * N * C;
   const float* __restrict__ bas_b = lv.basis + (size_t)b * N * K;
@@ -176,22 +189,24 @@ __global__ __launch_bounds__(kBlock) void adj_pixel_kernel(const AdjArgs a) {
   for (int i = 0; i < 3; ++i) Tv[i] = a.T[b * 3 + i];
   const float fx0 = lv.intr[b * 4 + 0], fy0 = lv.intr[b * 4 + 1], ox0 = lv.intr[b * 4 + 2], oy0 = lv.intr[b * 4 + 3];
   const float fx = fx0 / lv.scale, fy = fy0 / lv.scale, ox = ox0 / lv.scale, oy = oy0 / lv.scale;
-  float wc[kAdjMaxKJ], scd[kAdjMaxKJ][6], gbd[kAdjMaxKJ], dwc[kAdjMaxKJ];
+  float wc[KJ], scd[KJ][6], gbd[KJ], dwc[KJ];
+  bool kok[KJ], cok[CJ];
 #pragma unroll
-  for (int j = 0; j < kAdjMaxKJ; ++j) {
+  for (int j = 0; j < KJ; ++j) {
     const int k = lane + 64 * j;
-    const bool ok = k < K;
-    wc[j] = ok ? a.Wc[(size_t)b * K + k] : 0.f;
-    gbd[j] = ok ? gb[6 + k] : 0.f;
+    kok[j] = k < K;
+    wc[j] = kok[j] ? a.Wc[(size_t)b * K + k] : 0.f;
+    gbd[j] = kok[j] ? gb[6 + k] : 0.f;
     dwc[j] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) scd[j][i] = ok ? S[i * P + 6 + k] : 0.f;
+    for (int i = 0; i < 6; ++i) scd[j][i] = kok[j] ? S[i * P + 6 + k] : 0.f;
   }
-  float ga[kAdjMaxCJ];
+  float ga[CJ];
 #pragma unroll
-  for (int j = 0; j < kAdjMaxCJ; ++j) {
+  for (int j = 0; j < CJ; ++j) {
     const int c = lane + 64 * j;
-    ga[j] = c < C ? a.gabs[(size_t)b * C + c] : 0.f;
+    cok[j] = c < C;
+    ga[j] = cok[j] ? a.gabs[(size_t)b * C + c] : 0.f;
   }
   float accR[9], accT[3];
 #pragma unroll
@@ -211,14 +226,23 @@ __global__ __launch_bounds__(kBlock) void adj_pixel_kernel(const AdjArgs a) {
       p1 *= inv;
       p2 *= inv;
     }
-    float bv[kAdjMaxKJ], bsum = 0.f;
+    float bv[KJ], z2v[KJ], f1v[CJ], bsum = 0.f;
 #pragma unroll
-    for (int j = 0; j < kAdjMaxKJ; ++j) {
-      const int k = lane + 64 * j;
-      bv[j] = (j < KJ && k < K) ? bas_b[(size_t)n * K + k] : 0.f;
+    for (int j = 0; j < KJ; ++j) {
+      const int k = kok[j] ? lane + 64 * j : 0;
+      bv[j] = bas_b[(size_t)n * K + k];
+      z2v[j] = a.z2[((size_t)b * N + n) * K + k];
+      bv[j] = kok[j] ? bv[j] : 0.f;
       bsum = fmaf(bv[j], wc[j], bsum);
     }
-    const float D = lv.depth[(size_t)b * N + n] + wave_sum(bsum);
+#pragma unroll
+    for (int j = 0; j < CJ; ++j) f1v[j] = src_b[(size_t)n * C + (cok[j] ? lane + 64 * j : 0)];
+    const float* __restrict__ ar = a.arec + ((size_t)b * N + n) * 8;
+    float q[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) q[i] = ar[i];
+    const float zeta = ar[6], ee = ar[7];
+    const float D = lv.depth[(size_t)b * N + n] + wsum(bsum);
     const float rx = Rm[0] * p0 + Rm[1] * p1 + Rm[2] * p2;
     const float ry = Rm[3] * p0 + Rm[4] * p1 + Rm[5] * p2;
     const float rz = Rm[6] * p0 + Rm[7] * p1 + Rm[8] * p2;
@@ -234,64 +258,67 @@ __global__ __launch_bounds__(kBlock) void adj_pixel_kernel(const AdjArgs a) {
     const float xf = floorf(px), yf = floorf(py);
     const int x0 = (int)xf, y0 = (int)yf;
     const float ax = px - xf, ay = py - yf;
-    // ---- taps of the [f|gx|gy] map, gradient on the fly (grad_fixed, REFLECT rim -> 0), zero outside the image
-    float Sf[kAdjMaxCJ], Sgx[kAdjMaxCJ], Sgy[kAdjMaxCJ], Ax[kAdjMaxCJ][3], Ay[kAdjMaxCJ][3], dif[kAdjMaxCJ];
+    // ---- the 4x4 neighbourhood (minus corners) of the target map, clamped to the image: 12 coalesced row loads per
+    // channel chunk; [f|gx|gy] at the 4 bilinear taps from it (grad_fixed on the fly, REFLECT rim -> 0, outside -> 0)
+    float tex[CJ][4][4];
 #pragma unroll
-    for (int j = 0; j < kAdjMaxCJ; ++j) {
-      Sf[j] = Sgx[j] = Sgy[j] = dif[j] = 0.f;
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        if ((r == 0 || r == 3) && (cc == 0 || cc == 3)) continue;
+        const int yy = min(max(y0 - 1 + r, 0), H - 1), xx = min(max(x0 - 1 + cc, 0), W - 1);
+        const float* __restrict__ row = tgt_b + (size_t)(yy * W + xx) * C;
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) tex[j][r][cc] = row[cok[j] ? lane + 64 * j : 0];
+      }
+    float Sf[CJ], Sgx[CJ], Sgy[CJ], Ax[CJ][3], Ay[CJ][3], dif[CJ];
+#pragma unroll
+    for (int j = 0; j < CJ; ++j) {
+      Sf[j] = Sgx[j] = Sgy[j] = 0.f;
 #pragma unroll
       for (int e = 0; e < 3; ++e) Ax[j][e] = Ay[j][e] = 0.f;
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const int tx = x0 + (t & 1), ty = y0 + (t >> 1);
+      const int ix = t & 1, iy = t >> 1;
+      const int tx = x0 + ix, ty = y0 + iy;
       const bool in = tx <= W - 1 && ty <= H - 1;
-      const int txc = min(tx, W - 1), tyc = min(ty, H - 1);
-      const float hx = (in && txc > 0 && txc < W - 1) ? 0.5f : 0.f, hy = (in && tyc > 0 && tyc < H - 1) ? 0.5f : 0.f;
+      const float hx = (in && tx > 0 && tx < W - 1) ? 0.5f : 0.f, hy = (in && ty > 0 && ty < H - 1) ? 0.5f : 0.f;
       const float fin = in ? 1.f : 0.f;
-      const int xm = max(txc - 1, 0), xp = min(txc + 1, W - 1), ym = max(tyc - 1, 0), yp = min(tyc + 1, H - 1);
-      const float wx = (t & 1) ? ax : 1.f - ax, wy = (t >> 1) ? ay : 1.f - ay;
-      const float wt = wx * wy, sx = ((t & 1) ? 1.f : -1.f) * wy, sy = ((t >> 1) ? 1.f : -1.f) * wx;
-      const float* __restrict__ rc = tgt_b + (size_t)(tyc * W + txc) * C;
-      const float* __restrict__ rl = tgt_b + (size_t)(tyc * W + xm) * C;
-      const float* __restrict__ rr = tgt_b + (size_t)(tyc * W + xp) * C;
-      const float* __restrict__ ru = tgt_b + (size_t)(ym * W + txc) * C;
-      const float* __restrict__ rd = tgt_b + (size_t)(yp * W + txc) * C;
+      const float wx = ix ? ax : 1.f - ax, wy = iy ? ay : 1.f - ay;
+      const float wt = wx * wy, sx = (ix ? 1.f : -1.f) * wy, sy = (iy ? 1.f : -1.f) * wx;
 #pragma unroll
-      for (int j = 0; j < kAdjMaxCJ; ++j) {
-        const int c = lane + 64 * j;
-        if (j < CJ && c < C) {
-          const float F = fin * rc[c], GX = hx * (rr[c] - rl[c]), GY = hy * (rd[c] - ru[c]);
-          Sf[j] = fmaf(wt, F, Sf[j]);
-          Sgx[j] = fmaf(wt, GX, Sgx[j]);
-          Sgy[j] = fmaf(wt, GY, Sgy[j]);
-          Ax[j][0] = fmaf(sx, F, Ax[j][0]);
-          Ax[j][1] = fmaf(sx, GX, Ax[j][1]);
-          Ax[j][2] = fmaf(sx, GY, Ax[j][2]);
-          Ay[j][0] = fmaf(sy, F, Ay[j][0]);
-          Ay[j][1] = fmaf(sy, GX, Ay[j][1]);
-          Ay[j][2] = fmaf(sy, GY, Ay[j][2]);
-        }
+      for (int j = 0; j < CJ; ++j) {
+        const float F = fin * tex[j][1 + iy][1 + ix];
+        const float GX = hx * (tex[j][1 + iy][2 + ix] - tex[j][1 + iy][ix]);
+        const float GY = hy * (tex[j][2 + iy][1 + ix] - tex[j][iy][1 + ix]);
+        Sf[j] = fmaf(wt, F, Sf[j]);
+        Sgx[j] = fmaf(wt, GX, Sgx[j]);
+        Sgy[j] = fmaf(wt, GY, Sgy[j]);
+        Ax[j][0] = fmaf(sx, F, Ax[j][0]);
+        Ax[j][1] = fmaf(sx, GX, Ax[j][1]);
+        Ax[j][2] = fmaf(sx, GY, Ax[j][2]);
+        Ay[j][0] = fmaf(sy, F, Ay[j][0]);
+        Ay[j][1] = fmaf(sy, GX, Ay[j][1]);
+        Ay[j][2] = fmaf(sy, GY, Ay[j][2]);
       }
     }
     float M11 = 0.f, M12 = 0.f, M22 = 0.f, g1 = 0.f, g2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < kAdjMaxCJ; ++j) {
-      const int c = lane + 64 * j;
-      if (j < CJ && c < C) {
-        dif[j] = src_b[(size_t)n * C + c] - Sf[j];       // bundlenet.py:234
-        M11 = fmaf(Sgx[j], Sgx[j], M11);
-        M12 = fmaf(Sgx[j], Sgy[j], M12);
-        M22 = fmaf(Sgy[j], Sgy[j], M22);
-        g1 = fmaf(Sgx[j], dif[j], g1);
-        g2 = fmaf(Sgy[j], dif[j], g2);
-      }
+    for (int j = 0; j < CJ; ++j) {
+      if (!cok[j]) Sf[j] = Sgx[j] = Sgy[j] = f1v[j] = 0.f;
+      dif[j] = f1v[j] - Sf[j];       // bundlenet.py:234
+      M11 = fmaf(Sgx[j], Sgx[j], M11);
+      M12 = fmaf(Sgx[j], Sgy[j], M12);
+      M22 = fmaf(Sgy[j], Sgy[j], M22);
+      g1 = fmaf(Sgx[j], dif[j], g1);
+      g2 = fmaf(Sgy[j], dif[j], g2);
     }
-    M11 = wave_sum(M11);
-    M12 = wave_sum(M12);
-    M22 = wave_sum(M22);
-    g1 = wave_sum(g1);
-    g2 = wave_sum(g2);
+    M11 = wsum(M11);
+    M12 = wsum(M12);
+    M22 = wsum(M22);
+    g1 = wsum(g1);
+    g2 = wsum(g2);
     // ---- per-pixel algebra (bundlenet.py:49-74 Jacobians with the bundle sign, J = [-Jc | jd b])
     const float iz = 1.f / Z;
     float J0[6], J1[6];
@@ -308,11 +335,6 @@ __global__ __launch_bounds__(kBlock) void adj_pixel_kernel(const AdjArgs a) {
     J1[4] = fy * iz;
     J1[5] = fy * (-(y * iz));
     const float jd0 = fx * ((rx - rz * x) * iz), jd1 = fy * ((ry - rz * y) * iz);
-    const float* __restrict__ ar = a.arec + ((size_t)b * N + n) * 8;
-    float q[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) q[i] = ar[i];
-    const float zeta = ar[6], ee = ar[7];
     float JS0[6], JS1[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -354,9 +376,9 @@ __global__ __launch_bounds__(kBlock) void adj_pixel_kernel(const AdjArgs a) {
     float* __restrict__ dsrc_n = a.dsrc + ((size_t)b * N + n) * C;
     float* __restrict__ arow_n = a.arow + ((size_t)b * N + n) * 3 * C;
 #pragma unroll
-    for (int j = 0; j < kAdjMaxCJ; ++j) {
+    for (int j = 0; j < CJ; ++j) {
       const int c = lane + 64 * j;
-      if (j < CJ && c < C) {
+      if (cok[j]) {
         const float d = dif[j], gx = Sgx[j], gy = Sgy[j];
         const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
         const float dd = dg1 * gx + dg2 * gy + sgn * ga[j];
@@ -370,8 +392,8 @@ __global__ __launch_bounds__(kBlock) void adj_pixel_kernel(const AdjArgs a) {
         dpy += -dd * Ay[j][0] + dgx * Ay[j][1] + dgy * Ay[j][2];
       }
     }
-    dpx = wave_sum(dpx);
-    dpy = wave_sum(dpy);
+    dpx = wsum(dpx);
+    dpy = wsum(dpy);
     // ---- geometry adjoint
     float dx_ = fx * dpx + fx * (-y * dJ0[0] + 2.f * x * dJ0[1] - dJ0[5] * iz) + fy * (y * dJ1[1] + dJ1[2]);
     float dy_ = fy * dpy + fx * (-x * dJ0[0] - dJ0[2]) + fy * (-2.f * y * dJ1[0] + x * dJ1[1] - dJ1[5] * iz);
@@ -399,12 +421,11 @@ __global__ __launch_bounds__(kBlock) void adj_pixel_kernel(const AdjArgs a) {
     accR[8] = fmaf(drz, p2, accR[8]);
     // ---- depth, basis, coefficients
     float* __restrict__ dbas_n = a.dbasis + ((size_t)b * N + n) * K;
-    const float* __restrict__ z2_n = a.z2 + ((size_t)b * N + n) * K;
 #pragma unroll
-    for (int j = 0; j < kAdjMaxKJ; ++j) {
+    for (int j = 0; j < KJ; ++j) {
       const int k = lane + 64 * j;
-      if (j < KJ && k < K) {
-        float v = s_n * z2_n[k] + r_n * gbd[j] + dD * wc[j];
+      if (kok[j]) {
+        float v = s_n * z2v[j] + r_n * gbd[j] + dD * wc[j];
         float su = 0.f;
 #pragma unroll
         for (int i = 0; i < 6; ++i) su = fmaf(u[i], scd[j][i], su);
@@ -430,7 +451,7 @@ __global__ __launch_bounds__(kBlock) void adj_pixel_kernel(const AdjArgs a) {
   for (int i = 0; i < 3; ++i)
     if (lane == 9 + i) prow[9 + i] = accT[i];
 #pragma unroll
-  for (int j = 0; j < kAdjMaxKJ; ++j) {
+  for (int j = 0; j < KJ; ++j) {
     const int k = lane + 64 * j;
     if (k < K) prow[kAdjHdr + k] = dwc[j];
   }
@@ -473,9 +494,11 @@ __global__ __launch_bounds__(kScanThreads) void adj_scan_kernel(const int* __res
   }
   int run = sSum[tid] - s;
   for (int i = lo; i < hi; ++i) {
-    start[(size_t)b * HW + i] = run;
+    const int ci = c[i];
+    start[2 * ((size_t)b * HW + i)] = run;        // (start, count) pairs: one 8-byte load per cell in adj_map_kernel
+    start[2 * ((size_t)b * HW + i) + 1] = ci;
     cursor[(size_t)b * HW + i] = run;
-    run += c[i];
+    run += ci;
   }
 }
 
@@ -495,45 +518,75 @@ __device__ __forceinline__ int wave_min_i(int v) {
 }
 
 // One wave per target texel: the adjoint of the bilinear sampling as a GATHER over the source pixels whose footprint
-// covers the texel, in a fixed order (cells row-major, ascending pixel index inside a cell).
+// covers the texel, in a fixed order (cells row-major, ascending pixel index inside a cell).  Common case (every cell
+// holds at most one pixel, e.g. near-unit local scale): straight-line code, 4 + 4 + 4 independent loads, then the rows.
+template <int J3>   // 3C <= 64 J3
 __global__ __launch_bounds__(kBlock) void adj_map_kernel(const AdjArgs a) {
   const int b = blockIdx.y, lane = threadIdx.x & 63, w = wave_id();
   const int N = a.lv.N, C = a.lv.C, H = a.lv.H, W = a.lv.W, HW = H * W, C3 = 3 * C;
-  const int J3 = (C3 + 63) >> 6;   // <= 12
-  const int* __restrict__ cnt = a.cnt + (size_t)b * HW;
-  const int* __restrict__ start = a.start + (size_t)b * HW;
+  const int2* __restrict__ cs = reinterpret_cast<const int2*>(a.start) + (size_t)b * HW;
   const int* __restrict__ list = a.list + (size_t)b * N;
+  const float* __restrict__ frac = a.frac + (size_t)b * N * 4;
+  const float* __restrict__ arow = a.arow + (size_t)b * N * C3;
+  bool cok[J3];
+#pragma unroll
+  for (int j = 0; j < J3; ++j) cok[j] = lane + 64 * j < C3;
   for (int t = blockIdx.x * kNumWaves + w; t < HW; t += gridDim.x * kNumWaves) {
     const int ty = t / W, tx = t - ty * W;
-    float acc[12];
-#pragma unroll
-    for (int j = 0; j < 12; ++j) acc[j] = 0.f;
-    bool any = false;
+    int L[4], s0[4];
 #pragma unroll
     for (int cell = 0; cell < 4; ++cell) {
       const int cy = ty - 1 + (cell >> 1), cx = tx - 1 + (cell & 1);
-      if (cy < 0 || cx < 0) continue;   // wave-uniform (cy <= H-1, cx <= W-1 by construction)
-      const int ci = cy * W + cx;
-      const int L = cnt[ci], s0 = start[ci];
-      int last = -1;
-      for (int it = 0; it < L; ++it) {
-        int mn = 0x7fffffff;
-        for (int e = lane; e < L; e += 64) {
-          const int v = list[s0 + e];
-          if (v > last) mn = min(mn, v);
-        }
-        const int n = wave_min_i(mn);
-        last = n;
-        const float* __restrict__ fr = a.frac + ((size_t)b * N + n) * 4;
-        const float ax = fr[1], ay = fr[2];
-        const float wt = ((cell & 1) ? 1.f - ax : ax) * ((cell >> 1) ? 1.f - ay : ay);   // cell == texel - (1,1) ... texel
-        if (wt != 0.f) {
-          any = true;
-          const float* __restrict__ ar = a.arow + ((size_t)b * N + n) * C3;
+      const bool okc = cy >= 0 && cx >= 0;
+      const int2 v = cs[okc ? cy * W + cx : 0];
+      L[cell] = okc ? v.y : 0;
+      s0[cell] = v.x;
+    }
+    const int Lmax = max(max(L[0], L[1]), max(L[2], L[3]));
+    if (Lmax == 0) continue;   // wave-uniform
+    float acc[J3];
 #pragma unroll
-          for (int j = 0; j < 12; ++j) {
-            const int c = lane + 64 * j;
-            if (j < J3 && c < C3) acc[j] = fmaf(wt, ar[c], acc[j]);
+    for (int j = 0; j < J3; ++j) acc[j] = 0.f;
+    bool any = false;
+    if (Lmax == 1) {
+      int n1[4];
+#pragma unroll
+      for (int cell = 0; cell < 4; ++cell) n1[cell] = list[L[cell] ? s0[cell] : 0];
+      float wt[4];
+#pragma unroll
+      for (int cell = 0; cell < 4; ++cell) {
+        const float fax = frac[(size_t)n1[cell] * 4 + 1], fay = frac[(size_t)n1[cell] * 4 + 2];
+        const float v = ((cell & 1) ? 1.f - fax : fax) * ((cell >> 1) ? 1.f - fay : fay);   // cell = texel - (1,1) ... texel
+        wt[cell] = L[cell] ? v : 0.f;
+        any = any || wt[cell] != 0.f;
+      }
+      float val[4][J3];
+#pragma unroll
+      for (int cell = 0; cell < 4; ++cell)
+#pragma unroll
+        for (int j = 0; j < J3; ++j) val[cell][j] = arow[(size_t)n1[cell] * C3 + (cok[j] ? lane + 64 * j : 0)];
+#pragma unroll
+      for (int cell = 0; cell < 4; ++cell)
+#pragma unroll
+        for (int j = 0; j < J3; ++j) acc[j] = fmaf(wt[cell], wt[cell] != 0.f ? val[cell][j] : 0.f, acc[j]);
+    } else {
+#pragma unroll 1
+      for (int cell = 0; cell < 4; ++cell) {
+        int last = -1;
+        for (int it = 0; it < L[cell]; ++it) {
+          int mn = 0x7fffffff;
+          for (int e = lane; e < L[cell]; e += 64) {
+            const int v = list[s0[cell] + e];
+            if (v > last) mn = min(mn, v);
+          }
+          const int n = wave_min_i(mn);
+          last = n;
+          const float ax = frac[(size_t)n * 4 + 1], ay = frac[(size_t)n * 4 + 2];
+          const float wt = ((cell & 1) ? 1.f - ax : ax) * ((cell >> 1) ? 1.f - ay : ay);
+          if (wt != 0.f) {
+            any = true;
+#pragma unroll
+            for (int j = 0; j < J3; ++j) acc[j] = fmaf(wt, arow[(size_t)n * C3 + (cok[j] ? lane + 64 * j : 0)], acc[j]);
           }
         }
       }
@@ -541,10 +594,8 @@ __global__ __launch_bounds__(kBlock) void adj_map_kernel(const AdjArgs a) {
     if (any) {
       float* __restrict__ o = a.dmap3 + ((size_t)b * HW + t) * C3;
 #pragma unroll
-      for (int j = 0; j < 12; ++j) {
-        const int c = lane + 64 * j;
-        if (j < J3 && c < C3) o[c] += acc[j];
-      }
+      for (int j = 0; j < J3; ++j)
+        if (cok[j]) o[lane + 64 * j] += acc[j];
     }
   }
 }
@@ -597,7 +648,7 @@ void adj_plan(const banet_level_t* lv, AdjPlan* pl) {
   pl->off_arow = take(B * N * 3 * C * 4);
   pl->off_frac = take(B * N * 4 * 4);
   pl->off_cnt = take(B * N * 4);
-  pl->off_start = take(B * N * 4);
+  pl->off_start = take(B * N * 8);
   pl->off_cursor = take(B * N * 4);
   pl->off_list = take(B * N * 4);
   pl->off_part = take(B * (size_t)pl->G * kNumWaves * (kAdjHdr + K) * 4);
@@ -671,10 +722,33 @@ int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T
     case 8: launch_adj_basis<8>(a, pl.Ga, s); break;
     default: return BANET_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(adj_pixel_kernel, dim3(pl.G, B), dim3(kBlock), 0, s, a);
+  {
+    const int CJ = (lv->C + 63) / 64, KJ = (K + 63) / 64;
+    const dim3 grid(pl.G, B), block(kBlock);
+#define BANET_ADJ_PIXEL(cj, kj) \
+  if (CJ == cj && KJ == kj) hipLaunchKernelGGL((adj_pixel_kernel<cj, kj>), grid, block, 0, s, a)
+    BANET_ADJ_PIXEL(1, 1);
+    BANET_ADJ_PIXEL(2, 1);
+    BANET_ADJ_PIXEL(3, 1);
+    BANET_ADJ_PIXEL(4, 1);
+    BANET_ADJ_PIXEL(1, 2);
+    BANET_ADJ_PIXEL(2, 2);
+    BANET_ADJ_PIXEL(3, 2);
+    BANET_ADJ_PIXEL(4, 2);
+#undef BANET_ADJ_PIXEL
+  }
   hipLaunchKernelGGL(adj_scan_kernel, dim3(B), dim3(kScanThreads), 0, s, a.cnt, a.start, a.cursor, HW);
   hipLaunchKernelGGL(adj_fill_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, a.frac, a.cursor, a.list, N, HW);
-  hipLaunchKernelGGL(adj_map_kernel, dim3(pl.Gm, B), dim3(kBlock), 0, s, a);
+  {
+    const int J3 = (3 * lv->C + 63) / 64;
+    const dim3 grid(pl.Gm, B), block(kBlock);
+    if (J3 <= 3)
+      hipLaunchKernelGGL((adj_map_kernel<3>), grid, block, 0, s, a);
+    else if (J3 <= 6)
+      hipLaunchKernelGGL((adj_map_kernel<6>), grid, block, 0, s, a);
+    else
+      hipLaunchKernelGGL((adj_map_kernel<12>), grid, block, 0, s, a);
+  }
   hipLaunchKernelGGL(adj_fold_kernel, dim3((12 + K + 127) / 128, B), dim3(128), 0, s, a.part, pl.G * kNumWaves, K, dpose);
   return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;
 }

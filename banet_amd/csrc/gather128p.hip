@@ -539,10 +539,21 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
 
 int launch_gather128p(const GatherArgs& a, int K, hipStream_t s) {
   dim3 grid(a.G, a.pairloop ? a.lv.B : a.lv.B * a.pairs), block(kBlock);
+  // reserved_ bit 13 (A/B experiment, experiments/README.md): 60 KB of unused dynamic LDS per workgroup -> ONE workgroup per CU
+  // (one gather wave per SIMD), the occupancy a wave-specialised gather + MFMA-accumulator kernel would leave the gather
+  size_t dyn = 0;
+  if (a.lv.reserved_ & 8192) {
+    dyn = 60 * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_gather128p_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+      attr_set = true;
+    }
+  }
   if (K == 0)
     hipLaunchKernelGGL((ba_gather128p_kernel<0>), grid, block, 0, s, a);
   else if ((K & 3) == 0 && K <= 128)
-    hipLaunchKernelGGL((ba_gather128p_kernel<1>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((ba_gather128p_kernel<1>), grid, block, dyn, s, a);
   else if ((K & 3) == 0 && K <= 256)
     hipLaunchKernelGGL((ba_gather128p_kernel<2>), grid, block, 0, s, a);
   else
