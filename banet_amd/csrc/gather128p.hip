@@ -79,13 +79,17 @@ __device__ __forceinline__ void tap_math_p(const float4& f1, const float4& a0, c
   q[4] += qg2.x + qg2.y;
 }
 
-template <int KV4>
+// US = steps (of 4 pixels) per unit: 2 = a 4x2 pixel block, box <= 36 texels, 9 + 2 loads per lane in flight (the product
+// kernel of round 1); 4 = a 4x4 block, box <= 52 texels, 13 + 4 loads: half as many load -> LDS -> tap latency events per
+// tile, 3.06 instead of 4.4 box texels per pixel through the L1.
+template <int KV4, int US>
 __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kernel(const GatherArgs a) {
+  constexpr int PT = US == 2 ? kPatchTexels : 52, NL = (PT + 3) / 4, GL = 4 * US;   // patch texels, box loads per lane, lanes per unit
   __shared__ __attribute__((aligned(16))) float sPar[kNumWaves][64][kParStrideP];
   __shared__ float sQ[kNumWaves][64][5];
   __shared__ float sAbs[kNumWaves][kC128p];
-  __shared__ __attribute__((aligned(16))) float sPatch[kNumWaves][kPatchTexels * 64];   // one channel half of a step pair's box
-  __shared__ int sGrp[kNumWaves][8][4];                                                  // per step pair: base offset, pw, staged
+  __shared__ __attribute__((aligned(16))) float sPatch[kNumWaves][PT * 64];   // one channel half of a unit's box
+  __shared__ int sGrp[kNumWaves][8][4];                                        // per unit: base offset, pw, staged texels, ph
   const banet_level_t& lv = a.lv;
   // pairloop (levels with enough tiles per window): a workgroup serves one window and a multi-frame window's target frames
   // ("pairs") are looped over INSIDE a tile, so the depth D0 + b.W is computed once; otherwise grid y = (window, pair)
@@ -301,10 +305,15 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
       pb.x = mk * gw10;
       pb.y = mk * gw11;
       pb.z = mk;
-      // bounding box of the 8-pixel group (lanes 8k .. 8k+7 = step pair k) over its pixels that need taps
+      // bounding box of the unit's pixel group (lanes GL k .. GL k + GL - 1 = unit k) over its pixels that need taps
       {
         auto red8 = [](int v, bool mx) {
-          int o = __builtin_amdgcn_update_dpp(v, v, kDppHalfMirror, 0xF, 0xF, false);
+          int o;
+          if (US == 4) {
+            o = __builtin_amdgcn_update_dpp(v, v, kDppRor8, 0xF, 0xF, false);
+            v = mx ? max(v, o) : min(v, o);
+          }
+          o = __builtin_amdgcn_update_dpp(v, v, kDppHalfMirror, 0xF, 0xF, false);
           v = mx ? max(v, o) : min(v, o);
           o = __builtin_amdgcn_update_dpp(v, v, kDppXor2, 0xF, 0xF, false);
           v = mx ? max(v, o) : min(v, o);
@@ -315,13 +324,13 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
         const int bx0 = red8(fast ? x0 : big, false), bx1 = red8(fast ? x0 : -big, true);
         const int by0 = red8(fast ? y0 : big, false), by1 = red8(fast ? y0 : -big, true);
         const int x_lo = bx0 - 1, y_lo = by0 - 1, pw = bx1 - bx0 + 4, ph = by1 - by0 + 4;
-        const bool st = bx1 >= bx0 && pw * ph <= kPatchTexels && !(lv.reserved_ & 128);
+        const bool st = bx1 >= bx0 && pw * ph <= PT && !(lv.reserved_ & 128);
         pb.w = __int_as_float(((fast ? y0 - y_lo : 1) * pw + (fast ? x0 - x_lo : 1)) * 64);
-        if ((lane & 7) == 0) {
-          sGrp[w][lane >> 3][0] = st ? (y_lo * W + x_lo) * C : 0;
-          sGrp[w][lane >> 3][1] = st ? pw : 0;
-          sGrp[w][lane >> 3][2] = st ? pw * ph : 0;
-          sGrp[w][lane >> 3][3] = st ? ph : 0;
+        if ((lane & (GL - 1)) == 0) {
+          sGrp[w][lane / GL][0] = st ? (y_lo * W + x_lo) * C : 0;
+          sGrp[w][lane / GL][1] = st ? pw : 0;
+          sGrp[w][lane / GL][2] = st ? pw * ph : 0;
+          sGrp[w][lane / GL][3] = st ? ph : 0;
         }
       }
       *reinterpret_cast<float4*>(&sPar[w][lane][0]) = pa;
@@ -334,13 +343,13 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
     // wave's LDS patch and before its taps are computed, so their memory latency hides behind ~330 VALU
     // instructions -- the direct kernel would need 104 registers to prefetch one step.
     const int rowC = W * C;
-    f32x4 pst[9], pf1[2];
+    f32x4 pst[NL], pf1[US];
     bool pre = false;
     auto issue = [&](int sp_, int h_) __attribute__((always_inline)) {
       const int gb = rfl(sGrp[w][sp_][0]), pw_ = rfl(sGrp[w][sp_][1]), ph_ = rfl(sGrp[w][sp_][3]);
       int row = 0, col = lane >> 4;                       // texel (lane >> 4) + 4 i of the box, pw_ >= 4
 #pragma unroll
-      for (int i = 0; i < 9; ++i) {
+      for (int i = 0; i < NL; ++i) {
         unsigned off = (unsigned)gb + (unsigned)((min(row, ph_ - 1) * W + col) * C) + 4u * (unsigned)sub + 64u * (unsigned)h_;
         if (abl & 1) off = 4u * (unsigned)sub + 64u * (unsigned)h_ + (unsigned)((lane >> 4) * C);   // every box = texels 0..3
         pst[i] = *reinterpret_cast<const f32x4*>(tgt_b + (size_t)off);
@@ -351,34 +360,30 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
         }
       }
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        unsigned osrc = (unsigned)__float_as_int(sPar[w][4 * (2 * sp_ + t) + grp][0]);
+      for (int t = 0; t < US; ++t) {
+        unsigned osrc = (unsigned)__float_as_int(sPar[w][4 * (US * sp_ + t) + grp][0]);
         if (abl & 2) osrc = (unsigned)(grp * C);                                                        // every source row = pixels 0..3
         pf1[t] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src_b + (size_t)(osrc + 64u * (unsigned)h_ + 4u * sub)));
       }
     };
-    const int sp_end = s_hi >> 1;
-    for (int sp = s_lo >> 1; sp < sp_end; ++sp) {
+    const int sp_end = s_hi / US;
+    for (int sp = s_lo / US; sp < sp_end; ++sp) {
       const int pw = rfl(sGrp[w][sp][1]), ntex = rfl(sGrp[w][sp][2]);
-      float qa2[2][5];
+      float qa2[US][5];
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < US; ++t)
 #pragma unroll
         for (int i = 0; i < 5; ++i) qa2[t][i] = 0.f;
-      float4 pa[2], pb[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int j = 4 * (2 * sp + t) + grp;
-        pa[t] = *reinterpret_cast<const float4*>(&sPar[w][j][0]);
-        pb[t] = *reinterpret_cast<const float4*>(&sPar[w][j][4]);
-      }
-      if (ntex > 0) {   // wave-uniform: the pair's box fits the patch
+      if (ntex > 0) {   // wave-uniform: the unit's box fits the patch
 #pragma unroll 1
         for (int h = 0; h < 2; ++h) {
           if (!pre) issue(sp, h);
 #pragma unroll
-          for (int i = 0; i < 9; ++i) *reinterpret_cast<f32x4*>(&sPatch[w][(lane + 64 * i) * 4]) = pst[i];
-          const f32x4 f1v[2] = {pf1[0], pf1[1]};
+          for (int i = 0; i < NL; ++i)
+            if (US == 2 || (lane + 64 * i) < PT * 16) *reinterpret_cast<f32x4*>(&sPatch[w][(lane + 64 * i) * 4]) = pst[i];
+          f32x4 f1v[US];
+#pragma unroll
+          for (int t = 0; t < US; ++t) f1v[t] = pf1[t];
           {   // prefetch the next staged unit
             const int nsp = h ? sp + 1 : sp, nh = h ^ 1;
             pre = nsp < sp_end && rfl(sGrp[w][nsp][2]) > 0;
@@ -387,8 +392,11 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
           const int rs = pw * 64;
           if (!(abl & 8))
 #pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            const float* l = &sPatch[w][0] + __float_as_int(pb[t].w) + 4 * sub;
+          for (int t = 0; t < US; ++t) {
+            const int j = 4 * (US * sp + t) + grp;
+            const float4 pa = *reinterpret_cast<const float4*>(&sPar[w][j][0]);
+            const float4 pb = *reinterpret_cast<const float4*>(&sPar[w][j][4]);
+            const float* l = &sPatch[w][0] + __float_as_int(pb.w) + 4 * sub;
             const float4 f1 = make_float4(f1v[t][0], f1v[t][1], f1v[t][2], f1v[t][3]);
             const float4 a0 = *reinterpret_cast<const float4*>(l - 64), a1 = *reinterpret_cast<const float4*>(l),
                          a2 = *reinterpret_cast<const float4*>(l + 64), a3 = *reinterpret_cast<const float4*>(l + 128);
@@ -396,14 +404,16 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
                          b2 = *reinterpret_cast<const float4*>(l + rs + 64), b3 = *reinterpret_cast<const float4*>(l + rs + 128);
             const float4 m1 = *reinterpret_cast<const float4*>(l - rs), m2 = *reinterpret_cast<const float4*>(l - rs + 64);
             const float4 p1 = *reinterpret_cast<const float4*>(l + 2 * rs), p2 = *reinterpret_cast<const float4*>(l + 2 * rs + 64);
-            tap_math_p(f1, a0, a1, a2, a3, b0, b1, b2, b3, m1, m2, p1, p2, pa[t].z, pa[t].w, pb[t].x, pb[t].y, pb[t].z, qa2[t],
-                       &absd8[4 * h]);
+            tap_math_p(f1, a0, a1, a2, a3, b0, b1, b2, b3, m1, m2, p1, p2, pa.z, pa.w, pb.x, pb.y, pb.z, qa2[t], &absd8[4 * h]);
           }
         }
       } else {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const unsigned osrc = (unsigned)__float_as_int(pa[t].x), oa = (unsigned)__float_as_int(pa[t].y);
+        for (int t = 0; t < US; ++t) {
+          const int j = 4 * (US * sp + t) + grp;
+          const float4 pa = *reinterpret_cast<const float4*>(&sPar[w][j][0]);
+          const float4 pb = *reinterpret_cast<const float4*>(&sPar[w][j][4]);
+          const unsigned osrc = (unsigned)__float_as_int(pa.x), oa = (unsigned)__float_as_int(pa.y);
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             const unsigned co = 64u * h + 4u * sub;
@@ -419,14 +429,13 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
                          b2 = *reinterpret_cast<const float4*>(rb + C), b3 = *reinterpret_cast<const float4*>(rb + 2 * C);
             const float4 m1 = *reinterpret_cast<const float4*>(rm), m2 = *reinterpret_cast<const float4*>(rm + C);
             const float4 p1 = *reinterpret_cast<const float4*>(rp), p2 = *reinterpret_cast<const float4*>(rp + C);
-            tap_math_p(f1, a0, a1, a2, a3, b0, b1, b2, b3, m1, m2, p1, p2, pa[t].z, pa[t].w, pb[t].x, pb[t].y, pb[t].z, qa2[t],
-                       &absd8[4 * h]);
+            tap_math_p(f1, a0, a1, a2, a3, b0, b1, b2, b3, m1, m2, p1, p2, pa.z, pa.w, pb.x, pb.y, pb.z, qa2[t], &absd8[4 * h]);
           }
         }
       }
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int j = 4 * (2 * sp + t) + grp;
+      for (int t = 0; t < US; ++t) {
+        const int j = 4 * (US * sp + t) + grp;
         float qq[5];
 #pragma unroll
         for (int i = 0; i < 5; ++i) qq[i] = row16_sum(qa2[t][i]);
@@ -546,16 +555,19 @@ int launch_gather128p(const GatherArgs& a, int K, hipStream_t s) {
     dyn = 60 * 1024;
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_gather128p_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_gather128p_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
       attr_set = true;
     }
   }
+  const bool u4 = (a.lv.reserved_ & 16384) != 0;   // bit 14: 4-step units (A/B)
   if (K == 0)
-    hipLaunchKernelGGL((ba_gather128p_kernel<0>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((ba_gather128p_kernel<0, 2>), grid, block, 0, s, a);
+  else if ((K & 3) == 0 && K <= 128 && u4)
+    hipLaunchKernelGGL((ba_gather128p_kernel<1, 4>), grid, block, 0, s, a);
   else if ((K & 3) == 0 && K <= 128)
-    hipLaunchKernelGGL((ba_gather128p_kernel<1>), grid, block, dyn, s, a);
+    hipLaunchKernelGGL((ba_gather128p_kernel<1, 2>), grid, block, dyn, s, a);
   else if ((K & 3) == 0 && K <= 256)
-    hipLaunchKernelGGL((ba_gather128p_kernel<2>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((ba_gather128p_kernel<2, 2>), grid, block, 0, s, a);
   else
     return BANET_ERR_UNSUPPORTED;
   return BANET_OK;
