@@ -27,7 +27,7 @@ def _to_param(t, dev):
     return t.to(dev) if torch.is_tensor(t) else torch.as_tensor(t, dtype=torch.float32, device=dev)
 
 
-def solve_update_graph(AtA, Atb, absres, N, R, T, Wc, layers, l2_base):
+def solve_update_graph(AtA, Atb, absres, N, R, T, Wc, layers, l2_base, solve=torch.linalg.solve):
     """bundlenet.py:241-276 after the EquationConstruction op, as differentiable torch statements on the small tensors:
     avg -> lambda MLP -> damping (last coefficient undamped) -> matrix_solve -> SE(3) / W update."""
     nb = AtA.shape[0]
@@ -41,11 +41,99 @@ def solve_update_graph(AtA, Atb, absres, N, R, T, Wc, layers, l2_base):
     diag = torch.diagonal(AtA, dim1=1, dim2=2)
     damp = torch.cat([diag[:, :-1] + 1e-5, torch.zeros(nb, 1, device=diag.device, dtype=diag.dtype)], dim=-1)   # :266
     A = AtA + torch.diag_embed(damp * lam.squeeze(-1))
-    sol = torch.linalg.solve(A, Atb.unsqueeze(-1))                                   # :267
+    sol = solve(A, Atb.unsqueeze(-1))                                                # :267
     wx, wy, wz = sol[:, 0], sol[:, 1], sol[:, 2]
     dr = AngleaAxisRotation(wx, wy, wz)
     dv = VMatrix(wx.reshape(-1), wy.reshape(-1), wz.reshape(-1))
     return torch.matmul(dr, R), torch.matmul(dv, sol[:, 3:6]) + torch.matmul(dr, T), Wc + sol[:, 6:]
+
+
+class _SolveNoCheck(torch.autograd.Function):
+    """x = A^-1 b without the host-side `info` check of torch.linalg.solve (a device->host sync per call, and illegal inside
+    a captured graph); backward = the implicit-function gradient: lam = A^-T g, dA = -lam x^T, db = lam."""
+
+    @staticmethod
+    def forward(ctx, A, b):
+        x = torch.linalg.solve_ex(A, b, check_errors=False).result
+        ctx.save_for_backward(A, x)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        A, x = ctx.saved_tensors
+        lam = torch.linalg.solve_ex(A.transpose(-1, -2), g, check_errors=False).result
+        return -torch.matmul(lam, x.transpose(-1, -2)), lam
+
+
+def _small_grads(AtA, Atb, absres, R, T, Wc, gR, gT, gW, flat, N, l2_base):
+    """dL/d(AtA, Atb, sum|d|, R, T, Wc, lambda weights) of one iteration's small part, given dL/d(R', T', W')."""
+    with torch.enable_grad():
+        leaves = [t.detach().requires_grad_(True) for t in (AtA, Atb, absres, R, T, Wc)]
+        lw = [t.detach().requires_grad_(True) for t in flat]
+        R2, T2, W2 = solve_update_graph(leaves[0], leaves[1], leaves[2], N, leaves[3], leaves[4], leaves[5],
+                                        [(lw[2 * i], lw[2 * i + 1]) for i in range(5)], l2_base, solve=_SolveNoCheck.apply)
+        grads = torch.autograd.grad([R2, T2, W2], leaves + lw, [gR, gT, gW], allow_unused=True)
+    return [g if g is not None else torch.zeros_like(t) for g, t in zip(grads, leaves + lw)]
+
+
+class _SmallStepGraph:
+    """The small part of a backward iteration as ONE captured HIP graph (torch.cuda.CUDAGraph): ~150 kernels on [B,P,P] /
+    [B,C] tensors per iteration are launch-bound when issued one by one from Python.  Static input / output buffers; falls
+    back to eager execution if capture is not possible (BANET_TRAIN_GRAPH=0 disables it)."""
+
+    def __init__(self, shapes, dev, N, l2_base):
+        import os
+        self.N, self.l2 = N, l2_base
+        self.inp = [torch.zeros(s, dtype=torch.float32, device=dev) for s in shapes]
+        self.graph, self.out, self.error = None, None, None
+        if os.environ.get("BANET_TRAIN_GRAPH", "1") == "0":
+            return
+        for t in self.inp[3:4]:
+            t.copy_(torch.eye(3, device=dev).expand_as(t))          # a valid rotation / SPD system for the warm-up
+        self.inp[0].copy_(torch.eye(shapes[0][-1], device=dev).expand_as(self.inp[0]))
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self._run()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self._run()
+            self.graph, self.out = g, out
+        except Exception as e:                                       # capture not possible here: eager execution
+            self.graph, self.out, self.error = None, None, repr(e)
+            torch.cuda.synchronize(dev)
+
+    def _run(self):
+        i = self.inp
+        return _small_grads(i[0], i[1], i[2], i[3], i[4], i[5], i[6], i[7], i[8], i[9:], self.N, self.l2)
+
+    def __call__(self, tensors):
+        if self.graph is None:
+            return _small_grads(*tensors[:9], tensors[9:], self.N, self.l2)
+        for dst, src in zip(self.inp, tensors):
+            dst.copy_(src.reshape(dst.shape))
+        self.graph.replay()
+        return [o.clone() for o in self.out]
+
+
+_small_cache = {}
+
+
+def small_step_modes():
+    """{shape key: "graph" | "eager (<reason>)"} of the small backward steps built so far (diagnostics / benchmarks)."""
+    return {str(k[0][0]): ("graph" if v.graph is not None else "eager (%s)" % (v.error or "disabled")) for k, v in _small_cache.items()}
+
+
+def _small_step(tensors, N, l2_base):
+    dev = tensors[0].device
+    key = (tuple(tuple(t.shape) for t in tensors), str(dev), int(N), float(l2_base))
+    st = _small_cache.get(key)
+    if st is None:
+        st = _small_cache[key] = _SmallStepGraph([tuple(t.shape) for t in tensors], dev, N, l2_base)
+    return st(tensors)
 
 
 def dense_adjoint(problem, R, T, Wc, gAtA, gAtb, gabs, dsrc, dmap3, ddepth, dbasis, ws=None):
@@ -107,16 +195,10 @@ class _LevelSolve(torch.autograd.Function):
         gW = torch.zeros(B, K, 1, device=dev) if gW is None else gW.reshape(B, K, 1)
         ws = None
         for Ri, Ti, Wi, AtA, Atb, absres in reversed(ctx.saved):
-            with torch.enable_grad():
-                leaves = [t.detach().requires_grad_(True) for t in (AtA, Atb, absres, Ri, Ti, Wi)]
-                lw = [t.detach().requires_grad_(True) for t in flat]
-                R2, T2, W2 = solve_update_graph(leaves[0], leaves[1], leaves[2], N, leaves[3], leaves[4], leaves[5],
-                                                [(lw[2 * i], lw[2 * i + 1]) for i in range(5)], ba.l2_base)
-                grads = torch.autograd.grad([R2, T2, W2], leaves + lw, [gR, gT, gW], allow_unused=True)
+            grads = _small_step([AtA, Atb, absres, Ri, Ti, Wi, gR, gT, gW] + [t.detach() for t in flat], N, ba.l2_base)
             gAtA, gAtb, gabs_avg, dR, dT, dW = grads[:6]
             for acc, g in zip(glayers, grads[6:]):
-                if g is not None:
-                    acc += g
+                acc += g
             dpose, ws = dense_adjoint(prob, Ri, Ti, Wi, gAtA, gAtb, gabs_avg, dsrc, dmap3, ddepth, dbasis, ws)
             gR = dR + dpose[:, 0:9].reshape(B, 3, 3)
             gT = dT + dpose[:, 9:12].reshape(B, 3, 1)

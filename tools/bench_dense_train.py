@@ -56,3 +56,5 @@ print("dense BA training step, %d windows %dx%d, 5 levels x %d iterations, C = K
 print("  forward only (lm_level)                 %8.2f ms   (%.1f LM it/s)" % (f_ms, nit / f_ms * 1e3))
 print("  forward + backward (solve_differentiable) %6.2f ms   (%.1f LM it/s, %.2fx the forward), peak extra memory %.2f GB"
       % (t_ms, nit / t_ms * 1e3, t_ms / f_ms, mem))
+from banet_amd import dense_train
+print("  small backward step (lambda MLP / damping / solve / update adjoint on [B,P,P]):", dense_train.small_step_modes())
