@@ -3,7 +3,7 @@
 // the gradients with respect to everything the pass read -- source map, target map, depth, depth basis, pose (R, T)
 // and depth coefficients Wc.  It is what TF autodiff + the registered EquationConstructionGrad (bundlenet.py:79-82,
 // utils.cu:465-694) compute for the statements bundlenet.py:206-263, restated per pixel without J, G or d in memory
-// (derivation and float64 statement: oracle/dense_adjoint.py, validated there against finite differences).
+// (derivation and float64 statement: dense_adjoint.py of the test oracle, validated there against finite differences).
 //
 // With S = (gAtA + gAtA^T)/2, b = the pixel's basis row, J = [Jc | jd b^T], M = G^T G, g = G^T d:
 //   q = S_cd b, z = S_dd b, zeta = b.z, e = gAtb_d.b, t = Jc q + jd zeta

@@ -59,15 +59,23 @@ class DenseBA:
         T = T.reshape(B, -1, 3, 1) if self.pairs > 1 else T
         return ops.LmState(R, T, Wc if K > 0 else None, P=6 * self.pairs + K, pairs=self.pairs)
 
-    def solve(self, iters_per_level, state=None, early_termination=False, params=None, snapshots=None):
+    def solve(self, iters_per_level, state=None, early_termination=False, params=None, snapshots=None, level_events=None):
         """Enqueue the full schedule; returns the state (R,T,Wc updated in place) and the list
         of per-level iteration-count tensors.  params: ops.lm_params(...) (legacy/ba.py:5-9) or None for the
         reference's defaults.  snapshots: a list that receives, per level, a dict of clones of (R, T, W, delta, lam)
-        after that level (device tensors, no host sync)."""
+        after that level (device tensors, no host sync).  level_events: a list that receives one (start, end) pair of
+        torch.cuda.Event per level, recorded on the current stream (per-level times without a host sync)."""
         st = state if state is not None else self.new_state()
         counts = []
         for prob, mlp, its in zip(self.problems, self.mlps, iters_per_level):
+            if level_events is not None:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
             ops.lm_level(prob, mlp, self.l2_base, its, early_termination, st, ws=self.ws, params=params)
+            if level_events is not None:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                level_events.append((e0, e1))
             counts.append(st.iters.clone())
             if snapshots is not None:
                 snapshots.append(dict(R=st.R.clone(), T=st.T.clone(), W=None if st.Wc is None else st.Wc.clone(),

@@ -75,10 +75,10 @@ class Problem:
         # undamped last coefficient diverges (bundlenet.py:266)
         self.T0 = (self.gt["T"] * 0.7).reshape(B * self.pairs, 3, 1).to(dev)
 
-    def step(self, iters, total_windows):
+    def step(self, iters, total_windows, level_events=None):
         from banet_amd import parallel
         st = self.ba.new_state(T=self.T0)
-        st, counts = self.ba.solve(iters, st)
+        st, counts = self.ba.solve(iters, st, level_events=level_events)
         rec = parallel.pack_results(st.R, st.T, st.Wc, counts)
         return parallel.gather_results(rec, total_windows), st
 
@@ -116,6 +116,10 @@ def roofline_record(prob, prof, elapsed_s, traffic=None):
                                                 "syrk_avg_us": round(1e3 * sms / max(scnt, 1), 2),
                                                 "gather_GBps": round(by / max(ms, 1e-9) / 1e6, 1)}
     achieved = alg_bytes / max(kern_ms, 1e-9) / 1e6            # GB/s
+    lm = getattr(prob, "level_ms", None)
+    if lm and len(lm) == len(ba.problems):          # wall time of each level's whole LM loop in the last timed step
+        for rec, ms in zip(per_level.values(), lm):
+            rec["level_ms_last_step"] = round(ms, 3)
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "kernel": "ba_gather128p_kernel<1> (large levels) + ba_gather128_kernel<1> (small levels)",
@@ -138,11 +142,13 @@ def timed_run(prob, iters, steps, warmup, total_windows, fence, world=1, dev=Non
     fence()
     ops.profile_begin(2 * steps * sum(iters) + 8)
     t0 = time.perf_counter()
-    for _ in range(steps):
-        full, st = prob.step(iters, total_windows)
+    level_events = []
+    for i in range(steps):
+        full, st = prob.step(iters, total_windows, level_events if i == steps - 1 else None)
     fence()
     elapsed = time.perf_counter() - t0
     prof = ops.profile_end()
+    prob.level_ms = [e0.elapsed_time(e1) for e0, e1 in level_events]      # the last timed step, level by level
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -164,6 +170,7 @@ def sub_record(frames, B, Hh, Ww, Kk, iters_per_level, steps, warmup, seed, dev,
            "value": round(B * sum(iters) * steps / elapsed, 2), "unit": "LM iterations/s", "steps": steps, "warmup": warmup,
            "ms_per_step": round(1e3 * elapsed / steps, 3), "ms_per_solve": round(1e3 * elapsed / steps / B, 3),
            "end_to_end_hbm_frac": round(step_bytes / (elapsed / steps) / 1e9 / HBM_PEAK_GBS, 4),
+           "finest_level_only_value": round(B * iters_per_level / (prob.level_ms[-1] * 1e-3), 2) if getattr(prob, "level_ms", None) else None,
            "roofline": {k: rl[k] for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "kernel_time_share",
                                            "syrk_kernel", "per_level")},
            "check": chk}
@@ -333,6 +340,7 @@ def main():
                                       "heavily, so 50 iterations move the estimate only slightly; correctness is the `parity` "
                                       "record, not this"),
             "end_to_end_hbm_frac": round(step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+            "finest_level_only_value": round(B * args.iters / (prob.level_ms[-1] * 1e-3), 2) if getattr(prob, "level_ms", None) else None,
             "roofline": rl,
         }
         if world == 1:

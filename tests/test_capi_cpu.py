@@ -40,7 +40,7 @@ def test_every_declared_symbol_is_exported(capi):
 
 def test_version_and_error_strings(capi):
     L = capi.lib()
-    assert L.banet_version() == 130
+    assert L.banet_version() == 140
     assert L.banet_error_string(0) == b"ok"
     assert b"workspace" in L.banet_error_string(-2)
 
@@ -201,4 +201,4 @@ def test_plain_c_program_links_against_the_library(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
                            "-L", libdir, "-lbanet_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.check_output([str(exe)]).decode()
-    assert out.startswith("c-abi ok 130")
+    assert out.startswith("c-abi ok 140")
