@@ -620,6 +620,96 @@ __global__ void target_map_adjoint_kernel(const float* __restrict__ dmap3, float
   dimg[e] += v;
 }
 
+// ---- the same deterministic gather for the reference-layout adjoint (sparse points, [f|gx|gy] target map) ----------
+// ba_sample_stats_grad_kernel (sstats.hip) scatters its 3C-wide contributions with float atomics; this variant writes them as
+// per-point rows + (cell, fractions) records and lets adj_scan / adj_fill / adj_map_kernel gather them per texel in a fixed
+// order: bit-reproducible dconv2.  One wave per point at a time, lane = channel (+64 j).
+__global__ __launch_bounds__(kBlock) void sstats_rows_kernel(const float* __restrict__ conv1, const float* __restrict__ conv2,
+                                                             const float* __restrict__ px, const float* __restrict__ py, int N,
+                                                             int C, int H, int W, const float* __restrict__ dstats,
+                                                             const float* __restrict__ dabs, float* __restrict__ dconv1,
+                                                             float* __restrict__ dpos, float* __restrict__ arow,
+                                                             float* __restrict__ frac, int* __restrict__ cnt) {
+  constexpr int kPix = 16;
+  const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x & 63, w = wave_id();
+  const int CJ = (C + 63) >> 6, C3 = 3 * C;
+  float da[kAdjMaxCJ];
+  for (int j = 0; j < kAdjMaxCJ; ++j) {
+    const int c = lane + 64 * j;
+    da[j] = c < C ? dabs[(size_t)b * C + c] : 0.f;
+  }
+  for (int i = 0; i < kPix; ++i) {
+    const int n = g * kPix * kNumWaves + w * kPix + i;
+    if (n >= N) break;                                   // wave-uniform
+    const size_t q = (size_t)b * N + n;
+    const float pxv = px[q], pyv = py[q];
+    const bool m = (pxv >= 0.f) && (pxv <= (float)(W - 1)) && (pyv >= 0.f) && (pyv <= (float)(H - 1));   // bundlenet.py:231-233
+    float dpx = 0.f, dpy = 0.f;
+    if (!m) {
+      for (int j = 0; j < CJ; ++j) {
+        const int c = lane + 64 * j;
+        if (c < C) dconv1[q * C + c] = 0.f;
+      }
+      if (lane == 0) frac[q * 4] = __int_as_float(-1);
+    } else {
+      const float xf = floorf(pxv), yf = floorf(pyv);
+      const int x0 = (int)xf, y0 = (int)yf;
+      const float ax = pxv - xf, ay = pyv - yf;
+      const bool xi = x0 + 1 <= W - 1, yi = y0 + 1 <= H - 1;
+      const int xc = xi ? x0 + 1 : x0, yc = yi ? y0 + 1 : y0;
+      const float* __restrict__ base = conv2 + (size_t)b * H * W * C3;
+      const float* __restrict__ r0 = base + (size_t)(y0 * W + x0) * C3;
+      const float* __restrict__ r1 = base + (size_t)(y0 * W + xc) * C3;
+      const float* __restrict__ r2 = base + (size_t)(yc * W + x0) * C3;
+      const float* __restrict__ r3 = base + (size_t)(yc * W + xc) * C3;
+      const float w0 = (1.f - ax) * (1.f - ay), w1 = xi ? ax * (1.f - ay) : 0.f, w2 = yi ? (1.f - ax) * ay : 0.f,
+                  w3 = (xi && yi) ? ax * ay : 0.f;
+      const float4 s0 = *reinterpret_cast<const float4*>(dstats + q * 8);
+      const float dm11 = s0.x, dm12 = s0.y, dm22 = s0.z, dg1 = s0.w, dg2 = dstats[q * 8 + 4];
+      for (int j = 0; j < CJ; ++j) {
+        const int c = lane + 64 * j;
+        if (c < C) {
+          float v[4][3];
+#pragma unroll
+          for (int e = 0; e < 3; ++e) {
+            v[0][e] = r0[e * C + c];
+            v[1][e] = xi ? r1[e * C + c] : 0.f;
+            v[2][e] = yi ? r2[e * C + c] : 0.f;
+            v[3][e] = (xi && yi) ? r3[e * C + c] : 0.f;
+          }
+          float s[3];
+#pragma unroll
+          for (int e = 0; e < 3; ++e) s[e] = w0 * v[0][e] + w1 * v[1][e] + w2 * v[2][e] + w3 * v[3][e];
+          const float gx = s[1], gy = s[2], d = conv1[q * C + c] - s[0];
+          const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+          const float dd = gx * dg1 + gy * dg2 + sgn * da[j];
+          float dv[3];
+          dv[0] = -dd;                                              // d = conv1 - f2
+          dv[1] = 2.f * gx * dm11 + gy * dm12 + d * dg1;
+          dv[2] = 2.f * gy * dm22 + gx * dm12 + d * dg2;
+          dconv1[q * C + c] = dd;
+#pragma unroll
+          for (int e = 0; e < 3; ++e) {
+            arow[q * C3 + e * C + c] = dv[e];
+            dpx = fmaf(dv[e], (1.f - ay) * (v[1][e] - v[0][e]) + ay * (v[3][e] - v[2][e]), dpx);
+            dpy = fmaf(dv[e], (1.f - ax) * (v[2][e] - v[0][e]) + ax * (v[3][e] - v[1][e]), dpy);
+          }
+        }
+      }
+      dpx = wave_sum(dpx);
+      dpy = wave_sum(dpy);
+      if (lane == 0) {
+        const int key = y0 * W + x0;
+        frac[q * 4] = __int_as_float(key);
+        frac[q * 4 + 1] = ax;
+        frac[q * 4 + 2] = ay;
+        atomicAdd(&cnt[(size_t)b * H * W + key], 1);
+      }
+    }
+    if (lane == 0) *reinterpret_cast<float2*>(dpos + q * 2) = make_float2(dpx, dpy);
+  }
+}
+
 struct AdjPlan {
   int G, Ga, Gm;
   size_t off_S, off_z2, off_arec, off_arow, off_frac, off_cnt, off_start, off_cursor, off_list, off_part, bytes;
@@ -750,6 +840,76 @@ int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T
       hipLaunchKernelGGL((adj_map_kernel<12>), grid, block, 0, s, a);
   }
   hipLaunchKernelGGL(adj_fold_kernel, dim3((12 + K + 127) / 128, B), dim3(128), 0, s, a.part, pl.G * kNumWaves, K, dpose);
+  return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;
+}
+
+namespace {
+struct DetPlan {
+  size_t off_arow, off_frac, off_cnt, off_start, off_cursor, off_list, bytes;
+};
+void det_plan(int B, int N, int C, int H, int W, DetPlan* pl) {
+  const size_t HW = (size_t)H * W;
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    const size_t at = o;
+    o = align_up(o + bytes, 256);
+    return at;
+  };
+  pl->off_arow = take((size_t)B * N * 3 * C * 4);
+  pl->off_frac = take((size_t)B * N * 4 * 4);
+  pl->off_cnt = take((size_t)B * HW * 4);
+  pl->off_start = take((size_t)B * HW * 8);
+  pl->off_cursor = take((size_t)B * HW * 4);
+  pl->off_list = take((size_t)B * N * 4);
+  pl->bytes = o;
+}
+}  // namespace
+
+size_t sample_stats_grad_det_workspace_bytes(int B, int N, int C, int H, int W) {
+  if (B <= 0 || N <= 0 || C < 1 || C > 64 * kAdjMaxCJ || H <= 0 || W <= 0) return 0;
+  DetPlan pl;
+  det_plan(B, N, C, H, W, &pl);
+  return pl.bytes;
+}
+
+int launch_sample_stats_grad_det(const float* conv1, const float* conv2, const float* px, const float* py, int B, int N, int C,
+                                 int H, int W, const float* dstats, const float* dabs, float* dconv1, float* dconv2, float* dpos,
+                                 void* ws, hipStream_t s) {
+  if (C < 1 || C > 64 * kAdjMaxCJ) return BANET_ERR_UNSUPPORTED;
+  DetPlan pl;
+  det_plan(B, N, C, H, W, &pl);
+  char* base = static_cast<char*>(ws);
+  const int HW = H * W;
+  AdjArgs a = {};
+  a.lv.B = B;
+  a.lv.N = N;
+  a.lv.C = C;
+  a.lv.H = H;
+  a.lv.W = W;
+  a.arow = reinterpret_cast<float*>(base + pl.off_arow);
+  a.frac = reinterpret_cast<float*>(base + pl.off_frac);
+  a.cnt = reinterpret_cast<int*>(base + pl.off_cnt);
+  a.start = reinterpret_cast<int*>(base + pl.off_start);
+  a.cursor = reinterpret_cast<int*>(base + pl.off_cursor);
+  a.list = reinterpret_cast<int*>(base + pl.off_list);
+  a.dmap3 = dconv2;
+  if (hipMemsetAsync(a.cnt, 0, (size_t)B * HW * sizeof(int), s) != hipSuccess) return BANET_ERR_LAUNCH;
+  const int G = (N + 16 * kNumWaves - 1) / (16 * kNumWaves);
+  hipLaunchKernelGGL(sstats_rows_kernel, dim3(G, B), dim3(kBlock), 0, s, conv1, conv2, px, py, N, C, H, W, dstats, dabs, dconv1,
+                     dpos, a.arow, a.frac, a.cnt);
+  hipLaunchKernelGGL(adj_scan_kernel, dim3(B), dim3(kScanThreads), 0, s, a.cnt, a.start, a.cursor, HW);
+  hipLaunchKernelGGL(adj_fill_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, a.frac, a.cursor, a.list, N, HW);
+  {
+    const int J3 = (3 * C + 63) / 64;
+    const int Gm = (int)std::max<size_t>(1, std::min<size_t>(((size_t)HW + 3) / 4, (size_t)((4096 + B - 1) / B)));
+    const dim3 grid(Gm, B), block(kBlock);
+    if (J3 <= 3)
+      hipLaunchKernelGGL((adj_map_kernel<3>), grid, block, 0, s, a);
+    else if (J3 <= 6)
+      hipLaunchKernelGGL((adj_map_kernel<6>), grid, block, 0, s, a);
+    else
+      hipLaunchKernelGGL((adj_map_kernel<12>), grid, block, 0, s, a);
+  }
   return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;
 }
 

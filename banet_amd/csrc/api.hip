@@ -290,6 +290,23 @@ int banet_sample_stats_grad_f32(const float* conv1, const float* conv2, const fl
                                   static_cast<hipStream_t>(stream));
 }
 
+size_t banet_sample_stats_grad_workspace_bytes(int B, int N, int C, int H, int W) {
+  if (!sstats_shape_ok(B, N, C, H, W)) return 0;
+  return sample_stats_grad_det_workspace_bytes(B, N, C, H, W);
+}
+
+int banet_sample_stats_grad_det_f32(const float* conv1, const float* conv2, const float* px, const float* py, int B, int N, int C,
+                                    int H, int W, const float* dstats, const float* dabs, float* dconv1, float* dconv2,
+                                    float* dpos, void* ws, size_t ws_bytes, banet_stream_t stream) {
+  if (!conv1 || !conv2 || !px || !py || !dstats || !dabs || !dconv1 || !dconv2 || !dpos || !ws) return BANET_ERR_INVALID_ARG;
+  if (!sstats_shape_ok(B, N, C, H, W)) return BANET_ERR_INVALID_ARG;
+  const size_t need = sample_stats_grad_det_workspace_bytes(B, N, C, H, W);
+  if (need == 0) return BANET_ERR_UNSUPPORTED;
+  if (ws_bytes < need || (reinterpret_cast<uintptr_t>(ws) & 255) != 0) return BANET_ERR_WORKSPACE;
+  return launch_sample_stats_grad_det(conv1, conv2, px, py, B, N, C, H, W, dstats, dabs, dconv1, dconv2, dpos, ws,
+                                      static_cast<hipStream_t>(stream));
+}
+
 size_t banet_dense_adjoint_workspace_bytes(const banet_level_t* lv) {
   if (!lv || lv->B <= 0 || lv->N <= 0) return 0;
   return dense_adjoint_workspace_bytes(lv);

@@ -376,8 +376,12 @@ def sample_stats_forward(conv1, conv2, px, py):
     return stats, part.sum(dim=1)
 
 
-def sample_stats_grad(conv1, conv2, px, py, dstats, dabs):
-    """banet_sample_stats_grad_f32 -> (dconv1 [B,N,C], dconv2 [B,H,W,3C], dpos [B,N,2])."""
+DETERMINISTIC_GRADIENTS = True   # sample_stats backward: fixed-order per-texel gather (True) or float-atomic scatter (False)
+
+
+def sample_stats_grad(conv1, conv2, px, py, dstats, dabs, deterministic=None):
+    """banet_sample_stats_grad_det_f32 (default: bit-reproducible) / banet_sample_stats_grad_f32 (float-atomic scatter)
+    -> (dconv1 [B,N,C], dconv2 [B,H,W,3C], dpos [B,N,2])."""
     conv1, conv2, px, py = capi.f32c(conv1), capi.f32c(conv2), capi.f32c(px), capi.f32c(py)
     dstats, dabs = capi.f32c(dstats), capi.f32c(dabs)
     B, N, C = conv1.shape
@@ -385,6 +389,16 @@ def sample_stats_grad(conv1, conv2, px, py, dstats, dabs):
     dconv1 = torch.empty_like(conv1)
     dconv2 = torch.zeros_like(conv2)
     dpos = torch.empty((B, N, 2), dtype=torch.float32, device=conv1.device)
+    if DETERMINISTIC_GRADIENTS if deterministic is None else deterministic:
+        L = capi.lib()
+        nb = L.banet_sample_stats_grad_workspace_bytes(B, N, C, H, W)
+        if nb == 0:
+            raise capi.BanetError("sample_stats_grad: unsupported shape")
+        ws = capi.workspace(nb, conv1.device)
+        capi.check(L.banet_sample_stats_grad_det_f32(capi.ptr(conv1), capi.ptr(conv2), capi.ptr(px), capi.ptr(py), B, N, C, H, W,
+                                                     capi.ptr(dstats), capi.ptr(dabs), capi.ptr(dconv1), capi.ptr(dconv2),
+                                                     capi.ptr(dpos), ctypes.c_void_p(ws.data_ptr()), ws.numel(), capi.stream()))
+        return dconv1, dconv2, dpos
     capi.check(capi.lib().banet_sample_stats_grad_f32(capi.ptr(conv1), capi.ptr(conv2), capi.ptr(px), capi.ptr(py), B, N, C, H, W,
                                                       capi.ptr(dstats), capi.ptr(dabs), capi.ptr(dconv1), capi.ptr(dconv2),
                                                       capi.ptr(dpos), capi.stream()))

@@ -235,6 +235,15 @@ int banet_sample_stats_grad_f32(const float* conv1, const float* conv2, const fl
                                 int C, int H, int W, const float* dstats, const float* dabs, float* dconv1,
                                 float* dconv2, float* dpos, banet_stream_t stream);
 
+/*   banet_sample_stats_grad_det_f32: the same gradients with dconv2 accumulated WITHOUT float atomics -- every point
+ *     writes its 3C contribution row and (target cell, bilinear fractions); per texel the contributions are then gathered
+ *     in a fixed order (cells row-major, ascending point index): bit-reproducible training gradients.  Workspace from
+ *     banet_sample_stats_grad_workspace_bytes (3C + 12 floats per point, 16 bytes per texel).                            */
+size_t banet_sample_stats_grad_workspace_bytes(int B, int N, int C, int H, int W);
+int banet_sample_stats_grad_det_f32(const float* conv1, const float* conv2, const float* px, const float* py, int B, int N,
+                                    int C, int H, int W, const float* dstats, const float* dabs, float* dconv1,
+                                    float* dconv2, float* dpos, void* ws, size_t ws_bytes, banet_stream_t stream);
+
 /* (7b) backward of the fused dense assembly (3) -- SURVEY.md 8(f1).  Given the upstream gradients of ONE assembly pass at
  *     the state (R, T, Wc),
  *       gAtA [B,P,P] (any matrix: symmetrised internally, utils.cu:648-657 assumes symmetry), gAtb [B,P],

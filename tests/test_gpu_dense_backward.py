@@ -164,3 +164,30 @@ def test_solve_differentiable_matches_the_fused_forward_and_oracle_finite_differ
     scale = max(abs(c[1]) for c in checks)
     for name, num, ana in checks:
         assert abs(num - ana) <= 2e-2 * max(abs(num), abs(ana)) + 1e-4 * scale, (name, num, ana)
+
+
+@pytest.mark.parametrize("B,N,C,H,W", [(2, 700, 128, 24, 32), (1, 4096, 70, 48, 64)])
+def test_sample_stats_grad_deterministic_variant_matches_the_atomic_one_and_is_bit_reproducible(B, N, C, H, W):
+    """banet_sample_stats_grad_det_f32 (the default of the reference-layout training graph): same gradients as the
+    float-atomic scatter to rounding, identical bits run to run; points outside the image, on the last row / column and
+    several points per target cell included."""
+    from banet_amd import ops
+    g = torch.Generator().manual_seed(5)
+    conv1 = torch.randn(B, N, C, generator=g).to(DEV)
+    conv2 = torch.randn(B, H, W, 3 * C, generator=g).to(DEV)
+    px = (torch.rand(B, N, generator=g) * (W + 3) - 2).to(DEV)
+    py = (torch.rand(B, N, generator=g) * (H + 3) - 2).to(DEV)
+    px[:, :8] = float(W - 1)                      # x1 = W is outside the image (weight 0)
+    py[:, 8:16] = float(H - 1)
+    px[:, 16:48] = 5.25                           # 32 points in one cell
+    py[:, 16:48] = 7.5
+    dstats = torch.randn(B, N, 8, generator=g).to(DEV)
+    dabs = torch.randn(B, C, generator=g).to(DEV)
+    a = ops.sample_stats_grad(conv1, conv2, px, py, dstats, dabs, deterministic=True)
+    b = ops.sample_stats_grad(conv1, conv2, px, py, dstats, dabs, deterministic=True)
+    c = ops.sample_stats_grad(conv1, conv2, px, py, dstats, dabs, deterministic=False)
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    for x, y in zip(a, c):
+        assert float((x - y).abs().max()) <= 1e-5 * max(float(y.abs().max()), 1e-30)
