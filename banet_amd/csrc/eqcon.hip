@@ -343,7 +343,7 @@ int plan_eq(int B, int N, int C, int P, EqPlan* pl) {
   // P <= 144: the SYRK formulation (eqcon_syrk.hip), one workgroup per CU, >= 1 step of 16 pixels per wave
   // (environment BANET_EQ_LDS_KERNEL=1 keeps the LDS-operand kernel: development A/B only)
   static const bool force_lds = getenv("BANET_EQ_LDS_KERNEL") != nullptr && atoi(getenv("BANET_EQ_LDS_KERNEL")) != 0;
-  pl->fast = (pl->nb <= 9 && !force_lds) ? 1 : 0;
+  pl->fast = (pl->nb <= 17 && !force_lds) ? 1 : 0;
   if (pl->fast) {
     G = (256 + B - 1) / B;
     const int steps = (N + 15) / 16;

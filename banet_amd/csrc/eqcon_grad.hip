@@ -1,4 +1,4 @@
-// EquationConstructionGrad for P <= 144 on the bf16 matrix pipe (the literal op of utils.cu:420-428,465-694):
+// EquationConstructionGrad for P <= 272 on the bf16 matrix pipe (the literal op of utils.cu:420-428,465-694):
 //   dJ = 2 M U + g g1^T,  dG = 2 G Q + d v^T,  dd = G v    with  U = J g0 (2 x P per pixel),  Q = U J^T (2x2),  v = J g1 (2),
 //   M = G^T G, g = G^T d.
 // U is the only large product: the [2N x P] . [P x P] GEMM.  Three kernels:
@@ -11,7 +11,7 @@
 //                          there, and the pixel's Q and v are reduced over the 16 lanes of a DPP row;
 //   eq_grad_gd_kernel      streams G and d again with (Q, v) per pixel -> dG, dd.
 // The first-generation kernel (eq_construction_grad_kernel, eqcon.hip: J and U tiles in LDS, U on the VALU) stays for
-// 144 < P and for callers that pass no workspace.
+// callers that pass no workspace.
 #include "kernels.hpp"
 #include "syrk_split.hpp"
 
@@ -31,11 +31,16 @@ struct EqGradUArgs {
   float* gJ;           // [B][N][2][P]
   float* rec2;         // [B][N][8]: q00, q01, q10, q11, v0, v1
   int N, P, Gr;
+  int ob0;             // first 16-column block of this pass's output columns
+  int accumulate;      // 1: add this pass's share of (Q, v) to rec2 (passes after the first one)
 };
 
-template <int NB>
+// NBK = 16-row blocks of g0 (the inner dimension, all of P), NB = 16-column blocks of this pass's output columns.  P <= 144:
+// one pass <9, 9>.  144 < P <= 272: g0's split image for all 17 x 17 blocks (413 KB) does not fit the LDS, so the output
+// columns are cut into chunks of 5 blocks (9 k-steps x 5 x 3 KB = 135 KB): four passes over J, (Q, v) accumulated across them.
+template <int NBK, int NB>
 __global__ __launch_bounds__(kGradThreads) void eq_grad_u_kernel(const EqGradUArgs a) {
-  constexpr int KS = (NB + 1) / 2;                       // 32-wide k steps covering 16 NB columns
+  constexpr int KS = (NBK + 1) / 2;                      // 32-wide k steps covering 16 NBK rows of g0
   extern __shared__ __attribute__((aligned(16))) unsigned sB[];   // [KS][NB][3][64] quads: g0 as MFMA B operands
   const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -53,7 +58,7 @@ __global__ __launch_bounds__(kGradThreads) void eq_grad_u_kernel(const EqGradUAr
     float vv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int k = 32 * ks + 8 * kq + e, c = 16 * bj + m;
+      const int k = 32 * ks + 8 * kq + e, c = 16 * (a.ob0 + bj) + m;
       vv[e] = (k < P && c < P) ? g0[(size_t)k * P + c] : 0.f;
     }
     u32x4_t pc[3];
@@ -63,7 +68,7 @@ __global__ __launch_bounds__(kGradThreads) void eq_grad_u_kernel(const EqGradUAr
   }
   float g1v[NB];
 #pragma unroll
-  for (int bj = 0; bj < NB; ++bj) g1v[bj] = (16 * bj + m < P) ? a.g1[(size_t)b * P + 16 * bj + m] : 0.f;
+  for (int bj = 0; bj < NB; ++bj) g1v[bj] = (16 * (a.ob0 + bj) + m < P) ? a.g1[(size_t)b * P + 16 * (a.ob0 + bj) + m] : 0.f;
   __syncthreads();
 
   // ---- blocks of 16 rows (8 pixels): block index rb over the window, this wave's share
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(kGradThreads) void eq_grad_u_kernel(const EqGradUAr
       float* gr = gJ_b + nn * 2 * P;
 #pragma unroll
       for (int bj = 0; bj < NB; ++bj) {
-        const int c = 16 * bj + m;
+        const int c = 16 * (a.ob0 + bj) + m;
         if (c < P) {
           const float u0 = acc[bj][2 * hq], u1 = acc[bj][2 * hq + 1];
           const float j0 = jr[c], j1 = jr[P + c];
@@ -160,8 +165,14 @@ __global__ __launch_bounds__(kGradThreads) void eq_grad_u_kernel(const EqGradUAr
       v1 = row16_sum(v1);
       if (ok && m == 0) {
         float4* o = reinterpret_cast<float4*>(rec2_b + nn * 8);
-        o[0] = make_float4(q00, q01, q10, q11);
-        o[1] = make_float4(v0, v1, 0.f, 0.f);
+        if (a.accumulate) {   // same lane, passes in launch order: a fixed summation order
+          const float4 p0 = o[0], p1 = o[1];
+          o[0] = make_float4(p0.x + q00, p0.y + q01, p0.z + q10, p0.w + q11);
+          o[1] = make_float4(p1.x + v0, p1.y + v1, 0.f, 0.f);
+        } else {
+          o[0] = make_float4(q00, q01, q10, q11);
+          o[1] = make_float4(v0, v1, 0.f, 0.f);
+        }
       }
     }
   }
@@ -203,17 +214,17 @@ __global__ __launch_bounds__(kBlock) void eq_grad_gd_kernel(const float* __restr
 }
 
 size_t eq_grad_fast_ws_bytes(int B, int N, int P) {
-  if (P > 144) return 0;
+  if (P > 272) return 0;
   return 2 * align_up((size_t)B * N * 8 * sizeof(float), 256);
 }
 
 void launch_eq_pixel_records(const float* G, const float* d, int B, int N, int C, int raw, float* rec, hipStream_t s);
 
-template <int NB>
+template <int NBK, int NB = NBK>
 static void launch_u(const EqGradUArgs& a, int B, hipStream_t s) {
-  constexpr int KS = (NB + 1) / 2;
+  constexpr int KS = (NBK + 1) / 2;
   const size_t lds = (size_t)KS * NB * 3 * 64 * 16;
-  auto k = eq_grad_u_kernel<NB>;
+  auto k = eq_grad_u_kernel<NBK, NB>;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k, dim3(a.Gr, B), dim3(kGradThreads), lds, s, a);
 }
@@ -227,7 +238,7 @@ int launch_eq_grad_fast(const float* J, const float* G, const float* d, const fl
   const int nblk = (N + 7) / 8;
   if (Gr > (nblk + kGradWaves - 1) / kGradWaves) Gr = (nblk + kGradWaves - 1) / kGradWaves;
   if (Gr < 1) Gr = 1;
-  const EqGradUArgs a{J, g0, g1, rec, gJ, rec2, N, P, Gr};
+  EqGradUArgs a{J, g0, g1, rec, gJ, rec2, N, P, Gr, 0, 0};
   const int nb = (P + 15) / 16;
   if (nb <= 1)
     launch_u<1>(a, B, s);
@@ -237,7 +248,16 @@ int launch_eq_grad_fast(const float* J, const float* G, const float* d, const fl
     launch_u<5>(a, B, s);
   else if (nb <= 9)
     launch_u<9>(a, B, s);
-  else
+  else if (nb <= 17) {   // output columns in chunks of 5 blocks: 0-4, 5-9, 10-14, 15-16
+    for (int ob = 0; ob < nb; ob += 5) {
+      a.ob0 = ob;
+      a.accumulate = ob > 0;
+      if (nb - ob > 2)
+        launch_u<17, 5>(a, B, s);     // columns >= P are masked
+      else
+        launch_u<17, 2>(a, B, s);
+    }
+  } else
     return BANET_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(eq_grad_gd_kernel, dim3((N + 31) / 32, B), dim3(kBlock), 0, s, G, d, rec2, N, C, gG, gd);
   return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;

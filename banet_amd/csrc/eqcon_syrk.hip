@@ -1,4 +1,4 @@
-// EquationConstruction forward for P <= 144 on the SYRK engine of syrk.hip (the literal op of utils.cu:150-171,219-417).
+// EquationConstruction forward for P <= 272 on the SYRK engine of syrk.hip (the literal op of utils.cu:150-171,219-417).
 //   AtA = sum_n J_n^T M_n J_n,  Atb = sum_n J_n^T g_n,   M_n = G_n^T G_n (2x2, PSD),  g_n = G_n^T d_n
 // M = L L^T (2x2 Cholesky) turns the sum into a plain W^T W over the 2N rows  w = L^T J :
 //   w_{2n} = l11 j_{2n} + l21 j_{2n+1},  w_{2n+1} = l22 j_{2n+1},   AtA = sum_r w_r w_r^T,
@@ -10,8 +10,9 @@
 //                             values w split exactly into three bf16 pieces: six v_mfma_f32_16x16x32_bf16 per 16x16
 //                             block and 32 rows, fp32 accumulate (syrk_split.hpp); Atb rides along as one record
 //                             block row (A operand row 0 = h).
-// The previous kernel (eq_construction_kernel, eqcon.hip: J tile in LDS, every fp32-MFMA operand fetched from LDS,
-// two barriers per 32 pixels) stays for 144 < P <= 272.
+// 144 < P <= 272 (17 column blocks) runs the same engine as four jobs -- two diagonal groups and two off-diagonal
+// rectangles, four passes over J.  The previous kernel (eq_construction_kernel, eqcon.hip: J tile in LDS, every fp32-MFMA
+// operand fetched from LDS, two barriers per 32 pixels) stays behind BANET_EQ_LDS_KERNEL=1 for A/B.
 #include "kernels.hpp"
 #include "syrk_split.hpp"
 
@@ -107,38 +108,50 @@ struct EqSyrkArgs {
   const float* rec;   // [B][N][8]
   float* partials;    // [B][Gr][pstride]: P x P then P
   int N, P, Gr, pstride;
+  int rb0, cb0;       // first 16-column block of the job's row side / column side
 };
 
-template <int NB>
+// One pass over the pixels = one JOB.  SYM: the upper triangle of the NBC x NBC blocks starting at block cb0 (= rb0) plus
+// the record block row (Atb) of those columns -- P <= 144 is the single job <9, 9, true> at 0.  !SYM: all NBR x NBC blocks
+// of rows rb0.. x columns cb0.. (an off-diagonal rectangle).  144 < P <= 272 (17 blocks: a wave cannot hold the 153 upper
+// blocks) = sym(0, 9) + sym(9, 8) + rect(0..4 x 9..16) + rect(5..8 x 9..16): four passes, every entry of the partial
+// written by exactly one job, so the reduction is unchanged.
+template <int NBR, int NBC, bool SYM>
 __global__ __launch_bounds__(kBlock, 1) void eq_syrk_kernel(const EqSyrkArgs a) {
-  constexpr int NPAIR = NB * (NB + 1) / 2;
-  __shared__ float sAcc[NPAIR + NB][4][64];
+  constexpr int NPAIR = SYM ? NBC * (NBC + 1) / 2 : NBR * NBC;
+  constexpr int NACU = SYM ? NBC : 0, NR = SYM ? 1 : NBR;
+  __shared__ float sAcc[NPAIR + NACU][4][64];
   const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int w = wave_id();
   const int N = a.N, P = a.P;
   const int m = lane & 15, kq = lane >> 4;
   const float* __restrict__ J_b = a.J + (size_t)b * N * 2 * P;
   const float* __restrict__ rec_b = a.rec + (size_t)b * N * 8;
-  int colc[NB];      // this lane's column in block bi, clamped (columns >= P are masked at use)
-  bool colok[NB];
+  int colc[NBC], rowc[NR];      // this lane's column in block bi, clamped (columns >= P are masked at use)
+  bool colok[NBC], rowok[NR];
 #pragma unroll
-  for (int bi = 0; bi < NB; ++bi) {
-    colok[bi] = 16 * bi + m < P;
-    colc[bi] = colok[bi] ? 16 * bi + m : P - 1;
+  for (int bi = 0; bi < NBC; ++bi) {
+    colok[bi] = 16 * (a.cb0 + bi) + m < P;
+    colc[bi] = colok[bi] ? 16 * (a.cb0 + bi) + m : P - 1;
+  }
+#pragma unroll
+  for (int bi = 0; bi < NR; ++bi) {
+    rowok[bi] = 16 * (a.rb0 + bi) + m < P;
+    rowc[bi] = rowok[bi] ? 16 * (a.rb0 + bi) + m : P - 1;
   }
 
   f32x4 acc[NPAIR];
-  f32x4 acu[NB];
+  f32x4 acu[NACU ? NACU : 1];
 #pragma unroll
   for (int q = 0; q < NPAIR; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int q = 0; q < NB; ++q) acu[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int q = 0; q < (NACU ? NACU : 1); ++q) acu[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // this wave's run of 16-pixel steps (32 rows of J); lane (m, kq) holds rows 8 kq .. 8 kq + 7 = pixels 4 kq .. 4 kq + 3
   const int ns = (N + 15) >> 4, nwaves = a.Gr * kNumWaves, gw = g * kNumWaves + w;
   const int s0 = (int)(((long long)ns * gw) / nwaves), s1 = (int)(((long long)ns * (gw + 1)) / nwaves);
 
-  float pj[8][NB];
+  float pj[8][NBC], pjr[8][NR];
   f32x4 pr[4][2];
   auto issue = [&](int st) __attribute__((always_inline)) {
 #pragma unroll
@@ -148,9 +161,16 @@ __global__ __launch_bounds__(kBlock, 1) void eq_syrk_kernel(const EqSyrkArgs a) 
       pr[q][1] = *reinterpret_cast<const f32x4*>(rec_b + n * 8 + 4);
       const float* r0 = J_b + n * 2 * P;
 #pragma unroll
-      for (int bi = 0; bi < NB; ++bi) {
+      for (int bi = 0; bi < NBC; ++bi) {
         pj[2 * q][bi] = r0[colc[bi]];
         pj[2 * q + 1][bi] = r0[P + colc[bi]];
+      }
+      if constexpr (!SYM) {
+#pragma unroll
+        for (int bi = 0; bi < NR; ++bi) {
+          pjr[2 * q][bi] = r0[rowc[bi]];
+          pjr[2 * q + 1][bi] = r0[P + rowc[bi]];
+        }
       }
     }
   };
@@ -169,11 +189,11 @@ __global__ __launch_bounds__(kBlock, 1) void eq_syrk_kernel(const EqSyrkArgs a) 
         ut[2 * q] = (ok && m == 0) ? pr[q][0][3] : 0.f;  // A-operand row 0 of the record block row = h
         ut[2 * q + 1] = (ok && m == 0) ? pr[q][1][0] : 0.f;
       }
-      split8_bf16x3(ut, opu);
+      if constexpr (SYM) split8_bf16x3(ut, opu);
     }
-    u32x4_t op[NB][3];
+    u32x4_t op[NBC][3], opr[NR][3];
 #pragma unroll
-    for (int bi = 0; bi < NB; ++bi) {
+    for (int bi = 0; bi < NBC; ++bi) {
       float vv[8];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -183,18 +203,38 @@ __global__ __launch_bounds__(kBlock, 1) void eq_syrk_kernel(const EqSyrkArgs a) 
       }
       split8_bf16x3(vv, op[bi]);
     }
+    if constexpr (!SYM) {
+#pragma unroll
+      for (int bi = 0; bi < NR; ++bi) {
+        float vv[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float j0 = rowok[bi] ? pjr[2 * q][bi] : 0.f, j1 = rowok[bi] ? pjr[2 * q + 1][bi] : 0.f;
+          vv[2 * q] = fmaf(l11[q], j0, l21[q] * j1);
+          vv[2 * q + 1] = l22[q] * j1;
+        }
+        split8_bf16x3(vv, opr[bi]);
+      }
+    }
     issue(st + 1);                                          // the raw registers are free again
     __builtin_amdgcn_sched_barrier(0);                      // keep the prefetch ahead of the MFMA block
+    if constexpr (SYM) {
 #pragma unroll
-    for (int bj = 0; bj < NB; ++bj) acu[bj] = mm6e(opu, op[bj], acu[bj]);
-    int idx = 0;
+      for (int bj = 0; bj < NBC; ++bj) acu[bj] = mm6e(opu, op[bj], acu[bj]);
+      int idx = 0;
 #pragma unroll
-    for (int bi = 0; bi < NB; ++bi)
+      for (int bi = 0; bi < NBC; ++bi)
 #pragma unroll
-      for (int bj = bi; bj < NB; ++bj) {
-        acc[idx] = mm6e(op[bi], op[bj], acc[idx]);
-        ++idx;
-      }
+        for (int bj = bi; bj < NBC; ++bj) {
+          acc[idx] = mm6e(op[bi], op[bj], acc[idx]);
+          ++idx;
+        }
+    } else {
+#pragma unroll
+      for (int bi = 0; bi < NR; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < NBC; ++bj) acc[bi * NBC + bj] = mm6e(opr[bi], op[bj], acc[bi * NBC + bj]);
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
 
@@ -206,7 +246,7 @@ __global__ __launch_bounds__(kBlock, 1) void eq_syrk_kernel(const EqSyrkArgs a) 
 #pragma unroll
         for (int r = 0; r < 4; ++r) sAcc[q][r][lane] = (ww == 0 ? 0.f : sAcc[q][r][lane]) + acc[q][r];
 #pragma unroll
-      for (int q = 0; q < NB; ++q)
+      for (int q = 0; q < NACU; ++q)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float* c = &sAcc[NPAIR + q][r][lane];
@@ -217,11 +257,11 @@ __global__ __launch_bounds__(kBlock, 1) void eq_syrk_kernel(const EqSyrkArgs a) 
   }
   float* __restrict__ part = a.partials + ((size_t)b * a.Gr + g) * a.pstride;
   const int r = w, brow = 4 * kq + r;   // thread (w, lane) publishes accumulator register r = w: row 4 kq + r, column m
-  {
+  if constexpr (SYM) {
     int idx = 0;
-    for (int bi = 0; bi < NB; ++bi)
-      for (int bj = bi; bj < NB; ++bj) {
-        const int rr = 16 * bi + brow, cc = 16 * bj + m;
+    for (int bi = 0; bi < NBC; ++bi)
+      for (int bj = bi; bj < NBC; ++bj) {
+        const int rr = 16 * (a.cb0 + bi) + brow, cc = 16 * (a.cb0 + bj) + m;
         if (rr < P && cc < P && (bj > bi || rr <= cc)) {
           const float v = sAcc[idx][r][lane];
           part[rr * P + cc] = v;
@@ -229,12 +269,22 @@ __global__ __launch_bounds__(kBlock, 1) void eq_syrk_kernel(const EqSyrkArgs a) 
         }
         ++idx;
       }
-  }
-  if (brow == 0) {
-    for (int bj = 0; bj < NB; ++bj) {
-      const int cc = 16 * bj + m;
-      if (cc < P) part[P * P + cc] = sAcc[NPAIR + bj][r][lane];
+    if (brow == 0) {
+      for (int bj = 0; bj < NBC; ++bj) {
+        const int cc = 16 * (a.cb0 + bj) + m;
+        if (cc < P) part[P * P + cc] = sAcc[NPAIR + bj][r][lane];
+      }
     }
+  } else {
+    for (int bi = 0; bi < NR; ++bi)
+      for (int bj = 0; bj < NBC; ++bj) {
+        const int rr = 16 * (a.rb0 + bi) + brow, cc = 16 * (a.cb0 + bj) + m;
+        if (rr < P && cc < P) {
+          const float v = sAcc[bi * NBC + bj][r][lane];
+          part[rr * P + cc] = v;
+          part[cc * P + rr] = v;
+        }
+      }
   }
 }
 
@@ -247,14 +297,24 @@ size_t eq_syrk_record_bytes(int B, int N) { return align_up((size_t)B * N * 8 * 
 int launch_eq_syrk(const float* J, const float* G, const float* d, int B, int N, int C, int P, int nb, int Gr, int pstride,
                    float* partials, float* rec, hipStream_t s) {
   launch_eq_pixel_records(G, d, B, N, C, 0, rec, s);
-  const EqSyrkArgs a{J, rec, partials, N, P, Gr, pstride};
+  EqSyrkArgs a{J, rec, partials, N, P, Gr, pstride, 0, 0};
   const dim3 grid(Gr, B), block(kBlock);
   switch (nb) {
-    case 1: hipLaunchKernelGGL(eq_syrk_kernel<1>, grid, block, 0, s, a); break;
-    case 2: hipLaunchKernelGGL(eq_syrk_kernel<2>, grid, block, 0, s, a); break;
-    case 3: hipLaunchKernelGGL(eq_syrk_kernel<3>, grid, block, 0, s, a); break;
-    case 5: hipLaunchKernelGGL(eq_syrk_kernel<5>, grid, block, 0, s, a); break;
-    case 9: hipLaunchKernelGGL(eq_syrk_kernel<9>, grid, block, 0, s, a); break;
+    case 1: hipLaunchKernelGGL((eq_syrk_kernel<1, 1, true>), grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((eq_syrk_kernel<2, 2, true>), grid, block, 0, s, a); break;
+    case 3: hipLaunchKernelGGL((eq_syrk_kernel<3, 3, true>), grid, block, 0, s, a); break;
+    case 5: hipLaunchKernelGGL((eq_syrk_kernel<5, 5, true>), grid, block, 0, s, a); break;
+    case 9: hipLaunchKernelGGL((eq_syrk_kernel<9, 9, true>), grid, block, 0, s, a); break;
+    case 17: {   // 144 < P <= 272: four jobs (see eq_syrk_kernel)
+      hipLaunchKernelGGL((eq_syrk_kernel<9, 9, true>), grid, block, 0, s, a);
+      a.rb0 = a.cb0 = 9;
+      hipLaunchKernelGGL((eq_syrk_kernel<8, 8, true>), grid, block, 0, s, a);
+      a.rb0 = 0;
+      hipLaunchKernelGGL((eq_syrk_kernel<5, 8, false>), grid, block, 0, s, a);
+      a.rb0 = 5;
+      hipLaunchKernelGGL((eq_syrk_kernel<4, 8, false>), grid, block, 0, s, a);
+      break;
+    }
     default: return BANET_ERR_UNSUPPORTED;
   }
   return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;

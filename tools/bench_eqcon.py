@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from banet_amd import ops
 dev = torch.device("cuda:0")
 C = 128
-for B, N, P in ((8, 4096, 134), (8, 76800, 134), (2, 307200, 134), (8, 76800, 6), (2, 76800, 262)):
+for B, N, P in ((8, 4096, 134), (8, 76800, 134), (2, 307200, 134), (8, 76800, 6), (2, 76800, 262), (8, 76800, 262), (8, 76800, 200)):
     g = torch.Generator().manual_seed(1)
     J = torch.randn(B, N, 2, P, generator=g).to(dev)
     G = torch.randn(B, N, C, 2, generator=g).to(dev)
