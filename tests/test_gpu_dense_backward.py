@@ -55,7 +55,8 @@ def _run_adjoint(intr, lv, R, T, Wc, G, gb, gabs):
     return dict(dsrc=out["dsrc"], dmap3=out["dmap3"], ddepth=out["ddepth"], dbasis=out["dbasis"], dpose=dpose, dtgt=dtgt)
 
 
-@pytest.mark.parametrize("H,W,C,K,seed", [(24, 32, 6, 5, 3), (48, 64, 128, 128, 7), (30, 41, 70, 33, 11)])
+@pytest.mark.parametrize("H,W,C,K,seed", [(24, 32, 6, 5, 3), (48, 64, 128, 128, 7), (30, 41, 70, 33, 11), (9, 11, 3, 1, 5),
+                                          (16, 16, 64, 16, 2), (17, 33, 130, 40, 9), (20, 24, 256, 64, 4)])
 def test_dense_adjoint_kernels_match_the_float64_statement(H, W, C, K, seed):
     intr, levels, R, T, Wc, rng = _scene(H, W, C, K, seed)
     lv = levels[0]
@@ -191,3 +192,32 @@ def test_sample_stats_grad_deterministic_variant_matches_the_atomic_one_and_is_b
         assert torch.equal(x, y)
     for x, y in zip(a, c):
         assert float((x - y).abs().max()) <= 1e-5 * max(float(y.abs().max()), 1e-30)
+
+
+def test_dense_adjoint_with_most_pixels_outside_the_image_and_an_empty_window():
+    """A large rotation pushes most of window 0's pixels out of the target image (masked: no contribution anywhere), window 1
+    is translated out of view (every pixel masked): finite gradients, equal to the float64 statement; the empty window's are 0."""
+    H, W, C, K = 24, 32, 16, 8
+    intr, levels, R, T, Wc, rng = _scene(H, W, C, K, 13)
+    lv = levels[0]
+    R = R.copy()
+    R[0] = synth.rodrigues(np.array([0.0, 0.35, 0.05]))
+    T = T.copy()
+    T[1] = np.array([[60.0], [0.0], [0.0]])                      # every pixel projects far outside the image
+    B, P = 2, 6 + K
+    G = rng.standard_normal((B, P, P))
+    gb = rng.standard_normal((B, P, 1))
+    gabs = rng.standard_normal((B, 1, C)) * 0.1
+    f32 = lambda v: np.asarray(v, np.float32).astype(np.float64)
+    lv64 = {k: (f32(v) if isinstance(v, np.ndarray) else v) for k, v in lv.items()}
+    a = odense.level_inputs(intr, lv64, True, np.float64)
+    want = oadj.assembly_adjoint(a, lv64["tgt"], f32(R), f32(T), f32(Wc), f32(G), f32(gb), f32(gabs) * H * W)
+    frac = want["fwd"]["mask"].mean(axis=1)
+    assert 0.02 < frac[0] < 0.7 and frac[1] == 0.0, frac
+    got = _run_adjoint(intr, lv, R, T, Wc, G, gb, gabs)
+    for name, w in (("dsrc", want["dsrc"]), ("dtgt", want["dtgt"]), ("ddepth", want["dD0"]), ("dbasis", want["dbasis"])):
+        g = n(got[name]).reshape(w.shape)
+        assert np.isfinite(g).all()
+        assert np.abs(g - w).max() <= 2e-4 * max(np.abs(w).max(), 1e-30), name
+        assert np.abs(g[1]).max() == 0.0, name
+    assert np.isfinite(n(got["dpose"])).all() and np.abs(n(got["dpose"])[1]).max() == 0.0
