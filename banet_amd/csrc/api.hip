@@ -28,6 +28,7 @@ struct LevelWs {  // carve of the level workspace
   float* absres;
   float* nvalid;
   LmCtl* ctl;
+  float* mlp_y;   // [B] lambda-MLP outputs of the SYRK launch's role workgroups
   float* bigA;
   size_t total;
 };
@@ -47,6 +48,7 @@ static LevelWs carve_level(const banet_level_t* lv, const AsmPlan& pl, void* ws)
   w.absres = reinterpret_cast<float*>(take((size_t)lv->B * lv->C * sizeof(float)));
   w.nvalid = reinterpret_cast<float*>(take((size_t)lv->B * sizeof(float)));
   w.ctl = reinterpret_cast<LmCtl*>(take((size_t)lv->B * sizeof(LmCtl)));
+  w.mlp_y = reinterpret_cast<float*>(take((size_t)lv->B * sizeof(float)));
   const size_t big = solve_big_bytes(lv->B, pl.P, lv->C);
   w.bigA = big ? reinterpret_cast<float*>(take(big)) : nullptr;
   w.total = off;
@@ -78,6 +80,7 @@ static SolveArgs make_solve_args(const banet_level_t* lv, const banet_mlp_t* mlp
   a.queue = nullptr;
   a.nqueue = 0;
   a.bigA = nullptr;
+  a.mlp_y = nullptr;
   banet_lm_params_default(&a.lm);
   return a;
 }
@@ -240,9 +243,21 @@ int banet_lm_level_ex_f32(const banet_level_t* lv, const banet_mlp_t* mlp, float
     a.queue = assemble_queue(pl, w.partials);
     a.nqueue = 8 * npairs(lv);
     if (a.queue) launch_zero_iters(a.queue, lv->B * a.nqueue, s);   // a kernel, not hipMemsetAsync: see prepare_gather
+    // bundle levels whose SYRK is ba_syrk_bf16x6_kernel: the lambda MLP runs as a role workgroup of the SYRK launch, off the
+    // solve kernel's critical path (C <= 256: the role's LDS scratch)
+    // Small batches only (B <= 8): the SYRK kernel runs one workgroup per CU (512 registers per wave), so the role workgroups
+    // need CUs of their own -- at B = 32 (8 + 1 workgroups per window = 288 > 256 CUs) a second round of workgroups doubled
+    // the SYRK time (640x480 x 32: 1326 -> 2457 us); with B <= 8 one SYRK workgroup per window is given up where needed.
+    const bool role = lv->variant == BANET_BUNDLE && mlp != nullptr && a.use_mlp && syrk_runs_mlp_role(pl.s) && lv->C <= 256 &&
+                      (lv->C & 3) == 0 && lv->B <= 8 && ((long long)lv->B * (pl.s.Gs + 1) <= 256 || pl.s.Gs >= 16) &&
+                      !(lv->reserved_ & 32768);   // reserved_ bit 15: MLP inside the solve kernel (A/B)
+    if (role) {
+      a.mlp_y = w.mlp_y;
+      if ((long long)lv->B * (pl.s.Gs + 1) > 256) pl.s.Gs -= 1;
+    }
     for (int it = 0; it < max_iters; ++it) {
       rc = launch_assemble(lv, pl, st->R, st->T, st->Wc, nullptr, 0, w.partials, w.AtA, w.Atb, w.absres, w.nvalid, s,
-                           a.queue == nullptr);
+                           a.queue == nullptr, role ? mlp : nullptr, role ? w.mlp_y : nullptr);
       if (rc != BANET_OK) return rc;
       rc = launch_solve(a, s);
       if (rc != BANET_OK) return rc;

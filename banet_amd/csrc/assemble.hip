@@ -88,7 +88,7 @@ int* assemble_queue(const AsmPlan& pl, void* ws) {
 // tags for the profiler: +N = gather kernel at a level with N points, -N = syrk kernel
 int launch_assemble(const banet_level_t* lv, const AsmPlan& pl, const float* R, const float* T, const float* Wc,
                     const int32_t* active, int active_stride, void* ws, float* AtA, float* Atb, float* absres,
-                    float* nvalid, hipStream_t s, bool reset_queue) {
+                    float* nvalid, hipStream_t s, bool reset_queue, const banet_mlp_t* role_mlp, float* role_y) {
   char* base = static_cast<char*>(ws);
   float* gpart = reinterpret_cast<float*>(base);
   float* rec = lv->K > 0 ? reinterpret_cast<float*>(base + pl.off_rec) : nullptr;
@@ -103,7 +103,19 @@ int launch_assemble(const banet_level_t* lv, const AsmPlan& pl, const float* R, 
   const float* gred = finish_gather(lv, pl.g, active, active_stride, gpart, s);
   if (lv->K > 0) {
     Timed t(s, -lv->N);
-    rc = launch_syrk(lv->basis, rec, lv->B, lv->N, lv->K, npairs(lv), pl.s, active, active_stride, spart, s);
+    MlpRole mr{};
+    if (role_mlp != nullptr && role_y != nullptr && syrk_runs_mlp_role(pl.s)) {
+      mr.gpart = gred;
+      mr.grows = pl.g.frows;
+      mr.gstride = pl.g.pstride;
+      mr.mlp = *role_mlp;
+      mr.C = lv->C;
+      mr.pairs = npairs(lv);
+      mr.Nf = (float)lv->N * (float)npairs(lv);
+      mr.y = role_y;
+    }
+    rc = launch_syrk(lv->basis, rec, lv->B, lv->N, lv->K, npairs(lv), pl.s, active, active_stride, spart, s,
+                     mr.y != nullptr ? &mr : nullptr);
     if (rc != BANET_OK) return rc;
   }
   launch_reduce2(gred, pl.g.frows, pl.g.pstride, spart, pl.s.Gs, pl.s.pstride, active, active_stride, lv->B, lv->K, lv->C,

@@ -33,6 +33,14 @@ const float* finish_gather(const banet_level_t* lv, const GatherPlan& pl, const 
                            float* partials, hipStream_t s);
 
 // ---- syrk.hip --------------------------------------------------------------------------
+struct MlpRole {        // one extra workgroup per window of the SYRK launch evaluates the lambda MLP (mlp.hpp); y == nullptr: off
+  const float* gpart;   // folded gather partial rows [B * pairs][grows][gstride]
+  int grows, gstride;
+  banet_mlp_t mlp;
+  int C, pairs;
+  float Nf;             // residual rows per window (N * pairs)
+  float* y;             // [B] MLP output
+};
 struct SyrkPlan {
   int Gs, tiles, pstride, nb;
   int direct;   // 0: the LDS-tiled kernel, 1: ba_syrk_direct_kernel (fp32 MFMA, A/B), 2: ba_syrk_bf16x6_kernel (K = 64 / 128, <= 4 frames),
@@ -45,7 +53,8 @@ int launch_syrk_wide(const float* basis, const float* rec, int B, int N, int K, 
                      const int32_t* active, int active_stride, float* partials, float* aux, hipStream_t s);
 int plan_syrk(int B, int N, int K, int pairs, int dbg, SyrkPlan* pl);
 int launch_syrk(const float* basis, const float* rec, int B, int N, int K, int pairs, const SyrkPlan& pl,
-                const int32_t* active, int active_stride, float* partials, hipStream_t s);
+                const int32_t* active, int active_stride, float* partials, hipStream_t s, const MlpRole* mr = nullptr);
+inline bool syrk_runs_mlp_role(const SyrkPlan& pl) { return pl.direct == 2; }   // ba_syrk_bf16x6_kernel only
 void launch_reduce2(const float* gpart, int Gg, int gstride, const float* spart, int Gs, int sstride,
                     const int32_t* active, int active_stride, int B, int K, int C, int pairs, float* AtA, float* Atb,
                     float* absres, float* nvalid, hipStream_t s);
@@ -61,7 +70,8 @@ struct AsmPlan {
 int plan_assemble(const banet_level_t* lv, AsmPlan* pl);
 int launch_assemble(const banet_level_t* lv, const AsmPlan& pl, const float* R, const float* T, const float* Wc,
                     const int32_t* active, int active_stride, void* ws, float* AtA, float* Atb, float* absres,
-                    float* nvalid, hipStream_t s, bool reset_queue = true);
+                    float* nvalid, hipStream_t s, bool reset_queue = true, const banet_mlp_t* role_mlp = nullptr,
+                    float* role_y = nullptr);
 int* assemble_queue(const AsmPlan& pl, void* ws);   // the gather's tile-queue heads inside the workspace (or nullptr)
 int profile_begin(int max_launches);
 int profile_end(int max_tags, int32_t* tag_points, int32_t* tag_launches, double* tag_ms, int32_t* ntags);
@@ -120,6 +130,7 @@ struct SolveArgs {
   float* bigA; // workspace for the normal matrix when it does not fit in LDS (solve_big_bytes), else nullptr
   int* queue;  // LM loop: the next gather's tile-queue heads, zeroed by this kernel (saves a memset per iteration)
   int nqueue;  // words per window
+  const float* mlp_y;   // [B] lambda-MLP outputs precomputed by the SYRK launch's role workgroups, or nullptr
   banet_lm_params_t lm;   // run-time LM configuration (legacy/ba.py:5-9)
 };
 int launch_solve(const SolveArgs& a, hipStream_t s);

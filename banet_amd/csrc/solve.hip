@@ -12,6 +12,7 @@
 #include <type_traits>
 
 #include "kernels.hpp"
+#include "mlp.hpp"
 
 namespace banet {
 
@@ -27,28 +28,11 @@ __device__ __forceinline__ unsigned long long stick() {
 #endif
 
 constexpr int kSolveThreads = 1024;   // 16 waves: 4 per SIMD, so the latency-bound phases overlap
-constexpr int kSolveWaves = kSolveThreads / 64;
+[[maybe_unused]] constexpr int kSolveWaves = kSolveThreads / 64;
 constexpr int kGrid = 32;              // 2-D cyclic thread grid of the register-resident solvers
 
-constexpr float kSeluAlpha = 1.6732632423543772848170429916717f;
-constexpr float kSeluScale = 1.0507009873554804934193349852946f;
-// (the loop thresholds / residual ratio / solver choice of legacy/ba.py:5-9 arrive in SolveArgs::lm)
-
-__device__ __forceinline__ float selu(float x) {
-  return kSeluScale * (x > 0.f ? x : kSeluAlpha * (expf(x) - 1.f));
-}
-
-// block-wide sum of one value per thread, fixed order (deterministic)
-__device__ float block_sum(float v, float* sred) {
-  v = wave_sum(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = v;
-  __syncthreads();
-  float r = 0.f;
-#pragma unroll
-  for (int i = 0; i < kSolveWaves; ++i) r += sred[i];
-  return r;
-}
+// selu / block_sum_t / mlp_layer_t: mlp.hpp (shared with the MLP role workgroup of the SYRK launch)
+__device__ __forceinline__ float block_sum(float v, float* sred) { return block_sum_t<kSolveThreads>(v, sred); }
 
 // sum over the 64 lanes without the LDS crossbar; every lane gets the total
 __device__ __forceinline__ float wave_sum_fast(float v) {
@@ -86,68 +70,9 @@ __device__ __forceinline__ int wave_min_fast(int v) {
   return min(a, b);
 }
 
-// one k=1 conv layer: out[o] = act(sum_i in[i] W[i][o] + b[o]);  act: 0 selu, 1 tanh.
-// Output quads x input slices over the 256 threads: 16-byte weight loads, 8 in flight per thread,
-// partial sums combined in fixed order through LDS (sPart: >= 1024 floats).
-__device__ void mlp_layer(const float* in, float* out, const float* __restrict__ Wt, const float* __restrict__ bias,
-                          int nin, int nout, int act, float* sPart, float* sred) {
-  const int tid = threadIdx.x;
-  const int groups = nout >> 2;
-  if ((nout & 3) == 0 && groups <= kSolveThreads && ((reinterpret_cast<uintptr_t>(Wt) & 15) == 0)) {
-    int ksplit = kSolveThreads / groups;
-    if (ksplit > nin) ksplit = nin;
-    const int q = tid % groups, sl = tid / groups;
-    if (sl < ksplit) {
-      const int chunk = (nin + ksplit - 1) / ksplit;
-      const int i0 = sl * chunk, i1 = min(nin, i0 + chunk);
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float* wp = Wt + 4 * q;
-#pragma unroll 16
-      for (int i = i0; i < i1; ++i) {
-        const float4 w4 = *reinterpret_cast<const float4*>(wp + (size_t)i * nout);
-        const float xv = in[i];
-        acc.x = fmaf(xv, w4.x, acc.x);
-        acc.y = fmaf(xv, w4.y, acc.y);
-        acc.z = fmaf(xv, w4.z, acc.z);
-        acc.w = fmaf(xv, w4.w, acc.w);
-      }
-      *reinterpret_cast<float4*>(sPart + sl * nout + 4 * q) = acc;
-    }
-    __syncthreads();
-    for (int o = tid; o < nout; o += kSolveThreads) {
-      float v = 0.f;
-      for (int k = 0; k < ksplit; ++k) v += sPart[k * nout + o];
-      v += bias[o];
-      out[o] = act == 0 ? selu(v) : tanhf(v);
-    }
-    __syncthreads();
-  } else if (nout >= 64) {
-    for (int o = tid; o < nout; o += kSolveThreads) {
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-      int i = 0;
-      for (; i + 3 < nin; i += 4) {
-        a0 = fmaf(in[i], Wt[(size_t)i * nout + o], a0);
-        a1 = fmaf(in[i + 1], Wt[(size_t)(i + 1) * nout + o], a1);
-        a2 = fmaf(in[i + 2], Wt[(size_t)(i + 2) * nout + o], a2);
-        a3 = fmaf(in[i + 3], Wt[(size_t)(i + 3) * nout + o], a3);
-      }
-      for (; i < nin; ++i) a0 = fmaf(in[i], Wt[(size_t)i * nout + o], a0);
-      const float v = ((a0 + a1) + (a2 + a3)) + bias[o];
-      out[o] = act == 0 ? selu(v) : tanhf(v);
-    }
-    __syncthreads();
-  } else {
-    for (int o = 0; o < nout; ++o) {
-      float a = 0.f;
-      for (int i = tid; i < nin; i += kSolveThreads) a = fmaf(in[i], Wt[(size_t)i * nout + o], a);
-      const float s = block_sum(a, sred);
-      if (tid == 0) {
-        const float v = s + bias[o];
-        out[o] = act == 0 ? selu(v) : tanhf(v);
-      }
-    }
-    __syncthreads();
-  }
+__device__ __forceinline__ void mlp_layer(const float* in, float* out, const float* __restrict__ Wt, const float* __restrict__ bias,
+                                          int nin, int nout, int act, float* sPart, float* sred) {
+  mlp_layer_t<kSolveThreads>(in, out, Wt, bias, nin, nout, act, sPart, sred);
 }
 
 // Householder QR of a 6x6 system and back-substitution (thread 0, LDS-resident, fp32):
@@ -633,7 +558,10 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve_update_kernel(const So
   const float avg_scalar = block_sum(sm, sRed) / (float)C;     // legacy/ba.py:275
   // ---- lambda -----------------------------------------------------------------------
   float lam;
-  if (a.use_mlp) {
+  if (a.use_mlp && a.mlp_y != nullptr) {   // evaluated by the MLP role workgroup of this iteration's SYRK launch
+    const float e = legacy ? 1.f : 2.f;
+    lam = powf(nrm, e + a.mlp_y[b]);
+  } else if (a.use_mlp) {
     __syncthreads();
     mlp_layer(sAvg, sH0, a.mlp.w[0], a.mlp.b[0], C, 2 * C, 0, sPart, sRed);
     mlp_layer(sH0, sH1, a.mlp.w[1], a.mlp.b[1], 2 * C, 4 * C, 0, sPart, sRed);

@@ -17,6 +17,7 @@
 // LDS double buffer, one barrier per tile.  Wave w owns block rows w and NB-1-w of the upper
 // triangle (NB+1 blocks: balanced); accumulators stay in registers for the whole kernel.
 #include "kernels.hpp"
+#include "mlp.hpp"
 #include "syrk_split.hpp"
 
 namespace banet {
@@ -30,6 +31,7 @@ struct SyrkArgs {
   int N, K, Gs, tiles, pstride;
   int pairs;           // target frames per window (records of pair i: rec + ((b pairs + i) N) 8)
   int pass;            // LDS-tiled kernel only: pass p adds H_cd of pair p; pass 0 also H_dd / Atb_d with s, r summed over pairs
+  MlpRole mr;          // ba_syrk_bf16x6_kernel: workgroup Gs of every window evaluates the lambda MLP (mr.y != nullptr)
 };
 
 template <int NB>
@@ -453,8 +455,13 @@ __global__ __launch_bounds__(kBlock, 1) void ba_syrk_bf16x6_kernel(const SyrkArg
   constexpr int NBV = 4 * KH, NPAIR = NBV * (NBV + 1) / 2, K = 64 * KH;
   constexpr int NU = (PAIRS + 1) / 2;
   __shared__ float sAcc[NPAIR + NU * NBV][4][64];
+  __shared__ float sMlp[kMlpRoleFloats];
   const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   if (a.active != nullptr && a.active[(size_t)b * a.active_stride] == 0) return;
+  if (g == a.Gs) {   // the MLP role workgroup (launched only when a.mr.y != nullptr): hidden behind the SYRK workgroups
+    mlp_role_block(a.mr, b, sMlp);
+    return;
+  }
   const int w = wave_id();
   const int N = a.N;
   const int m = lane & 15, kq = lane >> 4;
@@ -783,7 +790,7 @@ static void launch_syrk_nb(const SyrkArgs& a, int B, hipStream_t s) {
 
 template <int KH>
 static void launch_bf16x6(const SyrkArgs& a, int B, hipStream_t s) {
-  const dim3 grid(a.Gs, B), block(kBlock);
+  const dim3 grid(a.Gs + (a.mr.y != nullptr ? 1 : 0), B), block(kBlock);
   switch (a.pairs) {
     case 1: hipLaunchKernelGGL((ba_syrk_bf16x6_kernel<KH, 1>), grid, block, 0, s, a); break;
     case 2: hipLaunchKernelGGL((ba_syrk_bf16x6_kernel<KH, 2>), grid, block, 0, s, a); break;
@@ -804,12 +811,13 @@ static void launch_direct(const SyrkArgs& a, int B, hipStream_t s) {
 }
 
 int launch_syrk(const float* basis, const float* rec, int B, int N, int K, int pairs, const SyrkPlan& pl,
-                const int32_t* active, int active_stride, float* partials, hipStream_t s) {
+                const int32_t* active, int active_stride, float* partials, hipStream_t s, const MlpRole* mr) {
   if (pl.direct == 3)
     return launch_syrk_wide(basis, rec, B, N, K, pairs, pl.Gs, pl.pstride, active, active_stride, partials,
                             reinterpret_cast<float*>(reinterpret_cast<char*>(partials) + pl.off_aux), s);
-  SyrkArgs a{basis, rec, active, active_stride, partials, N, K, pl.Gs, pl.tiles, pl.pstride, pairs, 0};
+  SyrkArgs a{basis, rec, active, active_stride, partials, N, K, pl.Gs, pl.tiles, pl.pstride, pairs, 0, MlpRole{}};
   if (pl.direct == 2) {
+    if (mr != nullptr) a.mr = *mr;
     if (K == 128)
       launch_bf16x6<2>(a, B, s);
     else
