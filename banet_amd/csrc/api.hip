@@ -249,7 +249,7 @@ int banet_lm_level_ex_f32(const banet_level_t* lv, const banet_mlp_t* mlp, float
     // need CUs of their own -- at B = 32 (8 + 1 workgroups per window = 288 > 256 CUs) a second round of workgroups doubled
     // the SYRK time (640x480 x 32: 1326 -> 2457 us); with B <= 8 one SYRK workgroup per window is given up where needed.
     const bool role = lv->variant == BANET_BUNDLE && mlp != nullptr && a.use_mlp && syrk_runs_mlp_role(pl.s) && lv->C <= 256 &&
-                      (lv->C & 3) == 0 && lv->B <= 8 && ((long long)lv->B * (pl.s.Gs + 1) <= 256 || pl.s.Gs >= 16) &&
+                      (lv->C & 3) == 0 && ((long long)lv->B * (pl.s.Gs + 1) <= 256 || (lv->B <= 8 && pl.s.Gs >= 16)) &&
                       !(lv->reserved_ & 32768);   // reserved_ bit 15: MLP inside the solve kernel (A/B)
     if (role) {
       a.mlp_y = w.mlp_y;
