@@ -202,3 +202,28 @@ def test_plain_c_program_links_against_the_library(tmp_path):
                            "-L", libdir, "-lbanet_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.check_output([str(exe)]).decode()
     assert out.startswith("c-abi ok 140")
+
+
+def test_backward_entry_points_validate_their_arguments_without_gpu(capi):
+    """banet_dense_adjoint_f32 / banet_target_map_adjoint_f32 / banet_sample_stats_grad_det_f32: supported-shape queries and
+    argument validation run on the host (no launch)."""
+    L = capi.lib()
+    lv = capi.Level()
+    lv.B, lv.N, lv.C, lv.K, lv.H, lv.W = 2, 48 * 64, 128, 128, 48, 64
+    lv.variant, lv.dense, lv.scale, lv.pairs = capi.BUNDLE, 1, 1.0, 1
+    nb = L.banet_dense_adjoint_workspace_bytes(ctypes.byref(lv))
+    assert nb > 0 and nb % 256 == 0
+    for field, bad in (("K", 129), ("K", 0), ("C", 257), ("pairs", 2), ("dense", 0), ("tgt_has_grad", 1), ("N", 100)):
+        keep = getattr(lv, field)
+        setattr(lv, field, bad)
+        assert L.banet_dense_adjoint_workspace_bytes(ctypes.byref(lv)) == 0, field      # outside the supported set
+        setattr(lv, field, keep)
+    lv.variant = capi.BUNDLE_CAMERA if hasattr(capi, "BUNDLE_CAMERA") else 2
+    assert L.banet_dense_adjoint_workspace_bytes(ctypes.byref(lv)) == 0
+    lv.variant = capi.BUNDLE
+    assert L.banet_dense_adjoint_f32(ctypes.byref(lv), *([None] * 11), None, 0, None) == -1   # null pointers
+    assert L.banet_dense_adjoint_f32(None, *([None] * 11), None, 0, None) == -1
+    assert L.banet_target_map_adjoint_f32(None, None, 1, 4, 4, 8, None) == -1
+    assert L.banet_sample_stats_grad_workspace_bytes(2, 1000, 128, 48, 64) > 0
+    assert L.banet_sample_stats_grad_workspace_bytes(2, 1000, 257, 48, 64) == 0              # C > 256
+    assert L.banet_sample_stats_grad_det_f32(*([None] * 4), 2, 1000, 128, 48, 64, *([None] * 5), None, 0, None) == -1
