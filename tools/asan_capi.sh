@@ -8,7 +8,7 @@ set -euo pipefail
 cd "$(dirname "$0")/.."
 OUT=build/asan
 mkdir -p $OUT
-SRCS="gather gather128 gather128p syrk syrk_wide assemble eqcon eqcon_syrk eqcon_grad solve prep sstats api"
+SRCS="gather gather128 gather128p syrk syrk_wide assemble eqcon eqcon_syrk eqcon_grad solve prep sstats adjoint api"
 SAN="-Xarch_host -fsanitize=address,undefined -Xarch_host -fno-omit-frame-pointer -Xarch_host -fno-sanitize-recover=undefined"
 pids=()
 for f in $SRCS; do
@@ -62,6 +62,12 @@ int main(void) {
             EXPECT(banet_ba_assemble_f32(&lv, dummy, dummy, dummy, dummy, dummy, dummy, dummy, dummy, 1u << 20, 0) == BANET_ERR_INVALID_ARG);
             banet_state_t st; memset(&st, 0, sizeof st);
             EXPECT(banet_lm_level_ex_f32(&lv, 0, 1.0f, 3, 1, &lp, &st, dummy, 1u << 20, 0) == BANET_ERR_INVALID_ARG);
+            /* backward of the dense assembly: supported-set query + plan arithmetic, rejection before any launch */
+            size_t adj = banet_dense_adjoint_workspace_bytes(&lv);
+            EXPECT((adj > 0) == (Ks[k] >= 1 && Ks[k] <= 128 && pairs <= 1)); EXPECT(adj % 256 == 0);
+            EXPECT(banet_dense_adjoint_f32(&lv, dummy, dummy, dummy, dummy, dummy, dummy, dummy, dummy, dummy, dummy, dummy, dummy,
+                                           1u << 20, 0) == BANET_ERR_INVALID_ARG);   /* null level tensors */
+            EXPECT(banet_sample_stats_grad_workspace_bytes(B, 4096, lv.C, lv.H, lv.W) % 256 == 0);   /* 0 when B H W 3C >= 2^32 */
           }
   /* sparse (reference-layout) levels */
   for (int N = 1; N <= 8192; N = N * 3 + 1) {
@@ -78,6 +84,9 @@ int main(void) {
   EXPECT(banet_sample_stats_blocks(0) == 0 && banet_sample_stats_blocks(100000) > 0);
   EXPECT(banet_sample_stats_f32(0, 0, 0, 0, 1, 1, 1, 1, 1, 0, 0, 0) == BANET_ERR_INVALID_ARG);
   EXPECT(banet_sample_stats_grad_f32(0, 0, 0, 0, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0) == BANET_ERR_INVALID_ARG);
+  EXPECT(banet_sample_stats_grad_det_f32(0, 0, 0, 0, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0) == BANET_ERR_INVALID_ARG);
+  EXPECT(banet_target_map_adjoint_f32(0, 0, 1, 1, 1, 1, 0) == BANET_ERR_INVALID_ARG);
+  EXPECT(banet_dense_adjoint_workspace_bytes(0) == 0);
   EXPECT(banet_profile_begin(0) == BANET_ERR_INVALID_ARG);
   EXPECT(banet_profile_end(0, 0, 0, 0, 0) == BANET_ERR_INVALID_ARG);
   printf("asan/ubsan driver: %d checks passed, no sanitizer report\n", checks);
