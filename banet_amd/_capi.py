@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbanet_hip.so")
+# BANET_HIP_LIB: development override (same-box A/B of two builds of the library, tools/ab_builds.sh); the in-tree build otherwise
+LIB_PATH = os.environ.get("BANET_HIP_LIB") or os.path.join(_HERE, "lib", "libbanet_hip.so")
 
 LEGACY_LM, LEGACY_FIXED, BUNDLE_CAMERA, BUNDLE = 0, 1, 2, 3
 

@@ -82,9 +82,13 @@ __device__ __forceinline__ void tap_math_p(const float4& f1, const float4& a0, c
 // US = steps (of 4 pixels) per unit: 2 = a 4x2 pixel block, box <= 36 texels, 9 + 2 loads per lane in flight (the product
 // kernel of round 1); 4 = a 4x4 block, box <= 52 texels, 13 + 4 loads: half as many load -> LDS -> tap latency events per
 // tile, 3.06 instead of 4.4 box texels per pixel through the L1.
-template <int KV4, int US>
+// FS = fixed-stride patch: the box is stored with a row stride of 8 texels (boxes up to 8 x 5) and fetched with buffer loads --
+// per-lane column offsets (2 per unit half) in voffset, the row offsets in the scalar offset: no per-load address arithmetic
+// (the packed layout costs 8 VALU instructions of row / column bookkeeping and 64-bit address maths per load, 96 per unit half),
+// and the tap rows of the patch sit at compile-time distances.
+template <int KV4, int US, bool FS>
 __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kernel(const GatherArgs a) {
-  constexpr int PT = US == 2 ? kPatchTexels : 52, NL = (PT + 3) / 4, GL = 4 * US;   // patch texels, box loads per lane, lanes per unit
+  constexpr int PT = FS ? 40 : (US == 2 ? kPatchTexels : 52), NL = (PT + 3) / 4, GL = 4 * US;   // patch texels, box loads per lane, lanes per unit
   __shared__ __attribute__((aligned(16))) float sPar[kNumWaves][64][kParStrideP];
   __shared__ float sQ[kNumWaves][64][5];
   __shared__ float sAbs[kNumWaves][kC128p];
@@ -210,9 +214,10 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
     const float* __restrict__ tgt_b = lv.tgt + (size_t)vb * H * W * C;
     float* __restrict__ rec_b = KV4 ? a.rec + (size_t)vb * N * 8 : nullptr;
     float* __restrict__ part_b = a.partials + (size_t)vb * nitems * (kGHdr + C);
-    float absd8[8];   // |d| of channels {4 sub + e, 64 + 4 sub + e} over this lane group's pixels
-#pragma unroll
-    for (int i = 0; i < 8; ++i) absd8[i] = 0.f;
+    // |d| of channels {4 sub + e} (absA) and {64 + 4 sub + e} (absB) over this lane group's pixels.  Two arrays that trade places
+    // after every channel half instead of one array indexed by the (rolled) half loop: `absd8[4 * h + e]` with a run-time h cost
+    // 15 v_cndmask per accumulation (8-way select on read and on write), 116 of the 259 VALU instructions of a unit half.
+    float absA[4] = {0.f, 0.f, 0.f, 0.f}, absB[4] = {0.f, 0.f, 0.f, 0.f};
     float absd2[1][2] = {{0.f, 0.f}};  // rim pixels (generic routine: channels 2 lane, 2 lane + 1)
 
     // ---- 2. geometry, lane = pixel -------------------------------------------------------
@@ -324,8 +329,8 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
         const int bx0 = red8(fast ? x0 : big, false), bx1 = red8(fast ? x0 : -big, true);
         const int by0 = red8(fast ? y0 : big, false), by1 = red8(fast ? y0 : -big, true);
         const int x_lo = bx0 - 1, y_lo = by0 - 1, pw = bx1 - bx0 + 4, ph = by1 - by0 + 4;
-        const bool st = bx1 >= bx0 && pw * ph <= PT && !(lv.reserved_ & 128);
-        pb.w = __int_as_float(((fast ? y0 - y_lo : 1) * pw + (fast ? x0 - x_lo : 1)) * 64);
+        const bool st = bx1 >= bx0 && (FS ? (pw <= 8 && ph <= 5) : pw * ph <= PT) && !(lv.reserved_ & 128);
+        pb.w = __int_as_float(((fast ? y0 - y_lo : 1) * (FS ? 8 : pw) + (fast ? x0 - x_lo : 1)) * 64);
         if ((lane & (GL - 1)) == 0) {
           sGrp[w][lane / GL][0] = st ? (y_lo * W + x_lo) * C : 0;
           sGrp[w][lane / GL][1] = st ? pw : 0;
@@ -345,25 +350,44 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
     const int rowC = W * C;
     f32x4 pst[NL], pf1[US];
     bool pre = false;
+    // buffer resources of this virtual window's target map and this window's source map (wave-uniform)
+    [[maybe_unused]] const auto rs_tgt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tgt_b), 0, H * W * C * 4, 0x00020000);
+    [[maybe_unused]] const auto rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src_b), 0, N * C * 4, 0x00020000);
     auto issue = [&](int sp_, int h_) __attribute__((always_inline)) {
       const int gb = rfl(sGrp[w][sp_][0]), pw_ = rfl(sGrp[w][sp_][1]), ph_ = rfl(sGrp[w][sp_][3]);
-      int row = 0, col = lane >> 4;                       // texel (lane >> 4) + 4 i of the box, pw_ >= 4
+      if constexpr (FS) {
+        const int qc = lane >> 4;
+        const unsigned c0 = (unsigned)(min(qc, pw_ - 1) * (C * 4) + 16 * sub), c1 = (unsigned)(min(qc + 4, pw_ - 1) * (C * 4) + 16 * sub);
+        const int sbase = gb * 4 + 256 * h_;
 #pragma unroll
-      for (int i = 0; i < NL; ++i) {
-        unsigned off = (unsigned)gb + (unsigned)((min(row, ph_ - 1) * W + col) * C) + 4u * (unsigned)sub + 64u * (unsigned)h_;
-        if (abl & 1) off = 4u * (unsigned)sub + 64u * (unsigned)h_ + (unsigned)((lane >> 4) * C);   // every box = texels 0..3
-        pst[i] = *reinterpret_cast<const f32x4*>(tgt_b + (size_t)off);
-        col += 4;
-        if (col >= pw_) {
-          col -= pw_;
-          row += 1;
+        for (int i = 0; i < NL; ++i) {
+          const int srow = sbase + min(i >> 1, ph_ - 1) * (W * C * 4);     // scalar
+          pst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_tgt, (i & 1) ? c1 : c0, srow, 0));
         }
-      }
 #pragma unroll
-      for (int t = 0; t < US; ++t) {
-        unsigned osrc = (unsigned)__float_as_int(sPar[w][4 * (US * sp_ + t) + grp][0]);
-        if (abl & 2) osrc = (unsigned)(grp * C);                                                        // every source row = pixels 0..3
-        pf1[t] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src_b + (size_t)(osrc + 64u * (unsigned)h_ + 4u * sub)));
+        for (int t = 0; t < US; ++t) {
+          const unsigned osrc = (unsigned)__float_as_int(sPar[w][4 * (US * sp_ + t) + grp][0]);
+          pf1[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, osrc * 4u + 16u * (unsigned)sub, 256 * h_, 2));
+        }
+      } else {
+        int row = 0, col = lane >> 4;                       // texel (lane >> 4) + 4 i of the box, pw_ >= 4
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+          unsigned off = (unsigned)gb + (unsigned)((min(row, ph_ - 1) * W + col) * C) + 4u * (unsigned)sub + 64u * (unsigned)h_;
+          if (abl & 1) off = 4u * (unsigned)sub + 64u * (unsigned)h_ + (unsigned)((lane >> 4) * C);   // every box = texels 0..3
+          pst[i] = *reinterpret_cast<const f32x4*>(tgt_b + (size_t)off);
+          col += 4;
+          if (col >= pw_) {
+            col -= pw_;
+            row += 1;
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < US; ++t) {
+          unsigned osrc = (unsigned)__float_as_int(sPar[w][4 * (US * sp_ + t) + grp][0]);
+          if (abl & 2) osrc = (unsigned)(grp * C);                                                        // every source row = pixels 0..3
+          pf1[t] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src_b + (size_t)(osrc + 64u * (unsigned)h_ + 4u * sub)));
+        }
       }
     };
     const int sp_end = s_hi / US;
@@ -389,7 +413,7 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
             pre = nsp < sp_end && rfl(sGrp[w][nsp][2]) > 0;
             if (pre) issue(nsp, nh);
           }
-          const int rs = pw * 64;
+          const int rs = FS ? 8 * 64 : pw * 64;
           if (!(abl & 8))
 #pragma unroll
           for (int t = 0; t < US; ++t) {
@@ -404,7 +428,13 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
                          b2 = *reinterpret_cast<const float4*>(l + rs + 64), b3 = *reinterpret_cast<const float4*>(l + rs + 128);
             const float4 m1 = *reinterpret_cast<const float4*>(l - rs), m2 = *reinterpret_cast<const float4*>(l - rs + 64);
             const float4 p1 = *reinterpret_cast<const float4*>(l + 2 * rs), p2 = *reinterpret_cast<const float4*>(l + 2 * rs + 64);
-            tap_math_p(f1, a0, a1, a2, a3, b0, b1, b2, b3, m1, m2, p1, p2, pa.z, pa.w, pb.x, pb.y, pb.z, qa2[t], &absd8[4 * h]);
+            tap_math_p(f1, a0, a1, a2, a3, b0, b1, b2, b3, m1, m2, p1, p2, pa.z, pa.w, pb.x, pb.y, pb.z, qa2[t], absA);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {   // half h done: the other half's accumulators become current (two swaps = identity)
+            const float tmp = absA[e];
+            absA[e] = absB[e];
+            absB[e] = tmp;
           }
         }
       } else {
@@ -429,7 +459,7 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
                          b2 = *reinterpret_cast<const float4*>(rb + C), b3 = *reinterpret_cast<const float4*>(rb + 2 * C);
             const float4 m1 = *reinterpret_cast<const float4*>(rm), m2 = *reinterpret_cast<const float4*>(rm + C);
             const float4 p1 = *reinterpret_cast<const float4*>(rp), p2 = *reinterpret_cast<const float4*>(rp + C);
-            tap_math_p(f1, a0, a1, a2, a3, b0, b1, b2, b3, m1, m2, p1, p2, pa.z, pa.w, pb.x, pb.y, pb.z, qa2[t], &absd8[4 * h]);
+            tap_math_p(f1, a0, a1, a2, a3, b0, b1, b2, b3, m1, m2, p1, p2, pa.z, pa.w, pb.x, pb.y, pb.z, qa2[t], h ? absB : absA);
           }
         }
       }
@@ -533,7 +563,7 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
     // ---- 5. the tile's C x sum|d| ------------------------------------------------------------
 #pragma unroll
     for (int i = 0; i < 8; ++i) {  // fold the 4 pixel groups (fixed order), group 0 publishes
-      float v = absd8[i];
+      float v = i < 4 ? absA[i] : absB[i - 4];
       v += __shfl_xor(v, 16, 64);
       v += __shfl_xor(v, 32, 64);
       if (grp == 0) sAbs[w][(i >> 2) * 64 + 4 * sub + (i & 3)] = v;
@@ -555,19 +585,23 @@ int launch_gather128p(const GatherArgs& a, int K, hipStream_t s) {
     dyn = 60 * 1024;
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_gather128p_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_gather128p_kernel<1, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
       attr_set = true;
     }
   }
-  const bool u4 = (a.lv.reserved_ & 16384) != 0;   // bit 14: 4-step units (A/B)
+  const bool u4 = (a.lv.reserved_ & 16384) != 0;   // bit 14: 4-step units (A/B, experiments/README.md)
+  const bool packed = (a.lv.reserved_ & 65536) != 0;   // bit 16: the packed patch with flat loads (A/B)
+  const bool small = (size_t)a.lv.H * a.lv.W * a.lv.C * 4 < ((size_t)1 << 31) && (size_t)a.lv.N * a.lv.C * 4 < ((size_t)1 << 31);
   if (K == 0)
-    hipLaunchKernelGGL((ba_gather128p_kernel<0, 2>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((ba_gather128p_kernel<0, 2, false>), grid, block, 0, s, a);
   else if ((K & 3) == 0 && K <= 128 && u4)
-    hipLaunchKernelGGL((ba_gather128p_kernel<1, 4>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((ba_gather128p_kernel<1, 4, false>), grid, block, 0, s, a);
+  else if ((K & 3) == 0 && K <= 128 && (packed || !small || dyn))
+    hipLaunchKernelGGL((ba_gather128p_kernel<1, 2, false>), grid, block, dyn, s, a);
   else if ((K & 3) == 0 && K <= 128)
-    hipLaunchKernelGGL((ba_gather128p_kernel<1, 2>), grid, block, dyn, s, a);
+    hipLaunchKernelGGL((ba_gather128p_kernel<1, 2, true>), grid, block, 0, s, a);
   else if ((K & 3) == 0 && K <= 256)
-    hipLaunchKernelGGL((ba_gather128p_kernel<2, 2>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((ba_gather128p_kernel<2, 2, false>), grid, block, 0, s, a);
   else
     return BANET_ERR_UNSUPPORTED;
   return BANET_OK;
