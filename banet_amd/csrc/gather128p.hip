@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
           const bool ok = k < K;
           const f32x4 bv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row + (ok ? k : 0)));
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc = fmaf(ok ? bv[e] : 0.f, wreg[kc][e], acc);
+          for (int e = 0; e < 4; ++e) acc = fmaf(bv[e], wreg[kc][e], acc);   // k >= K: the address is clamped to the row's own first quad and wreg is 0
         }
         part[i] = acc;
       }

@@ -35,9 +35,9 @@ for rnd in range(ROUNDS):                      # round-robin over the configurat
         for _ in range(2):
             ops.ba_assemble(p, R, T, Wc if K else None)
         torch.cuda.synchronize()
-        ops.profile_begin(64)
+        ops.profile_begin(4 * int(os.environ.get("PN", "5")) + 64)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n = 5
+        n = int(os.environ.get("PN", "5"))   # launches per timed burst (PN=50: sustained load, power-limited clocks)
         e0.record()
         for _ in range(n):
             ops.ba_assemble(p, R, T, Wc if K else None)
