@@ -391,7 +391,12 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
       }
     };
     const int sp_end = s_hi / US;
-    for (int sp = s_lo / US; sp < sp_end; ++sp) {
+    // unit order: 0..7 = left / right unit of pixel rows 0-1, 2-3, ... (Z order); reserved_ bit 17 (experiment, US = 2 only):
+    // the left column top to bottom, then the right column bottom to top -- horizontal neighbours 1..7 units apart instead of 1
+    const bool colmajor = US == 2 && (lv.reserved_ & 131072) != 0;
+    auto unit_at = [&](int it) { return colmajor ? (it < 4 ? 2 * it : 2 * (7 - it) + 1) : it; };
+    for (int it = s_lo / US; it < sp_end; ++it) {
+      const int sp = unit_at(it);
       const int pw = rfl(sGrp[w][sp][1]), ntex = rfl(sGrp[w][sp][2]);
       float qa2[US][5];
 #pragma unroll
@@ -409,7 +414,7 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
 #pragma unroll
           for (int t = 0; t < US; ++t) f1v[t] = pf1[t];
           {   // prefetch the next staged unit
-            const int nsp = h ? sp + 1 : sp, nh = h ^ 1;
+            const int nh = h ^ 1, nsp = h ? (it + 1 < sp_end ? unit_at(it + 1) : sp_end) : sp;
             pre = nsp < sp_end && rfl(sGrp[w][nsp][2]) > 0;
             if (pre) issue(nsp, nh);
           }
