@@ -122,7 +122,7 @@ def roofline_record(prob, prof, elapsed_s, traffic=None):
             rec["level_ms_last_step"] = round(ms, 3)
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "kernel": "ba_gather128p_kernel<1> (large levels) + ba_gather128_kernel<1> (small levels)",
+            "kernel": "ba_gather128p_kernel<1, 2, true> (large levels) + ba_gather128_kernel<1> (small levels)",
             "launches": nlaunch, "avg_launch_us": round(1e3 * kern_ms / max(nlaunch, 1), 2),
             "algorithmic_bytes_per_launch": round(alg_bytes / max(nlaunch, 1)),
             "kernel_time_share": round(kern_ms / (1e3 * elapsed_s), 4),
