@@ -305,6 +305,11 @@ int banet_sample_stats_grad_f32(const float* conv1, const float* conv2, const fl
                                   static_cast<hipStream_t>(stream));
 }
 
+int banet_spd_solve_f32(const float* A, const float* rhs, float* x, int B, int P, banet_stream_t stream) {
+  if (!A || !rhs || !x || B <= 0 || P <= 0) return BANET_ERR_INVALID_ARG;
+  return launch_spd_solve(A, rhs, x, B, P, static_cast<hipStream_t>(stream));
+}
+
 size_t banet_sample_stats_grad_workspace_bytes(int B, int N, int C, int H, int W) {
   if (!sstats_shape_ok(B, N, C, H, W)) return 0;
   return sample_stats_grad_det_workspace_bytes(B, N, C, H, W);

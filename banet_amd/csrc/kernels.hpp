@@ -134,6 +134,7 @@ struct SolveArgs {
   banet_lm_params_t lm;   // run-time LM configuration (legacy/ba.py:5-9)
 };
 int launch_solve(const SolveArgs& a, hipStream_t s);
+int launch_spd_solve(const float* A, const float* rhs, float* x, int B, int P, hipStream_t s);   // 32 <= P, matrix in LDS
 size_t solve_big_bytes(int B, int P, int C);
 void launch_ctl_init(LmCtl* ctl, int32_t* iters, int B, hipStream_t s);
 void launch_zero_iters(int32_t* iters, int B, hipStream_t s);

@@ -741,6 +741,46 @@ int launch_solve(const SolveArgs& a, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;
 }
 
+// --------------------------------------------------------------------------------------
+// banet_spd_solve_f32: x = A^-1 b for B symmetric positive definite systems (32 <= P <= ~190), the blocked LDL^T of the
+// update kernel as an op of its own.  Used by the backward of the dense layer (banet_amd/dense_train.py): the forward
+// solution of the damped system is recomputed and the implicit-function gradient lam = A^-T g is a second call with the
+// same matrix -- torch.linalg.solve costs ~2 ms per iteration there (rocSOLVER getrf + per-item trsv launches).
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kSolveThreads) void spd_solve_kernel(const float* __restrict__ A, const float* __restrict__ rhs,
+                                                                  float* __restrict__ x, int P) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int ld = ldlt_ld(P);
+  float* sA = smem;                                   // [(P + 4)][ld], right-hand side as row P
+  float* sX = sA + (((P + 4) * ld + 3) & ~3);         // [P + 8]
+  float* sScr = sX + ((P + 8 + 3) & ~3);              // [solve_scratch_floats(P)]
+  const float* A_g = A + (size_t)b * P * P;
+  for (int e = tid; e < P * P; e += kSolveThreads) {
+    const int i = e / P, j = e - i * P;
+    sA[i * ld + j] = A_g[e];
+  }
+  for (int i = tid; i < P; i += kSolveThreads) sA[P * ld + i] = rhs[(size_t)b * P + i];
+  __syncthreads();
+  ldlt_solve_blocked(smem, ld, P, sX, sScr);
+  for (int k = tid; k < P; k += kSolveThreads) x[(size_t)b * P + k] = sX[k];
+}
+
+static size_t spd_solve_lds_bytes(int P) {
+  const size_t fl = (size_t)(((P + 4) * ldlt_ld(P) + 3) & ~3) + ((P + 8 + 3) & ~3) + (size_t)solve_scratch_floats(P);
+  return fl * sizeof(float);
+}
+
+int launch_spd_solve(const float* A, const float* rhs, float* x, int B, int P, hipStream_t s) {
+  if (P < kGrid) return BANET_ERR_UNSUPPORTED;                 // the blocked factorisation wants at least two panels
+  const size_t lds = spd_solve_lds_bytes(P);
+  if (lds > 160 * 1024) return BANET_ERR_UNSUPPORTED;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)spd_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(spd_solve_kernel, dim3(B), dim3(kSolveThreads), lds, s, A, rhs, x, P);
+  return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;
+}
+
 void launch_ctl_init(LmCtl* ctl, int32_t* iters, int B, hipStream_t s) {
   hipLaunchKernelGGL(lm_ctl_init_kernel, dim3((B + 63) / 64), dim3(64), 0, s, ctl, iters, B);
 }

@@ -23,6 +23,11 @@ from . import ops
 from .bundlenet import AngleaAxisRotation, VMatrix
 
 
+import os as _os
+
+USE_SPD_SOLVE = _os.environ.get("BANET_SPD_SOLVE", "1") != "0"   # backward: the damped SPD system on banet_spd_solve_f32 (0: torch.linalg.solve_ex, A/B)
+
+
 def _to_param(t, dev):
     return t.to(dev) if torch.is_tensor(t) else torch.as_tensor(t, dtype=torch.float32, device=dev)
 
@@ -48,6 +53,32 @@ def solve_update_graph(AtA, Atb, absres, N, R, T, Wc, layers, l2_base, solve=tor
     return torch.matmul(dr, R), torch.matmul(dv, sol[:, 3:6]) + torch.matmul(dr, T), Wc + sol[:, 6:]
 
 
+def spd_solve(A, b):
+    """banet_spd_solve_f32: x [B,P,1] = A^-1 b for symmetric positive definite A [B,P,P] (blocked LDL^T in LDS, P >= 32)."""
+    A, b = capi.f32c(A), capi.f32c(b)
+    B, P = A.shape[0], A.shape[1]
+    x = torch.empty((B, P, 1), dtype=torch.float32, device=A.device)
+    capi.check(capi.lib().banet_spd_solve_f32(capi.ptr(A), capi.ptr(b), capi.ptr(x), B, P, capi.stream()))
+    return x
+
+
+class _SolveSPD(torch.autograd.Function):
+    """x = A^-1 b for the damped normal matrix (symmetric positive definite) on the library's LDL^T kernel; backward = the
+    implicit-function gradient with the same kernel: lam = A^-1 g (A = A^T), dA = -lam x^T, db = lam."""
+
+    @staticmethod
+    def forward(ctx, A, b):
+        x = spd_solve(A, b)
+        ctx.save_for_backward(A, x)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        A, x = ctx.saved_tensors
+        lam = spd_solve(A, g)
+        return -torch.matmul(lam, x.transpose(-1, -2)), lam
+
+
 class _SolveNoCheck(torch.autograd.Function):
     """x = A^-1 b without the host-side `info` check of torch.linalg.solve (a device->host sync per call, and illegal inside
     a captured graph); backward = the implicit-function gradient: lam = A^-T g, dA = -lam x^T, db = lam."""
@@ -71,7 +102,8 @@ def _small_grads(AtA, Atb, absres, R, T, Wc, gR, gT, gW, flat, N, l2_base):
         leaves = [t.detach().requires_grad_(True) for t in (AtA, Atb, absres, R, T, Wc)]
         lw = [t.detach().requires_grad_(True) for t in flat]
         R2, T2, W2 = solve_update_graph(leaves[0], leaves[1], leaves[2], N, leaves[3], leaves[4], leaves[5],
-                                        [(lw[2 * i], lw[2 * i + 1]) for i in range(5)], l2_base, solve=_SolveNoCheck.apply)
+                                        [(lw[2 * i], lw[2 * i + 1]) for i in range(5)], l2_base,
+                                        solve=_SolveSPD.apply if (AtA.is_cuda and AtA.shape[-1] >= 32 and USE_SPD_SOLVE) else _SolveNoCheck.apply)
         grads = torch.autograd.grad([R2, T2, W2], leaves + lw, [gR, gT, gW], allow_unused=True)
     return [g if g is not None else torch.zeros_like(t) for g, t in zip(grads, leaves + lw)]
 
@@ -86,7 +118,12 @@ class _SmallStepGraph:
         self.N, self.l2 = N, l2_base
         self.inp = [torch.zeros(s, dtype=torch.float32, device=dev) for s in shapes]
         self.graph, self.out, self.error = None, None, None
-        if os.environ.get("BANET_TRAIN_GRAPH", "1") == "0":
+        mode = os.environ.get("BANET_TRAIN_GRAPH", "1")
+        # Captured for small batches only: there the ~150 small launches are CPU-bound (2 windows: 37.6 -> 27.3 ms per training
+        # step); at 8 windows eager and replayed run the same, and at 32 windows replaying the graph between the large adjoint
+        # kernels was pathologically slow on ROCm 7.2 (192 -> 370-510 ms per step, cause not found) -- BANET_TRAIN_GRAPH=2 forces it.
+        if mode == "0" or (shapes[0][0] > 8 and mode != "2"):
+            self.error = "disabled" if mode == "0" else "batch > 8"
             return
         for t in self.inp[3:4]:
             t.copy_(torch.eye(3, device=dev).expand_as(t))          # a valid rotation / SPD system for the warm-up
@@ -124,7 +161,7 @@ _small_cache = {}
 
 def small_step_modes():
     """{shape key: "graph" | "eager (<reason>)"} of the small backward steps built so far (diagnostics / benchmarks)."""
-    return {str(k[0][0]): ("graph" if v.graph is not None else "eager (%s)" % (v.error or "disabled")) for k, v in _small_cache.items()}
+    return {str(k[0][0]): ("graph" if v.graph is not None else "eager (%s)" % (v.error or "capture failed")) for k, v in _small_cache.items()}
 
 
 def _small_step(tensors, N, l2_base):

@@ -260,6 +260,11 @@ int banet_sample_stats_grad_det_f32(const float* conv1, const float* conv2, cons
  *   banet_target_map_adjoint_f32: dimg [B,H,W,C] += dmap3_f + grad_fixed^T (dmap3_gx, dmap3_gy) -- the adjoint of
  *     banet_target_map_f32 (REFLECT rim: zero gradient on the 1-px border, bundlenet.py:92-100); once per level.      */
 size_t banet_dense_adjoint_workspace_bytes(const banet_level_t* lv);
+/*   banet_spd_solve_f32: x [B,P] = A^-1 rhs for B symmetric positive definite systems A [B,P,P] (the blocked LDL^T of (4) as an op
+ *     of its own; the matrix must fit the LDS: 32 <= P <= ~190, else BANET_ERR_UNSUPPORTED).  The backward of the layer calls it
+ *     twice per iteration -- the damped system of bundlenet.py:264-267 again, then lam = A^-T g for the implicit-function gradient
+ *     of tf.matrix_solve (dA = -lam x^T, db = lam).                                                                      */
+int banet_spd_solve_f32(const float* A, const float* rhs, float* x, int B, int P, banet_stream_t stream);
 int banet_dense_adjoint_f32(const banet_level_t* lv, const float* R, const float* T, const float* Wc, const float* gAtA,
                             const float* gAtb, const float* gabs, float* dsrc, float* dmap3, float* ddepth,
                             float* dbasis, float* dpose, void* ws, size_t ws_bytes, banet_stream_t stream);

@@ -221,3 +221,18 @@ def test_dense_adjoint_with_most_pixels_outside_the_image_and_an_empty_window():
         assert np.abs(g - w).max() <= 2e-4 * max(np.abs(w).max(), 1e-30), name
         assert np.abs(g[1]).max() == 0.0, name
     assert np.isfinite(n(got["dpose"])).all() and np.abs(n(got["dpose"])[1]).max() == 0.0
+
+
+@pytest.mark.parametrize("B,P", [(3, 38), (8, 134), (2, 150), (1, 32)])
+def test_spd_solve_matches_float64(B, P):
+    """banet_spd_solve_f32 (the blocked LDL^T of the update kernel as an op): the backward's two solves per iteration."""
+    from banet_amd import dense_train
+    g = torch.Generator().manual_seed(P)
+    M = torch.randn(B, P, P + 20, generator=g, dtype=torch.float64)
+    A = M @ M.transpose(1, 2) + 0.5 * torch.eye(P, dtype=torch.float64)
+    b = torch.randn(B, P, 1, generator=g, dtype=torch.float64)
+    want = torch.linalg.solve(A, b)
+    got = dense_train.spd_solve(A.float().to(DEV), b.float().to(DEV)).double().cpu()
+    assert float((got - want).abs().max()) <= 2e-4 * float(want.abs().max())
+    with pytest.raises(Exception):
+        dense_train.spd_solve(torch.eye(8, device=DEV)[None], torch.ones(1, 8, 1, device=DEV))       # P < 32: unsupported, loudly
