@@ -227,3 +227,6 @@ def test_backward_entry_points_validate_their_arguments_without_gpu(capi):
     assert L.banet_sample_stats_grad_workspace_bytes(2, 1000, 128, 48, 64) > 0
     assert L.banet_sample_stats_grad_workspace_bytes(2, 1000, 257, 48, 64) == 0              # C > 256
     assert L.banet_sample_stats_grad_det_f32(*([None] * 4), 2, 1000, 128, 48, 64, *([None] * 5), None, 0, None) == -1
+    assert L.banet_spd_solve_f32(None, None, None, 1, 134, None) == -1
+    buf = ctypes.c_void_p(4096)                                                                    # never dereferenced: rejected on the host
+    assert L.banet_spd_solve_f32(buf, buf, buf, 1, 8, None) == -3 and L.banet_spd_solve_f32(buf, buf, buf, 1, 400, None) == -3

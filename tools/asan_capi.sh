@@ -87,6 +87,10 @@ int main(void) {
   EXPECT(banet_sample_stats_grad_det_f32(0, 0, 0, 0, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0) == BANET_ERR_INVALID_ARG);
   EXPECT(banet_target_map_adjoint_f32(0, 0, 1, 1, 1, 1, 0) == BANET_ERR_INVALID_ARG);
   EXPECT(banet_dense_adjoint_workspace_bytes(0) == 0);
+  EXPECT(banet_spd_solve_f32(0, 0, 0, 1, 134, 0) == BANET_ERR_INVALID_ARG);
+  EXPECT(banet_spd_solve_f32(dummy, dummy, dummy, 0, 134, 0) == BANET_ERR_INVALID_ARG);
+  EXPECT(banet_spd_solve_f32(dummy, dummy, dummy, 1, 8, 0) == BANET_ERR_UNSUPPORTED);      /* below two panels */
+  EXPECT(banet_spd_solve_f32(dummy, dummy, dummy, 1, 400, 0) == BANET_ERR_UNSUPPORTED);    /* matrix does not fit the LDS */
   EXPECT(banet_profile_begin(0) == BANET_ERR_INVALID_ARG);
   EXPECT(banet_profile_end(0, 0, 0, 0, 0) == BANET_ERR_INVALID_ARG);
   printf("asan/ubsan driver: %d checks passed, no sanitizer report\n", checks);
