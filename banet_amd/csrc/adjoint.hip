@@ -457,6 +457,335 @@ __global__ __launch_bounds__(kBlock, 3) void adj_pixel_kernel(const AdjArgs a) {
   }
 }
 
+// ---- per-pixel adjoint, two pixels per wave -------------------------------------------------------------------------------
+// Same arithmetic as adj_pixel_kernel with a HALF wave per pixel (lanes 0-31: pixel n, lanes 32-63: pixel n + 1) and 4
+// channels / coefficients per lane: every row access is one 16-byte load or store per lane, the per-pixel algebra is done once
+// per pair of pixels instead of once per pixel, and the eight reductions per pixel run over 32 lanes (DPP row sum + one
+// permlane swap).  C % 4 == 0, C <= 128 CJ4, K % 4 == 0, K <= 128.  Pixels outside the image take safe coordinates and skip
+// their stores (the two halves of a wave diverge, so there is no early exit).
+__device__ __forceinline__ float hsum(float v) {   // sum over the 32 lanes of each half wave, every lane gets its half's total
+  v = row16_sum(v);
+  return bfly_merge(v, v, 16);
+}
+
+template <int CJ4>
+__global__ __launch_bounds__(kBlock, 2) void adj_pixel2_kernel(const AdjArgs a) {
+  const banet_level_t& lv = a.lv;
+  const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x & 63, w = wave_id();
+  const int N = lv.N, C = lv.C, K = lv.K, H = lv.H, W = lv.W, P = 6 + K;
+  const int hl = lane & 31, hi = lane >> 5;
+  const float* __restrict__ src_b = lv.src + (size_t)b * N * C;
+  const float* __restrict__ tgt_b = lv.tgt + (size_t)b * N * C;
+  const float* __restrict__ bas_b = lv.basis + (size_t)b * N * K;
+  const float* __restrict__ S = a.S + (size_t)b * P * P;
+  const float* __restrict__ gb = a.gb + (size_t)b * P;
+  float Scc[6][6], gbc[6], Rm[9], Tv[3];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    gbc[i] = gb[i];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) Scc[i][j] = S[i * P + j];
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Rm[i] = a.R[b * 9 + i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) Tv[i] = a.T[b * 3 + i];
+  const float fx0 = lv.intr[b * 4 + 0], fy0 = lv.intr[b * 4 + 1], ox0 = lv.intr[b * 4 + 2], oy0 = lv.intr[b * 4 + 3];
+  const float fx = fx0 / lv.scale, fy = fy0 / lv.scale, ox = ox0 / lv.scale, oy = oy0 / lv.scale;
+  // this lane's 4 depth coefficients (k = 4 hl .. 4 hl + 3) and channel quads (c = 4 hl + 128 j)
+  const int k0 = 4 * hl;
+  const bool kok = k0 < K;
+  f32x4 wc = {0.f, 0.f, 0.f, 0.f}, gbd = {0.f, 0.f, 0.f, 0.f}, dwc = {0.f, 0.f, 0.f, 0.f};
+  f32x4 scd[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) scd[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (kok) {
+    wc = *reinterpret_cast<const f32x4*>(a.Wc + (size_t)b * K + k0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gbd[e] = gb[6 + k0 + e];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) scd[i][e] = S[i * P + 6 + k0 + e];
+  }
+  bool cok[CJ4];
+  f32x4 ga[CJ4];
+#pragma unroll
+  for (int j = 0; j < CJ4; ++j) {
+    const int c = 4 * hl + 128 * j;
+    cok[j] = c < C;
+    ga[j] = cok[j] ? *reinterpret_cast<const f32x4*>(a.gabs + (size_t)b * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  float accR[9], accT[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) accR[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) accT[i] = 0.f;
+
+  const int nw = a.G * kNumWaves, chunk = ((N + nw - 1) / nw + 1) & ~1;   // even: the pairs of a wave never straddle two waves
+  const int n_lo = (g * kNumWaves + w) * chunk, n_hi = min(N, n_lo + chunk);
+  for (int n2 = n_lo; n2 < n_hi; n2 += 2) {
+    const int n = n2 + hi;
+    const bool live = n < n_hi;
+    const int nn = live ? n : n_hi - 1;                 // a dead upper half recomputes the lower pixel and stores nothing
+    const int qy = nn / W, qx = nn - qy * W;
+    float p0 = ((float)qx * lv.scale - ox0) / fx0, p1 = ((float)qy * lv.scale - oy0) / fy0, p2 = 1.f;
+    if (lv.normalize_rays) {
+      const float inv = 1.f / sqrtf(fmaxf(p0 * p0 + p1 * p1 + p2 * p2, 1e-12f));
+      p0 *= inv;
+      p1 *= inv;
+      p2 *= inv;
+    }
+    const size_t q = (size_t)b * N + nn;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f}, z2v = {0.f, 0.f, 0.f, 0.f};
+    if (kok) {
+      bv = *reinterpret_cast<const f32x4*>(bas_b + (size_t)nn * K + k0);
+      z2v = *reinterpret_cast<const f32x4*>(a.z2 + q * K + k0);
+    }
+    f32x4 f1v[CJ4];
+#pragma unroll
+    for (int j = 0; j < CJ4; ++j)
+      f1v[j] = cok[j] ? *reinterpret_cast<const f32x4*>(src_b + (size_t)nn * C + 4 * hl + 128 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* __restrict__ ar = a.arec + q * 8;
+    const f32x4 ar0 = *reinterpret_cast<const f32x4*>(ar), ar1 = *reinterpret_cast<const f32x4*>(ar + 4);
+    const float qv[6] = {ar0[0], ar0[1], ar0[2], ar0[3], ar1[0], ar1[1]};
+    const float zeta = ar1[2], ee = ar1[3];
+    const float D = lv.depth[q] + hsum(bv[0] * wc[0] + bv[1] * wc[1] + bv[2] * wc[2] + bv[3] * wc[3]);
+    const float rx = Rm[0] * p0 + Rm[1] * p1 + Rm[2] * p2;
+    const float ry = Rm[3] * p0 + Rm[4] * p1 + Rm[5] * p2;
+    const float rz = Rm[6] * p0 + Rm[7] * p1 + Rm[8] * p2;
+    const float X = rx * D + Tv[0], Y = ry * D + Tv[1], Z0 = rz * D + Tv[2];
+    float x = X / Z0, y = Y / Z0, Z = Z0;
+    float px = fx * x + ox, py = fy * y + oy;
+    const bool m = live && (px >= 0.f) && (px <= (float)(W - 1)) && (py >= 0.f) && (py <= (float)(H - 1));
+    if (!m) {            // safe stand-ins: everything below stays finite, nothing of it is stored
+      x = 0.f;
+      y = 0.f;
+      Z = 1.f;
+      px = 1.5f;
+      py = 1.5f;
+    }
+    const float xf = floorf(px), yf = floorf(py);
+    const int x0 = (int)xf, y0 = (int)yf;
+    const float ax = px - xf, ay = py - yf;
+    // ---- the 4x4 neighbourhood (minus corners), clamped: 12 row loads of 16 bytes per lane and channel chunk
+    f32x4 tex[CJ4][4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        if ((r == 0 || r == 3) && (cc == 0 || cc == 3)) continue;
+        const int yy = min(max(y0 - 1 + r, 0), H - 1), xx = min(max(x0 - 1 + cc, 0), W - 1);
+        const float* __restrict__ row = tgt_b + (size_t)(yy * W + xx) * C;
+#pragma unroll
+        for (int j = 0; j < CJ4; ++j) tex[j][r][cc] = *reinterpret_cast<const f32x4*>(row + (cok[j] ? 4 * hl + 128 * j : 0));
+      }
+    f32x4 Sf[CJ4], Sgx[CJ4], Sgy[CJ4], Ax[CJ4][3], Ay[CJ4][3];
+#pragma unroll
+    for (int j = 0; j < CJ4; ++j) {
+      Sf[j] = Sgx[j] = Sgy[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 3; ++e) Ax[j][e] = Ay[j][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int ix = t & 1, iy = t >> 1;
+      const int tx = x0 + ix, ty = y0 + iy;
+      const bool in = tx <= W - 1 && ty <= H - 1;
+      const float hx = (in && tx > 0 && tx < W - 1) ? 0.5f : 0.f, hy = (in && ty > 0 && ty < H - 1) ? 0.5f : 0.f;
+      const float fin = in ? 1.f : 0.f;
+      const float wx = ix ? ax : 1.f - ax, wy = iy ? ay : 1.f - ay;
+      const float wt = wx * wy, sx = (ix ? 1.f : -1.f) * wy, sy = (iy ? 1.f : -1.f) * wx;
+#pragma unroll
+      for (int j = 0; j < CJ4; ++j) {
+        const f32x4 F = fin * tex[j][1 + iy][1 + ix];
+        const f32x4 GX = hx * (tex[j][1 + iy][2 + ix] - tex[j][1 + iy][ix]);
+        const f32x4 GY = hy * (tex[j][2 + iy][1 + ix] - tex[j][iy][1 + ix]);
+        Sf[j] += wt * F;
+        Sgx[j] += wt * GX;
+        Sgy[j] += wt * GY;
+        Ax[j][0] += sx * F;
+        Ax[j][1] += sx * GX;
+        Ax[j][2] += sx * GY;
+        Ay[j][0] += sy * F;
+        Ay[j][1] += sy * GX;
+        Ay[j][2] += sy * GY;
+      }
+    }
+    f32x4 dif[CJ4];
+    float M11 = 0.f, M12 = 0.f, M22 = 0.f, g1 = 0.f, g2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < CJ4; ++j) {
+      if (!cok[j]) Sf[j] = Sgx[j] = Sgy[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dif[j] = f1v[j] - Sf[j];       // bundlenet.py:234
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        M11 = fmaf(Sgx[j][e], Sgx[j][e], M11);
+        M12 = fmaf(Sgx[j][e], Sgy[j][e], M12);
+        M22 = fmaf(Sgy[j][e], Sgy[j][e], M22);
+        g1 = fmaf(Sgx[j][e], dif[j][e], g1);
+        g2 = fmaf(Sgy[j][e], dif[j][e], g2);
+      }
+    }
+    M11 = hsum(M11);
+    M12 = hsum(M12);
+    M22 = hsum(M22);
+    g1 = hsum(g1);
+    g2 = hsum(g2);
+    // ---- per-pixel algebra (as adj_pixel_kernel)
+    const float iz = 1.f / Z;
+    float J0[6], J1[6];
+    J0[0] = fx * (-(x * y));
+    J0[1] = fx * (1.f + x * x);
+    J0[2] = fx * (-y);
+    J0[3] = fx * iz;
+    J0[4] = 0.f;
+    J0[5] = fx * (-(x * iz));
+    J1[0] = fy * (-1.f - y * y);
+    J1[1] = fy * (x * y);
+    J1[2] = fy * x;
+    J1[3] = 0.f;
+    J1[4] = fy * iz;
+    J1[5] = fy * (-(y * iz));
+    const float jd0 = fx * ((rx - rz * x) * iz), jd1 = fy * ((ry - rz * y) * iz);
+    float JS0[6], JS1[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float s0 = jd0 * qv[j], s1 = jd1 * qv[j];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        s0 = fmaf(J0[i], Scc[i][j], s0);
+        s1 = fmaf(J1[i], Scc[i][j], s1);
+      }
+      JS0[j] = s0;
+      JS1[j] = s1;
+    }
+    float t0 = jd0 * zeta, t1 = jd1 * zeta, dM11 = 0.f, dM12 = 0.f, dM22 = 0.f, dg1 = jd0 * ee, dg2 = jd1 * ee;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      t0 = fmaf(J0[i], qv[i], t0);
+      t1 = fmaf(J1[i], qv[i], t1);
+      dM11 = fmaf(JS0[i], J0[i], dM11);
+      dM12 = fmaf(JS0[i], J1[i], dM12);
+      dM22 = fmaf(JS1[i], J1[i], dM22);
+      dg1 = fmaf(J0[i], gbc[i], dg1);
+      dg2 = fmaf(J1[i], gbc[i], dg2);
+    }
+    dM11 = fmaf(t0, jd0, dM11);
+    dM12 = fmaf(t0, jd1, dM12);
+    dM22 = fmaf(t1, jd1, dM22);
+    float dJ0[6], dJ1[6], u[6];
+    const float Mjd0 = M11 * jd0 + M12 * jd1, Mjd1 = M12 * jd0 + M22 * jd1;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      dJ0[i] = 2.f * (M11 * JS0[i] + M12 * JS1[i]) + g1 * gbc[i];
+      dJ1[i] = 2.f * (M12 * JS0[i] + M22 * JS1[i]) + g2 * gbc[i];
+      u[i] = J0[i] * Mjd0 + J1[i] * Mjd1;
+    }
+    const float djd0 = 2.f * (M11 * t0 + M12 * t1) + g1 * ee, djd1 = 2.f * (M12 * t0 + M22 * t1) + g2 * ee;
+    const float s_n = jd0 * Mjd0 + jd1 * Mjd1, r_n = jd0 * g1 + jd1 * g2;
+    // ---- channel adjoints
+    float dpx = 0.f, dpy = 0.f;
+    float* __restrict__ dsrc_n = a.dsrc + q * C + 4 * hl;
+    float* __restrict__ arow_n = a.arow + q * 3 * C + 4 * hl;
+#pragma unroll
+    for (int j = 0; j < CJ4; ++j) {
+      if (cok[j]) {
+        f32x4 dd, dgx, dgy;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = dif[j][e], gx = Sgx[j][e], gy = Sgy[j][e];
+          const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+          dd[e] = dg1 * gx + dg2 * gy + sgn * ga[j][e];
+          dgx[e] = 2.f * (dM11 * gx + dM12 * gy) + dg1 * d;
+          dgy[e] = 2.f * (dM12 * gx + dM22 * gy) + dg2 * d;
+          dpx += -dd[e] * Ax[j][0][e] + dgx[e] * Ax[j][1][e] + dgy[e] * Ax[j][2][e];
+          dpy += -dd[e] * Ay[j][0][e] + dgx[e] * Ay[j][1][e] + dgy[e] * Ay[j][2][e];
+        }
+        if (m) {
+          f32x4* ds = reinterpret_cast<f32x4*>(dsrc_n + 128 * j);
+          *ds = *ds + dd;
+          *reinterpret_cast<f32x4*>(arow_n + 128 * j) = -dd;
+          *reinterpret_cast<f32x4*>(arow_n + C + 128 * j) = dgx;
+          *reinterpret_cast<f32x4*>(arow_n + 2 * C + 128 * j) = dgy;
+        }
+      }
+    }
+    dpx = hsum(dpx);
+    dpy = hsum(dpy);
+    // ---- geometry adjoint
+    float dx_ = fx * dpx + fx * (-y * dJ0[0] + 2.f * x * dJ0[1] - dJ0[5] * iz) + fy * (y * dJ1[1] + dJ1[2]);
+    float dy_ = fy * dpy + fx * (-x * dJ0[0] - dJ0[2]) + fy * (-2.f * y * dJ1[0] + x * dJ1[1] - dJ1[5] * iz);
+    float dZ_ = (fx * (-dJ0[3] + x * dJ0[5]) + fy * (-dJ1[4] + y * dJ1[5])) * iz * iz;
+    float drx = fx * djd0 * iz, dry = fy * djd1 * iz, drz = -(fx * x * djd0 + fy * y * djd1) * iz;
+    dx_ -= fx * rz * djd0 * iz;
+    dy_ -= fy * rz * djd1 * iz;
+    dZ_ -= (jd0 * djd0 + jd1 * djd1) * iz;
+    const float ms = m ? 1.f : 0.f;
+    const float dX = ms * dx_ * iz, dY = ms * dy_ * iz, dZt = ms * (dZ_ - (x * dx_ + y * dy_) * iz);
+    drx = fmaf(dX, D, ms * drx);
+    dry = fmaf(dY, D, ms * dry);
+    drz = fmaf(dZt, D, ms * drz);
+    const float dD = dX * rx + dY * ry + dZt * rz;
+    accT[0] += dX;
+    accT[1] += dY;
+    accT[2] += dZt;
+    accR[0] = fmaf(drx, p0, accR[0]);
+    accR[1] = fmaf(drx, p1, accR[1]);
+    accR[2] = fmaf(drx, p2, accR[2]);
+    accR[3] = fmaf(dry, p0, accR[3]);
+    accR[4] = fmaf(dry, p1, accR[4]);
+    accR[5] = fmaf(dry, p2, accR[5]);
+    accR[6] = fmaf(drz, p0, accR[6]);
+    accR[7] = fmaf(drz, p1, accR[7]);
+    accR[8] = fmaf(drz, p2, accR[8]);
+    // ---- depth, basis, coefficients
+    if (m && kok) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float su = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) su = fmaf(u[i], scd[i][e], su);
+        v[e] = fmaf(2.f, su, s_n * z2v[e] + r_n * gbd[e] + dD * wc[e]);
+        dwc[e] = fmaf(dD, bv[e], dwc[e]);
+      }
+      f32x4* db = reinterpret_cast<f32x4*>(a.dbasis + q * K + k0);
+      *db = *db + v;
+    }
+    if (hl == 0 && live) {
+      float* __restrict__ fr = a.frac + q * 4;
+      if (m) {
+        a.ddepth[q] += dD;
+        const int key = y0 * W + x0;
+        fr[0] = __int_as_float(key);
+        fr[1] = ax;
+        fr[2] = ay;
+        atomicAdd(&a.cnt[(size_t)b * H * W + key], 1);
+      } else {
+        fr[0] = __int_as_float(-1);
+      }
+    }
+  }
+  // the wave's partial row: lower half + upper half, fixed order
+  float* __restrict__ prow = a.part + ((size_t)b * a.G * kNumWaves + g * kNumWaves + w) * (kAdjHdr + K);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const float v = bfly_merge(accR[i], accR[i], 32);
+    if (lane == i) prow[i] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float v = bfly_merge(accT[i], accT[i], 32);
+    if (lane == 9 + i) prow[9 + i] = v;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float v = bfly_merge(dwc[e], dwc[e], 32);
+    if (hi == 0 && kok) prow[kAdjHdr + k0 + e] = v;
+  }
+}
+
 __global__ void adj_fold_kernel(const float* __restrict__ part, int rows, int K, float* __restrict__ dpose) {
   const int b = blockIdx.y, e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= 12 + K) return;
@@ -812,7 +1141,9 @@ int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T
     case 8: launch_adj_basis<8>(a, pl.Ga, s); break;
     default: return BANET_ERR_UNSUPPORTED;
   }
-  {
+  if ((lv->C & 3) == 0 && (K & 3) == 0 && lv->C <= 128 && K <= 128 && !(lv->reserved_ & 262144)) {   // bit 18: one pixel per wave (A/B)
+    hipLaunchKernelGGL((adj_pixel2_kernel<1>), dim3(pl.G, B), dim3(kBlock), 0, s, a);   // (C = 256: 264 B of spills -> the one-pixel kernel)
+  } else {
     const int CJ = (lv->C + 63) / 64, KJ = (K + 63) / 64;
     const dim3 grid(pl.G, B), block(kBlock);
 #define BANET_ADJ_PIXEL(cj, kj) \

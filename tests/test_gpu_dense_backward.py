@@ -56,7 +56,8 @@ def _run_adjoint(intr, lv, R, T, Wc, G, gb, gabs):
 
 
 @pytest.mark.parametrize("H,W,C,K,seed", [(24, 32, 6, 5, 3), (48, 64, 128, 128, 7), (30, 41, 70, 33, 11), (9, 11, 3, 1, 5),
-                                          (16, 16, 64, 16, 2), (17, 33, 130, 40, 9), (20, 24, 256, 64, 4)])
+                                          (16, 16, 64, 16, 2), (17, 33, 130, 40, 9), (20, 24, 256, 64, 4), (15, 21, 128, 128, 6),
+                                          (9, 7, 16, 8, 8)])
 def test_dense_adjoint_kernels_match_the_float64_statement(H, W, C, K, seed):
     intr, levels, R, T, Wc, rng = _scene(H, W, C, K, seed)
     lv = levels[0]
