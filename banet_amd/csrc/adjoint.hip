@@ -804,31 +804,87 @@ __global__ void adj_fold_kernel(const float* __restrict__ part, int rows, int K,
 }
 
 // ---- target cell lists ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kScanThreads) void adj_scan_kernel(const int* __restrict__ cnt, int* __restrict__ start,
-                                                                int* __restrict__ cursor, int HW) {
-  __shared__ int sSum[kScanThreads];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int chunk = (HW + kScanThreads - 1) / kScanThreads;
-  const int lo = min(HW, tid * chunk), hi = min(HW, lo + chunk);
+// Exclusive scan of the per-cell counts of every window, in three small launches (chunk sums -> scan of the chunk sums -> scan
+// inside the chunks): 1024 cells per 256-thread workgroup.  (A one-workgroup-per-window scan took 0.76 ms at 640x480.)
+constexpr int kScanChunk = 1024;
+
+__global__ __launch_bounds__(256) void adj_scan_sums_kernel(const int* __restrict__ cnt, int* __restrict__ chunk_sum, int HW, int nchunks) {
+  __shared__ int sRed[4];
+  const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
   const int* __restrict__ c = cnt + (size_t)b * HW;
   int s = 0;
-  for (int i = lo; i < hi; ++i) s += c[i];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int i = ch * kScanChunk + 4 * tid + e;
+    s += i < HW ? c[i] : 0;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+  if ((tid & 63) == 0) sRed[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) chunk_sum[(size_t)b * nchunks + ch] = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
+}
+
+__global__ __launch_bounds__(kScanThreads) void adj_scan_offsets_kernel(int* __restrict__ chunk_sum, int nchunks) {
+  __shared__ int sSum[kScanThreads];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  int* __restrict__ c = chunk_sum + (size_t)b * nchunks;
+  int carry = 0;
+  for (int base = 0; base < nchunks; base += kScanThreads) {     // in place: chunk sums -> exclusive offsets
+    const int i = base + tid;
+    const int v = i < nchunks ? c[i] : 0;
+    sSum[tid] = v;
+    __syncthreads();
+    for (int d = 1; d < kScanThreads; d <<= 1) {
+      const int t = tid >= d ? sSum[tid - d] : 0;
+      __syncthreads();
+      sSum[tid] += t;
+      __syncthreads();
+    }
+    if (i < nchunks) c[i] = carry + sSum[tid] - v;
+    carry += sSum[kScanThreads - 1];
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void adj_scan_apply_kernel(const int* __restrict__ cnt, const int* __restrict__ chunk_off,
+                                                             int* __restrict__ start, int* __restrict__ cursor, int HW, int nchunks) {
+  __shared__ int sSum[256];
+  const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+  const int* __restrict__ c = cnt + (size_t)b * HW;
+  int v[4], s = 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int i = ch * kScanChunk + 4 * tid + e;
+    v[e] = i < HW ? c[i] : 0;
+    s += v[e];
+  }
   sSum[tid] = s;
   __syncthreads();
-  for (int d = 1; d < kScanThreads; d <<= 1) {   // inclusive Hillis-Steele scan of the chunk sums
-    const int v = tid >= d ? sSum[tid - d] : 0;
+  for (int d = 1; d < 256; d <<= 1) {
+    const int t = tid >= d ? sSum[tid - d] : 0;
     __syncthreads();
-    sSum[tid] += v;
+    sSum[tid] += t;
     __syncthreads();
   }
-  int run = sSum[tid] - s;
-  for (int i = lo; i < hi; ++i) {
-    const int ci = c[i];
-    start[2 * ((size_t)b * HW + i)] = run;        // (start, count) pairs: one 8-byte load per cell in adj_map_kernel
-    start[2 * ((size_t)b * HW + i) + 1] = ci;
-    cursor[(size_t)b * HW + i] = run;
-    run += ci;
+  int run = chunk_off[(size_t)b * nchunks + ch] + sSum[tid] - s;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int i = ch * kScanChunk + 4 * tid + e;
+    if (i < HW) {
+      start[2 * ((size_t)b * HW + i)] = run;        // (start, count) pairs: one 8-byte load per cell in adj_map_kernel
+      start[2 * ((size_t)b * HW + i) + 1] = v[e];
+      cursor[(size_t)b * HW + i] = run;
+    }
+    run += v[e];
   }
+}
+
+static void launch_cell_scan(const int* cnt, int* start, int* cursor, int* chunk_tmp, int B, int HW, hipStream_t s) {
+  const int nchunks = (HW + kScanChunk - 1) / kScanChunk;
+  hipLaunchKernelGGL(adj_scan_sums_kernel, dim3(nchunks, B), dim3(256), 0, s, cnt, chunk_tmp, HW, nchunks);
+  hipLaunchKernelGGL(adj_scan_offsets_kernel, dim3(B), dim3(kScanThreads), 0, s, chunk_tmp, nchunks);
+  hipLaunchKernelGGL(adj_scan_apply_kernel, dim3(nchunks, B), dim3(256), 0, s, cnt, chunk_tmp, start, cursor, HW, nchunks);
 }
 
 __global__ void adj_fill_kernel(const float* __restrict__ frac, int* __restrict__ cursor, int* __restrict__ list, int N, int HW) {
@@ -849,9 +905,8 @@ __device__ __forceinline__ int wave_min_i(int v) {
 // One wave per target texel: the adjoint of the bilinear sampling as a GATHER over the source pixels whose footprint
 // covers the texel, in a fixed order (cells row-major, ascending pixel index inside a cell).  Common case (every cell
 // holds at most one pixel, e.g. near-unit local scale): straight-line code, 4 + 4 + 4 independent loads, then the rows.
-template <int J3>   // 3C <= 64 J3
-__global__ __launch_bounds__(kBlock) void adj_map_kernel(const AdjArgs a) {
-  const int b = blockIdx.y, lane = threadIdx.x & 63, w = wave_id();
+template <int J3>   // 3C <= 64 J3; one texel, the whole wave
+__device__ __forceinline__ void adj_map_texel(const AdjArgs& a, int b, int t, int lane) {
   const int N = a.lv.N, C = a.lv.C, H = a.lv.H, W = a.lv.W, HW = H * W, C3 = 3 * C;
   const int2* __restrict__ cs = reinterpret_cast<const int2*>(a.start) + (size_t)b * HW;
   const int* __restrict__ list = a.list + (size_t)b * N;
@@ -860,7 +915,7 @@ __global__ __launch_bounds__(kBlock) void adj_map_kernel(const AdjArgs a) {
   bool cok[J3];
 #pragma unroll
   for (int j = 0; j < J3; ++j) cok[j] = lane + 64 * j < C3;
-  for (int t = blockIdx.x * kNumWaves + w; t < HW; t += gridDim.x * kNumWaves) {
+  {
     const int ty = t / W, tx = t - ty * W;
     int L[4], s0[4];
 #pragma unroll
@@ -872,7 +927,7 @@ __global__ __launch_bounds__(kBlock) void adj_map_kernel(const AdjArgs a) {
       s0[cell] = v.x;
     }
     const int Lmax = max(max(L[0], L[1]), max(L[2], L[3]));
-    if (Lmax == 0) continue;   // wave-uniform
+    if (Lmax == 0) return;   // wave-uniform
     float acc[J3];
 #pragma unroll
     for (int j = 0; j < J3; ++j) acc[j] = 0.f;
@@ -925,6 +980,86 @@ __global__ __launch_bounds__(kBlock) void adj_map_kernel(const AdjArgs a) {
 #pragma unroll
       for (int j = 0; j < J3; ++j)
         if (cok[j]) o[lane + 64 * j] += acc[j];
+    }
+  }
+}
+
+template <int J3>
+__global__ __launch_bounds__(kBlock) void adj_map_kernel(const AdjArgs a) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63, w = wave_id();
+  const int HW = a.lv.H * a.lv.W;
+  for (int t = blockIdx.x * kNumWaves + w; t < HW; t += gridDim.x * kNumWaves) adj_map_texel<J3>(a, b, t, lane);
+}
+
+// Two texels per wave (a half wave each, 16-byte accesses) for the common case that every cell involved holds at most one
+// pixel; a pair with a fuller cell goes through adj_map_texel, one texel after the other.  Same fma sequence per element as
+// adj_map_kernel: identical bits.  3C % 4 == 0, 3C <= 128 J4.
+template <int J4, int J3>
+__global__ __launch_bounds__(kBlock) void adj_map2_kernel(const AdjArgs a) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63, w = wave_id(), hl = lane & 31, hi = lane >> 5;
+  const int N = a.lv.N, C = a.lv.C, H = a.lv.H, W = a.lv.W, HW = H * W, C3 = 3 * C;
+  const int2* __restrict__ cs = reinterpret_cast<const int2*>(a.start) + (size_t)b * HW;
+  const int* __restrict__ list = a.list + (size_t)b * N;
+  const float* __restrict__ frac = a.frac + (size_t)b * N * 4;
+  const float* __restrict__ arow = a.arow + (size_t)b * N * C3;
+  bool cok[J4];
+#pragma unroll
+  for (int j = 0; j < J4; ++j) cok[j] = 4 * hl + 128 * j < C3;
+  for (int t2 = 2 * (blockIdx.x * kNumWaves + w); t2 < HW; t2 += 2 * gridDim.x * kNumWaves) {
+    const int t = t2 + hi;
+    const bool live = t < HW;
+    const int tt = live ? t : HW - 1;
+    const int ty = tt / W, tx = tt - ty * W;
+    int L[4], s0[4];
+#pragma unroll
+    for (int cell = 0; cell < 4; ++cell) {
+      const int cy = ty - 1 + (cell >> 1), cx = tx - 1 + (cell & 1);
+      const bool okc = live && cy >= 0 && cx >= 0;
+      const int2 v = cs[okc ? cy * W + cx : 0];
+      L[cell] = okc ? v.y : 0;
+      s0[cell] = v.x;
+    }
+    const int Lmax = max(max(L[0], L[1]), max(L[2], L[3]));
+    if (__any(Lmax > 1)) {                       // wave-uniform: a fuller cell somewhere in the pair
+      adj_map_texel<J3>(a, b, t2, lane);
+      if (t2 + 1 < HW) adj_map_texel<J3>(a, b, t2 + 1, lane);
+      continue;
+    }
+    if (!__any(Lmax == 1)) continue;
+    int n1[4];
+#pragma unroll
+    for (int cell = 0; cell < 4; ++cell) n1[cell] = list[L[cell] ? s0[cell] : 0];
+    float wt[4];
+    bool any = false;
+#pragma unroll
+    for (int cell = 0; cell < 4; ++cell) {
+      const float fax = frac[(size_t)n1[cell] * 4 + 1], fay = frac[(size_t)n1[cell] * 4 + 2];
+      const float v = ((cell & 1) ? 1.f - fax : fax) * ((cell >> 1) ? 1.f - fay : fay);
+      wt[cell] = L[cell] ? v : 0.f;
+      any = any || wt[cell] != 0.f;
+    }
+    f32x4 val[4][J4];
+#pragma unroll
+    for (int cell = 0; cell < 4; ++cell)
+#pragma unroll
+      for (int j = 0; j < J4; ++j) val[cell][j] = *reinterpret_cast<const f32x4*>(arow + (size_t)n1[cell] * C3 + (cok[j] ? 4 * hl + 128 * j : 0));
+    f32x4 acc[J4];
+#pragma unroll
+    for (int j = 0; j < J4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cell = 0; cell < 4; ++cell)
+#pragma unroll
+      for (int j = 0; j < J4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(wt[cell], wt[cell] != 0.f ? val[cell][j][e] : 0.f, acc[j][e]);
+    if (any) {
+      float* __restrict__ o = a.dmap3 + ((size_t)b * HW + t) * C3 + 4 * hl;
+#pragma unroll
+      for (int j = 0; j < J4; ++j)
+        if (cok[j]) {
+          f32x4* op = reinterpret_cast<f32x4*>(o + 128 * j);
+          *op = *op + acc[j];
+        }
     }
   }
 }
@@ -1039,9 +1174,30 @@ __global__ __launch_bounds__(kBlock) void sstats_rows_kernel(const float* __rest
   }
 }
 
+static void launch_adj_map(const AdjArgs& a, int C, dim3 grid, dim3 block, hipStream_t s) {
+  const int C3 = 3 * C, J3 = (C3 + 63) / 64;
+  const bool half = (C3 & 3) == 0 && !(a.lv.reserved_ & 524288);   // bit 19: one texel per wave (A/B)
+  if (J3 <= 3) {
+    if (half)
+      hipLaunchKernelGGL((adj_map2_kernel<2, 3>), grid, block, 0, s, a);
+    else
+      hipLaunchKernelGGL((adj_map_kernel<3>), grid, block, 0, s, a);
+  } else if (J3 <= 6) {
+    if (half)
+      hipLaunchKernelGGL((adj_map2_kernel<3, 6>), grid, block, 0, s, a);
+    else
+      hipLaunchKernelGGL((adj_map_kernel<6>), grid, block, 0, s, a);
+  } else {
+    if (half)
+      hipLaunchKernelGGL((adj_map2_kernel<6, 12>), grid, block, 0, s, a);
+    else
+      hipLaunchKernelGGL((adj_map_kernel<12>), grid, block, 0, s, a);
+  }
+}
+
 struct AdjPlan {
   int G, Ga, Gm;
-  size_t off_S, off_z2, off_arec, off_arow, off_frac, off_cnt, off_start, off_cursor, off_list, off_part, bytes;
+  size_t off_S, off_z2, off_arec, off_arow, off_frac, off_cnt, off_start, off_cursor, off_list, off_part, off_chunks, bytes;
 };
 
 bool adj_supported(const banet_level_t* lv) {
@@ -1071,6 +1227,7 @@ void adj_plan(const banet_level_t* lv, AdjPlan* pl) {
   pl->off_cursor = take(B * N * 4);
   pl->off_list = take(B * N * 4);
   pl->off_part = take(B * (size_t)pl->G * kNumWaves * (kAdjHdr + K) * 4);
+  pl->off_chunks = take(B * ((N + 1023) / 1024) * 4);
   pl->bytes = o;
 }
 
@@ -1158,17 +1315,11 @@ int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T
     BANET_ADJ_PIXEL(4, 2);
 #undef BANET_ADJ_PIXEL
   }
-  hipLaunchKernelGGL(adj_scan_kernel, dim3(B), dim3(kScanThreads), 0, s, a.cnt, a.start, a.cursor, HW);
+  launch_cell_scan(a.cnt, a.start, a.cursor, reinterpret_cast<int*>(base + pl.off_chunks), B, HW, s);
   hipLaunchKernelGGL(adj_fill_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, a.frac, a.cursor, a.list, N, HW);
   {
-    const int J3 = (3 * lv->C + 63) / 64;
     const dim3 grid(pl.Gm, B), block(kBlock);
-    if (J3 <= 3)
-      hipLaunchKernelGGL((adj_map_kernel<3>), grid, block, 0, s, a);
-    else if (J3 <= 6)
-      hipLaunchKernelGGL((adj_map_kernel<6>), grid, block, 0, s, a);
-    else
-      hipLaunchKernelGGL((adj_map_kernel<12>), grid, block, 0, s, a);
+    launch_adj_map(a, lv->C, grid, block, s);
   }
   hipLaunchKernelGGL(adj_fold_kernel, dim3((12 + K + 127) / 128, B), dim3(128), 0, s, a.part, pl.G * kNumWaves, K, dpose);
   return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;
@@ -1176,7 +1327,7 @@ int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T
 
 namespace {
 struct DetPlan {
-  size_t off_arow, off_frac, off_cnt, off_start, off_cursor, off_list, bytes;
+  size_t off_arow, off_frac, off_cnt, off_start, off_cursor, off_list, off_chunks, bytes;
 };
 void det_plan(int B, int N, int C, int H, int W, DetPlan* pl) {
   const size_t HW = (size_t)H * W;
@@ -1192,6 +1343,7 @@ void det_plan(int B, int N, int C, int H, int W, DetPlan* pl) {
   pl->off_start = take((size_t)B * HW * 8);
   pl->off_cursor = take((size_t)B * HW * 4);
   pl->off_list = take((size_t)B * N * 4);
+  pl->off_chunks = take((size_t)B * ((HW + 1023) / 1024) * 4);
   pl->bytes = o;
 }
 }  // namespace
@@ -1228,18 +1380,12 @@ int launch_sample_stats_grad_det(const float* conv1, const float* conv2, const f
   const int G = (N + 16 * kNumWaves - 1) / (16 * kNumWaves);
   hipLaunchKernelGGL(sstats_rows_kernel, dim3(G, B), dim3(kBlock), 0, s, conv1, conv2, px, py, N, C, H, W, dstats, dabs, dconv1,
                      dpos, a.arow, a.frac, a.cnt);
-  hipLaunchKernelGGL(adj_scan_kernel, dim3(B), dim3(kScanThreads), 0, s, a.cnt, a.start, a.cursor, HW);
+  launch_cell_scan(a.cnt, a.start, a.cursor, reinterpret_cast<int*>(base + pl.off_chunks), B, HW, s);
   hipLaunchKernelGGL(adj_fill_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, a.frac, a.cursor, a.list, N, HW);
   {
-    const int J3 = (3 * C + 63) / 64;
     const int Gm = (int)std::max<size_t>(1, std::min<size_t>(((size_t)HW + 3) / 4, (size_t)((4096 + B - 1) / B)));
     const dim3 grid(Gm, B), block(kBlock);
-    if (J3 <= 3)
-      hipLaunchKernelGGL((adj_map_kernel<3>), grid, block, 0, s, a);
-    else if (J3 <= 6)
-      hipLaunchKernelGGL((adj_map_kernel<6>), grid, block, 0, s, a);
-    else
-      hipLaunchKernelGGL((adj_map_kernel<12>), grid, block, 0, s, a);
+    launch_adj_map(a, C, grid, block, s);
   }
   return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;
 }
