@@ -7,7 +7,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from banet_amd import ops
 dev = torch.device("cuda:0")
 C = 128
-for B, N, P in ((8, 4096, 134), (8, 76800, 134), (2, 307200, 134), (8, 76800, 6), (2, 76800, 262), (8, 76800, 262), (8, 76800, 200)):
+SHAPES = ((8, 4096, 134), (8, 76800, 134), (2, 307200, 134), (8, 76800, 6), (2, 76800, 262), (8, 76800, 262), (8, 76800, 200))
+if os.environ.get("EQ_SHAPES"):      # e.g. EQ_SHAPES=8x76800x262,8x76800x134 (under rocprofv3: one shape per run keeps the stats readable)
+    SHAPES = tuple(tuple(int(v) for v in t.split("x")) for t in os.environ["EQ_SHAPES"].split(","))
+for B, N, P in SHAPES:
     g = torch.Generator().manual_seed(1)
     J = torch.randn(B, N, 2, P, generator=g).to(dev)
     G = torch.randn(B, N, C, 2, generator=g).to(dev)
