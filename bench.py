@@ -38,6 +38,8 @@ SCALES = [16, 8, 4, 2, 1]
 ITERS = [10, 10, 10, 10, 10]
 WINDOWS_PER_GPU = 32          # BASELINE.json metric: "batch 32"
 HBM_PEAK_GBS = 8000.0
+MFMA_BF16_PEAK_TF = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md; not the 2:1-sparsity headline)
+MFMA_F32_PEAK_TF = 157.3        # fp32-in / fp32-accumulate MFMA peak (= the fp32 vector peak)
 PARITY_TOL = 1e-4             # BASELINE.json north_star: pose/depth updates within 1e-4 relative
 CHAIN_ITERS = [4, 4, 4, 4, 4]
 
@@ -103,6 +105,8 @@ def roofline_record(prob, prof, elapsed_s, traffic=None):
     summed over every launch of the timed region (all levels), per-level breakdown included."""
     ba, B = prob.ba, prob.B
     alg_bytes, kern_ms, nlaunch, per_level, syrk_ms, syrk_n = 0.0, 0.0, 0, {}, 0.0, 0
+    syrk_flops, syrk_exec = 0.0, 0.0
+    pairs = max(int(prob.pairs), 1)
     for li, p in enumerate(ba.problems):
         cnt, ms = prof.get(p.N, (0, 0.0))
         scnt, sms = prof.get(-p.N, (0, 0.0))
@@ -112,6 +116,14 @@ def roofline_record(prob, prof, elapsed_s, traffic=None):
         nlaunch += cnt
         syrk_ms += sms
         syrk_n += scnt
+        Kk = int(p.c.K)
+        # the SYRK's arithmetic per window-iteration: H_dd upper triangle N K (K+1) flops + per target frame H_cd / Atb_d 14 N K;
+        # what the bf16x6 kernel executes for it (K = 64 or 128): six bf16 MFMAs (16x16x32 = 16384 flops per 32 pixels) per
+        # 16x16 block of the upper triangle and of the record block rows
+        syrk_flops += float(p.N) * (Kk * (Kk + 1) + 14 * Kk * pairs) * B * scnt
+        if Kk in (64, 128):
+            nbv = Kk // 16
+            syrk_exec += float(p.N) / 32.0 * 6 * 16384 * (nbv * (nbv + 1) // 2 + ((pairs + 1) // 2) * nbv) * B * scnt
         per_level["%dx%d" % (p.c.W, p.c.H)] = {"launches": cnt, "gather_avg_us": round(1e3 * ms / max(cnt, 1), 2),
                                                 "syrk_avg_us": round(1e3 * sms / max(scnt, 1), 2),
                                                 "gather_GBps": round(by / max(ms, 1e-9) / 1e6, 1)}
@@ -127,7 +139,15 @@ def roofline_record(prob, prof, elapsed_s, traffic=None):
             "algorithmic_bytes_per_launch": round(alg_bytes / max(nlaunch, 1)),
             "kernel_time_share": round(kern_ms / (1e3 * elapsed_s), 4),
             "syrk_kernel": {"launches": syrk_n, "avg_launch_us": round(1e3 * syrk_ms / max(syrk_n, 1), 2),
-                            "time_share": round(syrk_ms / (1e3 * elapsed_s), 4)},
+                            "time_share": round(syrk_ms / (1e3 * elapsed_s), 4),
+                            # the matrix-core side of the path (north_star: "MFMA utilisation against gfx950 peak")
+                            "mfma": {"bound": "mfma", "kernel": "ba_syrk_bf16x6_kernel (fp32 operands split exactly into 3 bf16 pieces, 6 products)",
+                                     "algorithmic_fp32_TFLOPs": round(syrk_flops / max(syrk_ms, 1e-9) / 1e9, 1),
+                                     "peak_fp32_matrix_TFLOPs": MFMA_F32_PEAK_TF,
+                                     "frac_of_fp32_matrix_peak": round(syrk_flops / max(syrk_ms, 1e-9) / 1e9 / MFMA_F32_PEAK_TF, 4),
+                                     "achieved": round(syrk_exec / max(syrk_ms, 1e-9) / 1e9, 1) if syrk_exec else None,
+                                     "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s (bf16 MFMA flops executed)",
+                                     "frac": round(syrk_exec / max(syrk_ms, 1e-9) / 1e9 / MFMA_BF16_PEAK_TF, 4) if syrk_exec else None}},
             "pipeline_GBps": round(alg_bytes / max(kern_ms + syrk_ms, 1e-9) / 1e6, 1),
             "per_level": per_level}
 
