@@ -597,7 +597,10 @@ int launch_gather128p(const GatherArgs& a, int K, hipStream_t s) {
   const bool u4 = (a.lv.reserved_ & 16384) != 0;   // bit 14: 4-step units (A/B, experiments/README.md)
   const bool packed = (a.lv.reserved_ & 65536) != 0;   // bit 16: the packed patch with flat loads (A/B)
   const bool small = (size_t)a.lv.H * a.lv.W * a.lv.C * 4 < ((size_t)1 << 31) && (size_t)a.lv.N * a.lv.C * 4 < ((size_t)1 << 31);
-  if (K == 0)
+  const bool fs = small && !packed && !dyn;          // the fixed-stride patch addresses the maps with 32-bit buffer offsets
+  if (K == 0 && fs)
+    hipLaunchKernelGGL((ba_gather128p_kernel<0, 2, true>), grid, block, 0, s, a);
+  else if (K == 0)
     hipLaunchKernelGGL((ba_gather128p_kernel<0, 2, false>), grid, block, 0, s, a);
   else if ((K & 3) == 0 && K <= 128 && u4)
     hipLaunchKernelGGL((ba_gather128p_kernel<1, 4, false>), grid, block, 0, s, a);
@@ -605,6 +608,8 @@ int launch_gather128p(const GatherArgs& a, int K, hipStream_t s) {
     hipLaunchKernelGGL((ba_gather128p_kernel<1, 2, false>), grid, block, dyn, s, a);
   else if ((K & 3) == 0 && K <= 128)
     hipLaunchKernelGGL((ba_gather128p_kernel<1, 2, true>), grid, block, 0, s, a);
+  else if ((K & 3) == 0 && K <= 256 && fs)
+    hipLaunchKernelGGL((ba_gather128p_kernel<2, 2, true>), grid, block, 0, s, a);
   else if ((K & 3) == 0 && K <= 256)
     hipLaunchKernelGGL((ba_gather128p_kernel<2, 2, false>), grid, block, 0, s, a);
   else
