@@ -2,7 +2,7 @@
 # Build libbanet_hip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
 set -euo pipefail
 cd "$(dirname "$0")"
-OUT=../lib
+OUT=${BANET_BUILD_OUT:-../lib}     # BANET_BUILD_OUT: a second build (e.g. -DBANET_TIMING) next to the product library
 mkdir -p "$OUT"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 SRCS="gather gather128 gather128p syrk syrk_wide assemble eqcon eqcon_syrk eqcon_grad solve prep sstats adjoint api"

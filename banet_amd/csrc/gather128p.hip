@@ -179,6 +179,10 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
     };
     bool valid;
     const int pt = point_of(lane, valid);
+    BANET_TICK(tp0);
+#if defined(BANET_TIMING) && BANET_TIMING == 1
+    float tp_stage = 0.f, tp_taps = 0.f;
+#endif
 
     // ---- 1. depth: D_j = D0_j + b_j . W.  A half wave reads one basis row per instruction
     // (16 B per lane); 32 row pairs go through a 5-level transposing butterfly inside each half,
@@ -342,6 +346,7 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
       *reinterpret_cast<float4*>(&sPar[w][lane][4]) = pb;
     }
 
+    BANET_TICK(tp2);
     // ---- 3. gather: 8 step pairs x (2 steps x 4 pixels); lane = (pixel group, 8-channel slice) -----
     // Software pipeline over the units (pair, channel half): the 9 box loads + 2 source loads of the NEXT
     // staged unit are issued (into 44 registers) right after the current unit's box has been written to the
@@ -406,6 +411,9 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
       if (ntex > 0) {   // wave-uniform: the unit's box fits the patch
 #pragma unroll 1
         for (int h = 0; h < 2; ++h) {
+#if BANET_TIMING == 1
+          BANET_TICK(tu0);
+#endif
           if (!pre) issue(sp, h);
 #pragma unroll
           for (int i = 0; i < NL; ++i)
@@ -419,6 +427,10 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
             if (pre) issue(nsp, nh);
           }
           const int rs = FS ? 8 * 64 : pw * 64;
+#if BANET_TIMING == 1
+          BANET_TICK(tu1);   // (the tick waits for the LDS writes of the box)
+          BANET_TACC(tp_stage, tu0, tu1);
+#endif
           if (!(abl & 8))
 #pragma unroll
           for (int t = 0; t < US; ++t) {
@@ -435,6 +447,12 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
             const float4 p1 = *reinterpret_cast<const float4*>(l + 2 * rs), p2 = *reinterpret_cast<const float4*>(l + 2 * rs + 64);
             tap_math_p(f1, a0, a1, a2, a3, b0, b1, b2, b3, m1, m2, p1, p2, pa.z, pa.w, pb.x, pb.y, pb.z, qa2[t], absA);
           }
+#if BANET_TIMING == 1
+          {
+            BANET_TICK(tu2);
+            BANET_TACC(tp_taps, tu1, tu2);
+          }
+#endif
 #pragma unroll
           for (int e = 0; e < 4; ++e) {   // half h done: the other half's accumulators become current (two swaps = identity)
             const float tmp = absA[e];
@@ -480,6 +498,7 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
         }
       }
     }
+    BANET_TICK(tp3);
     Q5 q;
     {
       q.m11 = sQ[w][lane][0];
@@ -565,6 +584,7 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
       }
     }
 
+    BANET_TICK(tp4);
     // ---- 5. the tile's C x sum|d| ------------------------------------------------------------
 #pragma unroll
     for (int i = 0; i < 8; ++i) {  // fold the 4 pixel groups (fixed order), group 0 publishes
@@ -577,6 +597,23 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
     sAbs[w][2 * lane + 1] += absd2[0][1];
     part[kGHdr + lane] = sAbs[w][lane];
     part[kGHdr + 64 + lane] = sAbs[w][64 + lane];
+#ifdef BANET_TIMING   // tools/time_gather.py: cycles of this tile (wave-private counters, the last target frame of the window)
+    {
+      BANET_TICK(tp9);
+      if (lane == 0) {
+#if BANET_TIMING == 1
+        part[28] = tp_stage;                 // unit halves: wait for the box + ds_write + issue of the next unit's loads
+        part[29] = tp_taps;                  // unit halves: ds_read of the taps + channel maths
+        part[30] = (float)(tp2 - tp0);       // depth dot + geometry
+#else                                        // -DBANET_TIMING=2: no ticks inside the unit loop
+        part[28] = (float)(tp3 - tp2);       // the unit loop
+        part[29] = (float)(tp4 - tp3);       // rim pixels, per-pixel algebra, pose sums, records
+        part[30] = (float)(tp9 - tp4);       // sum|d| fold + partial
+#endif
+        part[31] = (float)(tp9 - tp0);       // whole tile
+      }
+    }
+#endif
     }  // pairs
   }  // tiles
 }

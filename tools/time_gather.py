@@ -11,12 +11,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from banet_amd import _capi as capi, dense as bdense, synth as bsynth  # noqa: E402
 from banet_amd.bundlenet import he_normal_lambda_weights  # noqa: E402
 
-B, H, W, C, K = 4, 480, 640, 128, int(os.environ.get("PK", "128"))
+B, H, W, C, K = int(os.environ.get("PB", "4")), 480, 640, 128, int(os.environ.get("PK", "128"))
 dev = torch.device("cuda:0")
 intr, levels, gt = bsynth.make_dense_windows(B, H, W, C, K, [1], 5, dev, trans_mag=0.06)
 ba = bdense.DenseBA(intr, levels, [he_normal_lambda_weights(C, 1)], "bundle" if K else "bundle_camera", 1000.0)
 p = ba.problems[0]
-p.c.reserved_ = 64   # the instrumented kernel is the direct ba_gather128_kernel (large levels default to the patch kernel)
+PATCH = os.environ.get("PPATCH", "1") == "1"   # 1: the patch kernel (ba_gather128p_kernel), 0: the direct ba_gather128_kernel
+p.c.reserved_ = 0 if PATCH else 64
 L = capi.lib()
 R = torch.eye(3, device=dev).repeat(B, 1, 1)
 T = (gt["T"] * 0.7).reshape(B, 3, 1).to(dev)
@@ -34,7 +35,10 @@ torch.cuda.synchronize()
 tiles = 80 * 60
 part = ws[:B * tiles * (32 + C) * 4].view(torch.float32).reshape(B, tiles, 32 + C)
 t = part[:, :, 28:32].reshape(-1, 4).cpu()
-names = ["16 gather steps", "rim+algebra+partials", "depth dot", "whole tile"]
+MODE2 = os.environ.get("PMODE", "1") == "2"   # the library was built with -DBANET_TIMING=2
+names = (["unit loop", "rim + algebra + pose sums + records", "sum|d| fold + partial", "whole tile"] if PATCH and MODE2 else
+         ["unit halves: wait + box -> LDS + next issue", "unit halves: taps", "depth dot + geometry", "whole tile"] if PATCH else
+         ["16 gather steps", "rim+algebra+partials", "depth dot", "whole tile"])
 for i, nme in enumerate(names):
     v = t[:, i]
     print("%-22s mean %9.0f cycles/tile  (p10 %9.0f  p90 %9.0f)  %7.1f cycles/step" % (
