@@ -228,7 +228,9 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
     float gw00 = 0.f, gw01 = 0.f, gw10 = 0.f, gw11 = 0.f, jd0 = 0.f, jd1 = 0.f;
     float jc[12];
     int gx0 = 1, gy0 = 1, gflags = 0;
-    {
+    // the pixel's projection, tap weights and Jacobian rows from (pt, D, R, T)
+    auto pixel_geometry = [&]() __attribute__((always_inline)) {
+      gw00 = gw01 = gw10 = gw11 = jd0 = jd1 = 0.f;
       float p0 = 0.f, p1 = 0.f, p2 = 1.f, fx = 1.f, fy = 1.f, ox = 0.f, oy = 0.f;
       if (valid) {
         if (dense) {
@@ -303,6 +305,11 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
       gflags = (m ? 1 : 0) | (fast ? 2 : 0) | ((m && !fast) ? 4 : 0);
       gx0 = x0;
       gy0 = y0;
+    };
+    pixel_geometry();
+    {
+      const int x0 = gx0, y0 = gy0;
+      const bool fast = (gflags & 2) != 0;
       // parameters of the branch-free gather: non-fast pixels read the safe texel (1,1) with
       // zero weights
       const float mk = fast ? 1.f : 0.f;
