@@ -6,8 +6,8 @@ One autograd node per pyramid LEVEL (all of its fixed-count iterations, as bundl
   forward   iteration by iteration with the product kernels (banet_ba_assemble_f32 + banet_ba_solve_update_f32), keeping the
             per-iteration state (R, T, Wc) and the small outputs of the assembly (AtA, Atb, sum |d|);
   backward  iterations in reverse: (a) the small part -- lambda MLP, damping, solve, SE(3)/W update -- is re-evaluated as
-            a torch graph on the saved [B,P,P] / [B,P] / [B,C] tensors (implicit differentiation of the damped solve is
-            torch.linalg.solve's backward), giving dL/d(AtA, Atb, sum|d|), the direct dL/d(R, T, Wc) and the lambda-weight
+            a torch graph on the saved [B,P,P] / [B,P] / [B,C] tensors (the damped solve and its implicit-function gradient
+            on banet_spd_solve_f32: lam = A^-1 g, dA = -lam x^T), giving dL/d(AtA, Atb, sum|d|), the direct dL/d(R, T, Wc) and the lambda-weight
             gradients; (b) banet_dense_adjoint_f32 turns the former into gradients of the feature maps, depth, basis and
             pose, accumulated over the iterations in place; (c) once per level banet_target_map_adjoint_f32 folds the
             [f|gx|gy] map adjoint into the target map's gradient.

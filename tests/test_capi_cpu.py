@@ -230,3 +230,27 @@ def test_backward_entry_points_validate_their_arguments_without_gpu(capi):
     assert L.banet_spd_solve_f32(None, None, None, 1, 134, None) == -1
     buf = ctypes.c_void_p(4096)                                                                    # never dereferenced: rejected on the host
     assert L.banet_spd_solve_f32(buf, buf, buf, 1, 8, None) == -3 and L.banet_spd_solve_f32(buf, buf, buf, 1, 400, None) == -3
+
+
+def test_bench_roofline_record_arithmetic():
+    """bench.py's roofline object: the HBM side (algorithmic bytes / gather time) and the matrix-core side of the SYRK
+    (algorithmic fp32 flops and executed bf16 MFMA flops / SYRK time) from a synthetic launch profile."""
+    import types
+    sys.path.insert(0, ROOT) if ROOT not in sys.path else None
+    import bench
+    N, K, B = 1024, 128, 2
+    lvl = types.SimpleNamespace(N=N, c=types.SimpleNamespace(W=32, H=32, K=K))
+    ba = types.SimpleNamespace(problems=[lvl], algorithmic_bytes_per_iteration=lambda li: 4 * N * (2 * 128 + K + 1))
+    prob = types.SimpleNamespace(ba=ba, B=B, pairs=1)
+    prof = {N: (10, 2.0), -N: (10, 1.0)}            # 10 gather launches in 2 ms, 10 SYRK launches in 1 ms
+    r = bench.roofline_record(prob, prof, elapsed_s=0.004, traffic=123)
+    by = 4 * N * (2 * 128 + K + 1) * B * 10
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["traffic"] == 123
+    assert abs(r["achieved"] - by / 2.0 / 1e6) < 0.1 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-3
+    assert r["launches"] == 10 and abs(r["kernel_time_share"] - 0.5) < 1e-6
+    m = r["syrk_kernel"]["mfma"]
+    flops = N * (K * (K + 1) + 14 * K) * B * 10
+    executed = N / 32 * 6 * 16384 * (36 + 8) * B * 10
+    assert m["bound"] == "mfma" and m["peak"] == 2500.0 and m["peak_fp32_matrix_TFLOPs"] == 157.3
+    assert abs(m["algorithmic_fp32_TFLOPs"] - flops / 1.0 / 1e9) < 0.06
+    assert abs(m["achieved"] - executed / 1.0 / 1e9) < 0.06 and abs(m["frac"] - m["achieved"] / 2500.0) < 1e-3
