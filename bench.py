@@ -38,6 +38,7 @@ SCALES = [16, 8, 4, 2, 1]
 ITERS = [10, 10, 10, 10, 10]
 WINDOWS_PER_GPU = 32          # BASELINE.json metric: "batch 32"
 HBM_PEAK_GBS = 8000.0
+HBM_STREAM_GBS = 6300.0         # what a streaming read reaches (MI355X_MICROARCH.md, HBM section)
 MFMA_BF16_PEAK_TF = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md; not the 2:1-sparsity headline)
 MFMA_F32_PEAK_TF = 157.3        # fp32-in / fp32-accumulate MFMA peak (= the fp32 vector peak)
 PARITY_TOL = 1e-4             # BASELINE.json north_star: pose/depth updates within 1e-4 relative
@@ -134,6 +135,10 @@ def roofline_record(prob, prof, elapsed_s, traffic=None):
             rec["level_ms_last_step"] = round(ms, 3)
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            # the fetched bytes (PMC pass of the same command, profiles/pmc_traffic.json) over the live launch time: how close the
+            # kernel runs to what a streaming copy reaches on this part (MI355X_MICROARCH.md: ~6.3 of the 8 TB/s)
+            "traffic_GBps": round(traffic / max(kern_ms / max(nlaunch, 1), 1e-9) / 1e6, 1) if traffic else None,
+            "streaming_copy_GBps": HBM_STREAM_GBS,
             "kernel": "ba_gather128p_kernel<1, 2, true> (large levels) + ba_gather128_kernel<1> (small levels)",
             "launches": nlaunch, "avg_launch_us": round(1e3 * kern_ms / max(nlaunch, 1), 2),
             "algorithmic_bytes_per_launch": round(alg_bytes / max(nlaunch, 1)),

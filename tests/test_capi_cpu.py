@@ -248,6 +248,7 @@ def test_bench_roofline_record_arithmetic():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["traffic"] == 123
     assert abs(r["achieved"] - by / 2.0 / 1e6) < 0.1 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-3
     assert r["launches"] == 10 and abs(r["kernel_time_share"] - 0.5) < 1e-6
+    assert abs(r["traffic_GBps"] - 123 / 0.2e-3 / 1e9) < 0.1 and r["streaming_copy_GBps"] == 6300.0
     m = r["syrk_kernel"]["mfma"]
     flops = N * (K * (K + 1) + 14 * K) * B * 10
     executed = N / 32 * 6 * 16384 * (36 + 8) * B * 10
