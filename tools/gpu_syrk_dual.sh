@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the reserved_ bit this script toggles belongs to an experiment that is no longer in the library (its code: see
+# banet_amd/csrc/experiments/README.md and the *.patch.txt / *.hip.txt files there); kept as the record of how the numbers were taken.
 # A/B of ba_syrk_dual_kernel (reserved_ bit 20) against the one-role SYRK: kernel times + bit-identity (prof_assemble.py), then the bench
 set -u
 OUT=gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp PYTHONUNBUFFERED=1

@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the reserved_ bit this script toggles belongs to an experiment that is no longer in the library (its code: see
+# banet_amd/csrc/experiments/README.md and the *.patch.txt / *.hip.txt files there); kept as the record of how the numbers were taken.
 # workgroup items (reserved_ bit 22) vs per-wave items: time, bit-identity, then fabric requests (PMC)
 set -u
 OUT=gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp PYTHONUNBUFFERED=1
