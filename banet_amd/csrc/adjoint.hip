@@ -1235,11 +1235,10 @@ template <int NK>
 void launch_adj_basis(const AdjArgs& a, int Ga, hipStream_t s) {
   constexpr int KP = 16 * NK, LS = KP + 20;
   const size_t shm = (size_t)KP * LS * sizeof(float);
-  static bool attr_set = false;   // > 64 KB of dynamic LDS needs the attribute once per process
-  if (!attr_set) {
+  // > 64 KB of dynamic LDS needs the attribute; it belongs to the CURRENT device's function object, so it is set on every
+  // launch (like launch_spd_solve / launch_syrk_nb) rather than once per process behind a flag
+  if (shm > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&adj_basis_kernel<NK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    attr_set = true;
-  }
   hipLaunchKernelGGL((adj_basis_kernel<NK>), dim3(Ga, a.lv.B), dim3(kBlock), shm, s, a);
 }
 

@@ -234,7 +234,10 @@ int banet_lm_level_ex_f32(const banet_level_t* lv, const banet_mlp_t* mlp, float
       rc = launch_assemble(lv, pl, st->R, st->T, st->Wc, &w.ctl->active, stride, w.partials, w.AtA, w.Atb, w.absres,
                            w.nvalid, s);
       if (rc != BANET_OK) return rc;
-      rc = launch_solve(a, s);
+      {
+        RangeScope r("solve", lv->N);
+        rc = launch_solve(a, s);
+      }
       if (rc != BANET_OK) return rc;
     }
   } else {
@@ -259,7 +262,10 @@ int banet_lm_level_ex_f32(const banet_level_t* lv, const banet_mlp_t* mlp, float
       rc = launch_assemble(lv, pl, st->R, st->T, st->Wc, nullptr, 0, w.partials, w.AtA, w.Atb, w.absres, w.nvalid, s,
                            a.queue == nullptr, role ? mlp : nullptr, role ? w.mlp_y : nullptr);
       if (rc != BANET_OK) return rc;
-      rc = launch_solve(a, s);
+      {
+        RangeScope r("solve", lv->N);
+        rc = launch_solve(a, s);
+      }
       if (rc != BANET_OK) return rc;
     }
   }
@@ -349,6 +355,11 @@ int banet_target_map_adjoint_f32(const float* dmap3, float* dimg, int B, int H, 
   if (!dmap3 || !dimg || B <= 0 || H <= 0 || W <= 0 || C <= 0) return BANET_ERR_INVALID_ARG;
   return launch_target_map_adjoint(dmap3, dimg, B, H, W, C, static_cast<hipStream_t>(stream));
 }
+
+#include "build_id.h"   // generated by build.sh: BANET_BUILD_ID
+const char* banet_build_id(void) { return BANET_BUILD_ID; }
+
+int banet_profile_ranges(int enable) { return profile_ranges(enable); }
 
 int banet_profile_begin(int max_launches) { return profile_begin(max_launches); }
 

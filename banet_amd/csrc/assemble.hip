@@ -2,6 +2,10 @@
 // reductions, pose block) + ba_fold_kernel + a SYRK kernel (syrk*.hip; depth-basis blocks on the matrix cores) +
 // ba_reduce2_kernel (fixed-order sum of the per-tile / per-workgroup partials).  Also hosts the optional
 // launch timer behind banet_profile_begin/_end.
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "kernels.hpp"
@@ -31,6 +35,48 @@ struct Timed {  // brackets one kernel launch with two events when profiling is 
   }
 };
 }  // namespace
+
+// ---- roctx ranges (banet_profile_ranges / BANET_ROCTX=1): the marker library is loaded on first use, never linked ----
+namespace {
+struct Roctx {
+  int state = -1;                       // -1: not probed, 0: off / unavailable, 1: on
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  bool load() {
+    if (push) return true;
+    for (const char* name : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+      void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (!h) continue;
+      push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+      pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+      if (push && pop) return true;
+      push = nullptr;
+    }
+    return false;
+  }
+} g_roctx;
+}  // namespace
+
+int profile_ranges(int enable) {
+  g_roctx.state = (enable && g_roctx.load()) ? 1 : 0;
+  return g_roctx.state;
+}
+
+RangeScope::RangeScope(const char* role, int n) : on(false) {
+  if (g_roctx.state < 0) {
+    const char* e = getenv("BANET_ROCTX");
+    profile_ranges(e && e[0] == '1');
+  }
+  if (g_roctx.state != 1) return;
+  char buf[64];
+  if (n >= 0) snprintf(buf, sizeof buf, "banet.%s N=%d", role, n);
+  else snprintf(buf, sizeof buf, "banet.%s", role);
+  g_roctx.push(buf);
+  on = true;
+}
+RangeScope::~RangeScope() {
+  if (on) g_roctx.pop();
+}
 
 int profile_begin(int max_launches) {
   if (g_prof.on || max_launches <= 0) return BANET_ERR_INVALID_ARG;
@@ -96,12 +142,18 @@ int launch_assemble(const banet_level_t* lv, const AsmPlan& pl, const float* R, 
   int rc;
   if (reset_queue) prepare_gather(lv, pl.g, gpart, s);
   {
+    RangeScope r("gather", lv->N);
     Timed t(s, lv->N);
     rc = launch_gather(lv, pl.g, R, T, Wc, active, active_stride, rec, gpart, s);
   }
   if (rc != BANET_OK) return rc;
-  const float* gred = finish_gather(lv, pl.g, active, active_stride, gpart, s);
+  const float* gred;
+  {
+    RangeScope r("fold", lv->N);
+    gred = finish_gather(lv, pl.g, active, active_stride, gpart, s);
+  }
   if (lv->K > 0) {
+    RangeScope r("syrk", lv->N);
     Timed t(s, -lv->N);
     MlpRole mr{};
     if (role_mlp != nullptr && role_y != nullptr && syrk_runs_mlp_role(pl.s)) {
@@ -118,6 +170,7 @@ int launch_assemble(const banet_level_t* lv, const AsmPlan& pl, const float* R, 
                      mr.y != nullptr ? &mr : nullptr);
     if (rc != BANET_OK) return rc;
   }
+  RangeScope r("reduce", lv->N);
   launch_reduce2(gred, pl.g.frows, pl.g.pstride, spart, pl.s.Gs, pl.s.pstride, active, active_stride, lv->B, lv->K, lv->C,
                  npairs(lv), AtA, Atb, absres, nvalid, s);
   return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;

@@ -6,18 +6,24 @@ OUT=${BANET_BUILD_OUT:-../lib}     # BANET_BUILD_OUT: a second build (e.g. -DBAN
 mkdir -p "$OUT"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 SRCS="gather gather128 gather128p syrk syrk_wide assemble eqcon eqcon_syrk eqcon_grad solve prep sstats adjoint api"
+# build id: digest of every kernel source + the compile flags (banet_build_id(); bench.py ties PMC traffic files to it).
+# Only api.o depends on it, and the header is rewritten only when the digest changes.
+BID=$( { cat $(ls *.hip *.hpp | sort) ../../include/banet_hip.h; echo "$FLAGS ${EXTRA_HIPCC_FLAGS:-}"; } | sha256sum | cut -c1-16)
+if ! grep -qs "\"$BID\"" "$OUT/build_id.h"; then echo "#define BANET_BUILD_ID \"$BID\"" > "$OUT/build_id.h"; fi
 pids=()
 names=()
 for f in $SRCS; do
   stale=0
   [ -f "$OUT/$f.o" ] || stale=1
-  for dep in "$f.hip" *.hpp ../../include/banet_hip.h; do
+  extra_dep=""
+  [ "$f" = api ] && extra_dep="$OUT/build_id.h"
+  for dep in "$f.hip" *.hpp ../../include/banet_hip.h $extra_dep; do
     [ "$stale" = 1 ] || { [ "$dep" -nt "$OUT/$f.o" ] && stale=1; } || true
   done
   if [ "$stale" = 1 ]; then
     echo "hipcc $f.hip"
     rm -f "$OUT/$f.o"      # a failed compile must not leave an older object for the link step
-    hipcc $FLAGS ${EXTRA_HIPCC_FLAGS:-} -c "$f.hip" -o "$OUT/$f.o" &
+    hipcc $FLAGS ${EXTRA_HIPCC_FLAGS:-} -I"$OUT" -c "$f.hip" -o "$OUT/$f.o" &
     pids+=($!)
     names+=("$f")
   fi

@@ -632,11 +632,7 @@ int launch_gather128p(const GatherArgs& a, int K, hipStream_t s) {
   size_t dyn = 0;
   if (a.lv.reserved_ & 8192) {
     dyn = 60 * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_gather128p_kernel<1, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-      attr_set = true;
-    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_gather128p_kernel<1, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
   }
   const bool u4 = (a.lv.reserved_ & 16384) != 0;   // bit 14: 4-step units (A/B, experiments/README.md)
   const bool packed = (a.lv.reserved_ & 65536) != 0;   // bit 16: the packed patch with flat loads (A/B)

@@ -73,6 +73,12 @@ int launch_assemble(const banet_level_t* lv, const AsmPlan& pl, const float* R, 
                     float* nvalid, hipStream_t s, bool reset_queue = true, const banet_mlp_t* role_mlp = nullptr,
                     float* role_y = nullptr);
 int* assemble_queue(const AsmPlan& pl, void* ws);   // the gather's tile-queue heads inside the workspace (or nullptr)
+int profile_ranges(int enable);             // roctx ranges around the launches (banet_profile_ranges)
+struct RangeScope {                         // pushes "banet.<role>[ N=<n>]" when ranges are on
+  bool on;
+  RangeScope(const char* role, int n = -1);
+  ~RangeScope();
+};
 int profile_begin(int max_launches);
 int profile_end(int max_tags, int32_t* tag_points, int32_t* tag_launches, double* tag_ms, int32_t* ntags);
 

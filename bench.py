@@ -20,8 +20,12 @@ HBM.  value = windows * 50 * steps / time over all ranks.  The JSON line also ca
                  chained over the same schedule: single updates from identical states (one GPU iteration from the oracle's
                  level-start state) and the carried state after every level; the bench FAILS above 1e-4 = north_star's
                  tolerance, iteration counts must equal the schedule;
-  cpu_baseline : that same oracle chain timed on the host cores (numpy port) and the float32 torch port with all
-                 intra-op threads (oracle/torch_port.py) -- 1 window x 4 iterations at each of the 5 levels.
+  cpu_baseline : BASELINE.md section 2's protocol on the host cores: the level-0..4 chain at one iteration per level
+                 (window 0), 3 warm-ups + >= 10 timed repeats, median / p10 / p90, numpy port and float32 torch port
+                 (oracle/torch_port.py, all intra-op threads); cfg-1 (160x120, K = 32, 3 iterations) timed the same way.
+
+`python bench.py --gpus N` without a torch.distributed environment launches its own N ranks (torch.distributed.run,
+127.0.0.1); under torchrun it is one rank of the job.  Rank 0 prints the one JSON line.
 """
 import argparse
 import gc
@@ -45,32 +49,40 @@ PARITY_TOL = 1e-4             # BASELINE.json north_star: pose/depth updates wit
 CHAIN_ITERS = [4, 4, 4, 4, 4]
 
 
-def workload_name(frames, B, Hh, Ww, Kk, iters):
+def workload_name(frames, B, Hh, Ww, Kk, iters, nlevels=5):
     pairs = frames - 1
-    if (Hh, Ww, Kk, iters) == (H, W, K, ITERS[0]):
+    tag = "custom"
+    if (Hh, Ww, Kk, iters, nlevels) == (H, W, K, ITERS[0], 5):
         tag = "cfg-2 shape at the metric's batch" if frames == 2 else ("cfg-3 (configs[2])" if frames == 5 else "custom")
-    else:
-        tag = "custom"
+    elif (Hh, Ww, Kk, iters, nlevels, frames) == (120, 160, 32, 3, 1, 2):
+        tag = "cfg-1 (configs[0], the reference's CPU-runnable case)"
+    elif (Hh, Ww, Kk, iters, nlevels, frames) == (960, 1280, 256, 15, 5, 8):
+        tag = "cfg-5 (configs[4]) per-GPU share"
+    pyr = "%d-level pyramid" % nlevels if nlevels > 1 else "single scale"
     if frames == 2:
-        return ("%s: 2-frame %dx%d 5-level pyramid, C=128, K=%d basis, %d LM iters/level, batch %d windows per GPU, "
-                "BundleIteration (bundlenet.py:193-278), dense points" % (tag, Ww, Hh, Kk, iters, B))
-    return ("%s: %d-frame sliding window (key frame + %d target frames sharing depth/basis, P = %d), %dx%d 5-level "
-            "pyramid, C=128, K=%d, %d LM iters/level, batch %d windows per GPU, dense points"
-            % (tag, frames, pairs, 6 * pairs + Kk, Ww, Hh, Kk, iters, B))
+        return ("%s: 2-frame %dx%d %s, C=128, K=%d basis, %d LM iters/level, batch %d windows per GPU, "
+                "BundleIteration (bundlenet.py:193-278), dense points" % (tag, Ww, Hh, pyr, Kk, iters, B))
+    return ("%s: %d-frame sliding window (key frame + %d target frames sharing depth/basis, P = %d), %dx%d %s, "
+            "C=128, K=%d, %d LM iters/level, batch %d windows per GPU, dense points"
+            % (tag, frames, pairs, 6 * pairs + Kk, Ww, Hh, pyr, Kk, iters, B))
 
 
 class Problem:
     """B synthetic windows resident in HBM + the solver object for them."""
 
-    def __init__(self, B, frames, Hh, Ww, Kk, seed, dev, reserved=0):
+    def __init__(self, B, frames, Hh, Ww, Kk, seed, dev, reserved=0, scales=None, cpu_only=False):
         import torch
         from banet_amd import dense as bdense, synth as bsynth
         from banet_amd.bundlenet import he_normal_lambda_weights
         self.B, self.pairs, self.K = B, frames - 1, Kk
+        self.scales = list(SCALES if scales is None else scales)
         torch.manual_seed(seed)
-        self.intr, self.levels, self.gt = bsynth.make_dense_windows(B, Hh, Ww, C, Kk, SCALES, seed + 2, dev, trans_mag=0.06,
+        self.intr, self.levels, self.gt = bsynth.make_dense_windows(B, Hh, Ww, C, Kk, self.scales, seed + 2, dev, trans_mag=0.06,
                                                                     pairs=self.pairs)
-        self.mlps = [he_normal_lambda_weights(C, 100 + i) for i in range(len(SCALES))]
+        self.mlps = [he_normal_lambda_weights(C, 100 + i) for i in range(len(self.scales))]
+        self.T0 = (self.gt["T"] * 0.7).reshape(B * self.pairs, 3, 1).to(dev)
+        if cpu_only:        # the synthetic inputs only (cpu_baseline leg: the oracle is timed on them, no GPU object)
+            return
         self.ba = bdense.DenseBA(self.intr, self.levels, self.mlps, "bundle", 1000.0)
         for prob in self.ba.problems:
             prob.c.reserved_ = reserved
@@ -182,16 +194,80 @@ def timed_run(prob, iters, steps, warmup, total_windows, fence, world=1, dev=Non
     return elapsed, prof, st
 
 
-def sub_record(frames, B, Hh, Ww, Kk, iters_per_level, steps, warmup, seed, dev, fence, reserved):
-    """One sweep entry measured like the headline (smaller step count)."""
+def twin_parity(prob, dev, window=0):
+    """In-line parity of a sweep entry (a kernel selection the headline does not run): window `window` is solved with a
+    [1]*L schedule on the GPU -- the same library calls, the same per-level kernel selection rules at B = 1 are NOT what
+    is wanted, so the single steps are taken by the WHOLE batch's solver object (prob.ba.step_from at every level, all
+    windows, production selection) and window `window` of the result is compared with ONE float64 iteration from the
+    identical start state: oracle/torch_port.window_iteration = the float64 twin of banet_oracle.bundle_window_iteration
+    (pinned to it on the CPU in tests/test_torch_ref_cpu.py; evaluated on the GPU in float64 because the numpy statement
+    needs 25 GB and 90 s per 640x480 5-frame iteration), and -- at levels of <= 19200 pixels -- with the numpy oracle
+    itself in float64.  Gate as the headline's: every coefficient group of the update within 1e-4 relative."""
+    import numpy as np
     import torch
-    prob = Problem(B, frames, Hh, Ww, Kk, seed, dev, reserved)
-    iters = [iters_per_level] * len(SCALES)
+    from oracle import banet_oracle as orc, torch_port
+    ba, pairs, B, Kk = prob.ba, max(prob.pairs, 1), prob.B, prob.K
+    st = ba.new_state(T=prob.T0)
+    R = st.R.reshape(B * pairs, 3, 3).clone()
+    T = st.T.reshape(B * pairs, 3, 1).clone()
+    Wc = st.Wc.clone()
+    w = slice(window, window + 1)
+    o = 6 * pairs
+    per_level, worst = {}, 0.0
+    for li, lv in enumerate(prob.levels):
+        s1 = ba.step_from(li, R.clone(), T.clone(), Wc.clone())
+        torch.cuda.synchronize()
+        tg = lv.tgt if lv.tgt.dim() == 5 else lv.tgt.unsqueeze(1)
+        mlp = [(w_.cpu().numpy(), b_.cpu().numpy()) for w_, b_ in prob.mlps[li]]
+        R2, T2, W2, d = torch_port.window_iteration(prob.intr[w], lv.scale, lv.src[w], tg[w], lv.depth[w], lv.basis[w],
+                                                    R.reshape(B, pairs, 3, 3)[w], T.reshape(B, pairs, 3, 1)[w], Wc[w], mlp, 1000.0)
+
+        def rel(a, b):
+            a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+            return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+        dl, sol = s1.delta[window].cpu().numpy(), d["solution"][0].cpu().numpy()
+        rec = {"step_pose": rel(dl[:o], sol[:o]), "step_depth": rel(dl[o:-1], sol[o:-1]), "step_last": rel(dl[-1:], sol[-1:]),
+               "step_lam": rel(s1.lambda_out[window:window + 1].cpu().numpy(), d["lam"].cpu().numpy()),
+               "R": rel(s1.R.reshape(B, pairs, 3, 3)[window].cpu().numpy(), R2[0].cpu().numpy()),
+               "T": rel(s1.T.reshape(B, pairs, 3, 1)[window].cpu().numpy(), T2[0].cpu().numpy()),
+               "W": rel(s1.Wc[window].cpu().numpy(), W2[0].cpu().numpy())}
+        del d, R2, T2, W2
+        if lv.H * lv.W <= 19200:        # the numpy oracle itself, float64, same start state
+            from oracle import dense as odense
+            f8 = lambda x: x.detach().cpu().numpy().astype(np.float64)  # noqa: E731
+            one = dict(scale=lv.scale, H=lv.H, W=lv.W, src=f8(lv.src[w]), tgt=f8(tg[w][:, 0]), D0=f8(lv.depth[w]), basis=f8(lv.basis[w]))
+            a = odense.level_inputs(f8(prob.intr[w]), one, True, np.float64)
+            conv2s = [orc.target_map(f8(tg[w][:, i])) for i in range(pairs)]
+            Rs = [f8(R.reshape(B, pairs, 3, 3)[w][:, i]) for i in range(pairs)]
+            Ts = [f8(T.reshape(B, pairs, 3, 1)[w][:, i]) for i in range(pairs)]
+            *_, dbg = orc.bundle_window_iteration(a["conv1"], conv2s, a["fx"], a["fy"], a["ox"], a["oy"], a["p"], a["D"], a["Bs"],
+                                                  Rs, Ts, f8(Wc[w]), mlp, 1000.0, eq=orc.equation_construction_gemm)
+            so = dbg["solution"][0, :, 0]
+            rec.update(oracle64_step_pose=rel(dl[:o], so[:o]), oracle64_step_depth=rel(dl[o:-1], so[o:-1]),
+                       oracle64_step_last=rel(dl[-1:], so[-1:]))
+        per_level["%dx%d" % (lv.W, lv.H)] = {k: float("%.3e" % v) for k, v in rec.items()}
+        worst = max(worst, max(rec.values()))
+        R, T, Wc = s1.R.reshape(B * pairs, 3, 3).clone(), s1.T.reshape(B * pairs, 3, 1).clone(), s1.Wc.clone()   # the GPU's own chain
+        torch.cuda.empty_cache()
+    return {"against": "ONE iteration per level from the identical start state (schedule [1]*%d chained on the GPU, the batch's own "
+                       "kernel selection): oracle/torch_port.window_iteration in float64 (twin of banet_oracle.bundle_window_"
+                       "iteration, pinned on the CPU) at every level + the numpy oracle in float64 where a level has <= 19200 "
+                       "pixels (oracle64_*)" % len(prob.levels),
+            "window": window, "tolerance": PARITY_TOL, "max_rel_err": float("%.3e" % worst), "ok": bool(worst <= PARITY_TOL),
+            "per_level": per_level}
+
+
+def sub_record(frames, B, Hh, Ww, Kk, iters_per_level, steps, warmup, seed, dev, fence, reserved, scales=None, parity=True):
+    """One sweep entry measured like the headline (smaller step count) + its own in-line parity record."""
+    import torch
+    prob = Problem(B, frames, Hh, Ww, Kk, seed, dev, reserved, scales)
+    nl = len(prob.scales)
+    iters = [iters_per_level] * nl
     elapsed, prof, st = timed_run(prob, iters, steps, warmup, B, fence)
     chk = prob.convergence_check(st, dev)
     rl = roofline_record(prob, prof, elapsed)
-    step_bytes = sum(prob.ba.algorithmic_bytes_per_iteration(li) for li in range(len(SCALES))) * B * iters_per_level
-    rec = {"workload": workload_name(frames, B, Hh, Ww, Kk, iters_per_level), "windows": B, "frames": frames,
+    step_bytes = sum(prob.ba.algorithmic_bytes_per_iteration(li) for li in range(nl)) * B * iters_per_level
+    rec = {"workload": workload_name(frames, B, Hh, Ww, Kk, iters_per_level, nl), "windows": B, "frames": frames,
            "value": round(B * sum(iters) * steps / elapsed, 2), "unit": "LM iterations/s", "steps": steps, "warmup": warmup,
            "ms_per_step": round(1e3 * elapsed / steps, 3), "ms_per_solve": round(1e3 * elapsed / steps / B, 3),
            "end_to_end_hbm_frac": round(step_bytes / (elapsed / steps) / 1e9 / HBM_PEAK_GBS, 4),
@@ -199,36 +275,44 @@ def sub_record(frames, B, Hh, Ww, Kk, iters_per_level, steps, warmup, seed, dev,
            "roofline": {k: rl[k] for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "kernel_time_share",
                                            "syrk_kernel", "per_level")},
            "check": chk}
+    if parity:
+        rec["parity"] = twin_parity(prob, dev)
     del prob, st
     gc.collect()
     torch.cuda.empty_cache()
     return rec
 
 
-def parity_and_cpu_baseline(prob, dev, want_baseline):
-    """Window 0 of the headline problem: the GPU solve with the [4]*5 schedule vs the numpy oracle chained over the same
-    schedule (parity), the chain's wall time = the CPU baseline (numpy port), plus the float32 torch port with all
-    host threads on the same chain."""
+def _percentiles(secs):
+    import numpy as np
+    a = np.sort(np.asarray(secs, np.float64))
+    return float(np.median(a)), float(np.percentile(a, 10)), float(np.percentile(a, 90))
+
+
+def chain_parity_record(prob, dev, window):
+    """Window `window` of the headline problem: the GPU solve with the [4]*5 schedule vs the numpy oracle chained over the
+    same schedule (oracle/dense.py::bundle_chain + chain_parity).  Returns (record, oracle-side inputs for the CPU timing)."""
     import numpy as np
     import torch
     from banet_amd import dense as bdense
     from oracle import dense as odense
-    lv1 = [bdense.DenseLevel(l.scale, l.src[0:1].contiguous(), l.tgt[0:1].contiguous(), l.depth[0:1].contiguous(),
-                             l.basis[0:1].contiguous()) for l in prob.levels]
-    ba1 = bdense.DenseBA(prob.intr[0:1].contiguous(), lv1, prob.mlps, "bundle", 1000.0)
-    st = ba1.new_state(T=prob.T0[0:1].contiguous())
+    w = slice(window, window + 1)
+    lv1 = [bdense.DenseLevel(l.scale, l.src[w].contiguous(), l.tgt[w].contiguous(), l.depth[w].contiguous(),
+                             l.basis[w].contiguous()) for l in prob.levels]
+    ba1 = bdense.DenseBA(prob.intr[w].contiguous(), lv1, prob.mlps, "bundle", 1000.0)
+    st = ba1.new_state(T=prob.T0[w].contiguous())
     snaps = []
     _, cnts = ba1.solve(CHAIN_ITERS, st, snapshots=snaps)
     torch.cuda.synchronize()
     counts_run = [int(c[0]) for c in cnts]
     assert counts_run == CHAIN_ITERS, "iteration counts differ from the schedule: %s" % counts_run
     gpu = [{k: v.cpu().numpy() for k, v in s.items()} for s in snaps]
-    intr = prob.intr[0:1].cpu().numpy()
+    intr = prob.intr[w].cpu().numpy()
     nlv = [dict(scale=l.scale, H=l.H, W=l.W, src=l.src.cpu().numpy(), tgt=l.tgt.cpu().numpy(), D0=l.depth.cpu().numpy(),
                 basis=l.basis.cpu().numpy()) for l in lv1]
-    mlps = [[(np.asarray(w.cpu()), np.asarray(b.cpu())) for w, b in lw] for lw in prob.mlps]
+    mlps = [[(np.asarray(w_.cpu()), np.asarray(b_.cpu())) for w_, b_ in lw] for lw in prob.mlps]
     R0 = np.eye(3, dtype=np.float32)[None]
-    T0 = prob.T0[0:1].cpu().numpy().reshape(1, 3, 1)
+    T0 = prob.T0[w].cpu().numpy().reshape(1, 3, 1)
     W0 = np.zeros((1, prob.K, 1), np.float32)
     ref, sec_np = odense.bundle_chain(intr, nlv, mlps, CHAIN_ITERS, R0, T0, W0, engine="numpy", truth=True)
     # single updates from identical states: one GPU iteration from the oracle's state at the start of every level
@@ -241,16 +325,36 @@ def parity_and_cpu_baseline(prob, dev, want_baseline):
     bad = odense.parity_failures(per_level, PARITY_TOL)
     worst = max(max(r[k] for k in ("R", "T", "W", "step_pose", "step_depth", "step_last")) for r in per_level)
     names = ["%dx%d" % (l.W, l.H) for l in lv1]
-    parity = {"against": "oracle.banet_oracle.bundle_iteration, window 0, schedule %s: float32 chain for the carried state, "
-                         "float64 for the single steps" % CHAIN_ITERS,
-              "tolerance": PARITY_TOL, "max_rel_err": float("%.3e" % worst), "ok": not bad,
-              "failures": [[names[li], k, float("%.3e" % v)] for li, k, v in bad], "iters": [int(c) for c in counts_run],
+    rec = {"window": window, "max_rel_err": float("%.3e" % worst), "ok": not bad,
+           "failures": [[names[li], k, float("%.3e" % v)] for li, k, v in bad], "iters": [int(c) for c in counts_run],
+           "per_level": {nm: {k: float("%.3e" % v) for k, v in r.items()} for nm, r in zip(names, per_level)}}
+    return rec, dict(intr=intr, nlv=nlv, mlps=mlps, R0=R0, T0=T0, W0=W0, ref=ref, sec_np=sec_np)
+
+
+def parity_and_cpu_baseline(prob, dev, want_baseline, scenes=(0, 1)):
+    """Headline parity (windows `scenes` = different synthetic scenes / poses, the worst is reported) and the CPU baseline."""
+    import numpy as np
+    import torch
+    from oracle import dense as odense
+    recs, side = [], None
+    for wdw in scenes:
+        if wdw >= prob.B:
+            break
+        r, sd = chain_parity_record(prob, dev, wdw)
+        recs.append(r)
+        side = side or sd
+    worst = max(r["max_rel_err"] for r in recs)
+    parity = {"against": "oracle.banet_oracle.bundle_iteration, schedule %s: float32 chain for the carried state, float64 for the "
+                         "single steps; %d scenes (windows %s of the timed batch: different fields, poses, depth coefficients), "
+                         "the worst is max_rel_err" % (CHAIN_ITERS, len(recs), [r["window"] for r in recs]),
+              "tolerance": PARITY_TOL, "max_rel_err": worst, "ok": all(r["ok"] for r in recs),
+              "failures": [f for r in recs for f in r["failures"]], "iters": recs[0]["iters"],
               "note": "R/T/W = carried state after the level's chained iterations vs the float32 oracle chain; step_<group> = "
                       "ONE iteration from the oracle's state at the start of the level (the same system on both sides) vs the "
                       "float64 oracle, per coefficient group (pose / damped depth / the undamped last coefficient, "
                       "bundlenet.py:264-266); *_ref32 = the float32 oracle's own error against float64, *_vs32 = GPU vs float32 "
                       "oracle (gate: <= max(tol, 2 x ref32)); update_* reported only (oracle/dense.py::chain_parity)",
-              "per_level": {nm: {k: float("%.3e" % v) for k, v in r.items()} for nm, r in zip(names, per_level)}}
+              "per_level": recs[0]["per_level"], "scenes": recs}
     base = None
     if want_baseline:
         try:
@@ -258,24 +362,71 @@ def parity_and_cpu_baseline(prob, dev, want_baseline):
             blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
         except Exception:
             blas_threads = os.cpu_count() or 1
-        n_it = sum(CHAIN_ITERS)
-        tref, sec_t = odense.bundle_chain(intr, nlv, mlps, CHAIN_ITERS, R0, T0, W0, engine="torch")
-        port_vs_oracle = max(max(r[k] for k in ("R", "T", "W")) for r in odense.chain_parity(tref, ref))
-        v_np, v_t = n_it / sec_np, n_it / sec_t
-        best = "torch" if v_t >= v_np else "numpy"
-        base = {"value": round(max(v_np, v_t), 4), "unit": "LM iterations/s",
+        intr, nlv, mlps, R0, T0, W0 = (side[k] for k in ("intr", "nlv", "mlps", "R0", "T0", "W0"))
+        # the torch port agrees with the numpy oracle (it is timed, so it must be the same computation)
+        tref, _sec_t = odense.bundle_chain(intr, nlv, mlps, [1] * len(nlv), R0, T0, W0, engine="torch")
+        nref, _sec_n = odense.bundle_chain(intr, nlv, mlps, [1] * len(nlv), R0, T0, W0, engine="numpy")
+        port_vs_oracle = max(max(r[k] for k in ("R", "T", "W")) for r in odense.chain_parity(tref, nref))
+        WARM, REPS = 3, 10
+        eng = {}
+        for name in ("numpy", "torch"):
+            # one probe repeat decides which engine gets the full protocol (the slower one: 1 warm-up + 3 repeats)
+            probe, n_it = odense.chain_repeat_timer(intr, nlv, mlps, R0, T0, W0, name, 0, 1)
+            eng[name] = dict(probe=probe[0], n_it=n_it)
+        fast = min(eng, key=lambda k: eng[k]["probe"])
+        for name in ("numpy", "torch"):
+            warm, reps = (WARM, REPS) if name == fast else (1, 3)
+            secs, n_it = odense.chain_repeat_timer(intr, nlv, mlps, R0, T0, W0, name, warm, reps)
+            med, p10, p90 = _percentiles(secs)
+            eng[name].update(value=round(n_it / med, 4), median_s=round(med, 4), p10_s=round(p10, 4), p90_s=round(p90, 4),
+                             repeats=reps, warmups=warm)
+        # cfg-1 = configs[0], "the reference's own CPU-runnable case": 160x120 single scale, K = 32, 3 LM iterations, B = 1
+        c1 = Problem(1, 2, 120, 160, 32, 977, "cpu", scales=[1], cpu_only=True)
+        c1l = [dict(scale=l.scale, H=l.H, W=l.W, src=l.src.numpy(), tgt=l.tgt.numpy(), D0=l.depth.numpy(), basis=l.basis.numpy())
+               for l in c1.levels]
+        c1m = [[(np.asarray(w_), np.asarray(b_)) for w_, b_ in lw] for lw in c1.mlps]
+        c1T0 = c1.T0.numpy().reshape(1, 3, 1)
+        c1rec = {}
+        for name in ("numpy", "torch"):
+            secs, n_it = odense.chain_repeat_timer(c1.intr.numpy(), c1l, c1m, R0, c1T0, np.zeros((1, 32, 1), np.float32), name,
+                                                   WARM, REPS, iters_per_level=3)
+            med, p10, p90 = _percentiles(secs)
+            c1rec[name] = {"value": round(n_it / med, 3), "ms_per_solve": round(1e3 * med, 3), "p10_ms": round(1e3 * p10, 3),
+                           "p90_ms": round(1e3 * p90, 3), "repeats": REPS, "warmups": WARM}
+        best = fast
+        base = {"value": eng[best]["value"], "unit": "LM iterations/s",
                 "cores": int(torch.get_num_threads() if best == "torch" else blas_threads), "kind": "port",
                 "host_cpus": os.cpu_count(), "engine": best,
-                "numpy_port": {"value": round(v_np, 4), "seconds": round(sec_np, 2), "blas_threads": int(blas_threads),
-                               "note": "oracle/banet_oracle.bundle_iteration, GEMM-arranged normal equations, BLAS-threaded "
-                                       "matmuls, single-threaded elementwise"},
-                "torch_port": {"value": round(v_t, 4), "seconds": round(sec_t, 2), "threads": int(torch.get_num_threads()),
-                               "max_rel_diff_vs_numpy_oracle": float("%.3e" % port_vs_oracle),
-                               "note": "oracle/torch_port.bundle_iteration, float32, torch intra-op threads = all host cores, "
-                                       "normal equations from the per-pixel 2x2 M (never materialises J)"},
-                "sample": "1 window x %d chained LM iterations at each of the 5 levels (20 LM iterations) of the same synthetic "
-                          "640x480 C=128 K=128 workload, window 0 of the timed batch" % CHAIN_ITERS[0]}
+                "median_s": eng[best]["median_s"], "p10_s": eng[best]["p10_s"], "p90_s": eng[best]["p90_s"],
+                "repeats": eng[best]["repeats"], "warmups": eng[best]["warmups"],
+                "ms_per_solve_extrapolated": round(1e3 * sum(ITERS) / eng[best]["value"], 1),
+                "numpy_port": dict({k: v for k, v in eng["numpy"].items() if k not in ("probe", "n_it")}, blas_threads=int(blas_threads),
+                                   note="oracle/banet_oracle.bundle_iteration, GEMM-arranged normal equations, BLAS-threaded "
+                                        "matmuls, single-threaded elementwise"),
+                "torch_port": dict({k: v for k, v in eng["torch"].items() if k not in ("probe", "n_it")},
+                                   threads=int(torch.get_num_threads()), max_rel_diff_vs_numpy_oracle=float("%.3e" % port_vs_oracle),
+                                   note="oracle/torch_port.bundle_iteration, float32, torch intra-op threads = all host cores, "
+                                        "normal equations from the per-pixel 2x2 M (never materialises J)"),
+                "cfg1_160x120_K32_3iters": dict(c1rec, workload=workload_name(2, 1, 120, 160, 32, 3, 1)),
+                "sample": "BASELINE.md section 2: the level-0..4 chain of the same synthetic 640x480 C=128 K=128 workload (window 0 of "
+                          "the timed batch) at ONE LM iteration per level (5 LM iterations per repeat), every repeat from the same "
+                          "start state, per-level preparation excluded; %d warm-ups + %d timed repeats for the faster port "
+                          "(1 + 3 for the other), value = 5 / median; ms_per_solve_extrapolated = 50 iterations at that rate" % (WARM, REPS)}
     return parity, base
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` outside a torch.distributed environment: become the launcher of N ranks on this node."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -291,11 +442,15 @@ def main():
     ap.add_argument("--basis", type=int, default=K, help="depth-basis coefficients K")
     ap.add_argument("--iters", type=int, default=ITERS[0], help="LM iterations per level")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-sweep", action="store_true", help="skip the B = 1 / 8 / cfg-3 sub-records")
-    ap.add_argument("--no-parity", action="store_true", help="skip the in-line oracle parity record")
-    ap.add_argument("--no-sweep-large", action="store_true", help="leave B = 256 two-frame windows (161 GB of inputs) out of the sweep")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the sub-records (B = 1 / 8 / 256, cfg-1, cfg-3, cfg-5 share)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the in-line oracle parity records")
+    ap.add_argument("--no-sweep-large", action="store_true", help="leave B = 256 two-frame windows (161 GB of inputs) and the "
+                    "cfg-5 share (8 x 8-frame 1280x960 K=256 windows, 67 GB) out of the sweep")
     ap.add_argument("--reserved", type=int, default=0, help="development: banet_level_t.reserved_ bits for every level (A/B switches)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -304,9 +459,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
     # development overrides (to exercise the multi-rank path on a one-GPU box): BANET_BENCH_DEVICE pins every rank to one
     # device, BANET_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU)
+    ndev = torch.cuda.device_count()
+    if "BANET_BENCH_DEVICE" not in os.environ and world > ndev:
+        raise SystemExit("bench.py: --gpus %d but only %d device(s) visible; to exercise the multi-rank path on fewer GPUs set "
+                         "BANET_BENCH_DEVICE=0 BANET_BENCH_BACKEND=gloo (ranks then share a device: not a scaling measurement)"
+                         % (world, ndev))
     dev_index = int(os.environ.get("BANET_BENCH_DEVICE", local_rank))
     backend = os.environ.get("BANET_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(dev_index)
@@ -338,17 +498,27 @@ def main():
     check = prob.convergence_check(st, dev)
 
     if rank == 0:
+        from banet_amd import _capi
+        build_id = _capi.lib().banet_build_id().decode()
         iters_per_step = sum(iters)
         value = total_windows * iters_per_step * args.steps / elapsed
-        traffic = None
+        traffic, traffic_note = None, "no PMC pass on file for this workload"
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc) and headline:    # the PMC pass is taken on the headline workload
             try:
                 pj = json.load(open(pmc))
-                traffic = pj.get("hbm_bytes_per_launch") if pj.get("windows") == B else None
-            except Exception:
-                traffic = None
+                if pj.get("windows") != B:
+                    traffic_note = "profiles/pmc_traffic.json is for %s windows" % pj.get("windows")
+                elif pj.get("build_id") != build_id:
+                    traffic_note = ("profiles/pmc_traffic.json was recorded on build %s, this library is build %s: refused"
+                                    % (pj.get("build_id"), build_id))
+                else:
+                    traffic = pj.get("hbm_bytes_per_launch")
+                    traffic_note = "rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE passes of this build (tools/gpu_final_round.sh)"
+            except Exception as e:  # noqa: BLE001
+                traffic_note = "profiles/pmc_traffic.json unreadable: %s" % e
         rl = roofline_record(prob, prof, elapsed, traffic)
+        rl["traffic_note"] = traffic_note
         step_bytes = sum(prob.ba.algorithmic_bytes_per_iteration(li) for li in range(len(SCALES))) * B * args.iters
         out = {
             "metric": "LM iterations/sec (%d-frame %dx%d 5-level dense BA, %d-coeff depth basis, batch %d)" % (
@@ -360,7 +530,10 @@ def main():
             "config": {"workload": workload_name(args.frames, B, Hh, Ww, Kk, args.iters),
                        "windows_per_gpu": B, "windows_total": total_windows, "iters_per_level": iters, "scales": SCALES,
                        "shape": {"H": Hh, "W": Ww, "C": C, "K": Kk, "frames": args.frames},
-                       "parallelism": "windows sharded, dp%d" % world},
+                       "parallelism": "windows sharded, dp%d" % world,
+                       "world_size": world, "backend": (backend if world > 1 else None), "devices_visible": ndev,
+                       "ranks_share_a_device": bool(world > 1 and "BANET_BENCH_DEVICE" in os.environ)},
+            "build_id": build_id,
             "check": dict(check, note="random-init lambda MLP and l2_regularizer_base = 1000 (bundlenet.py:393) damp every step "
                                       "heavily, so 50 iterations move the estimate only slightly; correctness is the `parity` "
                                       "record, not this"),
@@ -379,14 +552,31 @@ def main():
             torch.cuda.empty_cache()
             if headline and not args.no_sweep:
                 sweep = {}
-                for name, fr, bb, stp in (("B1_2frame", 2, 1, 4), ("B8_2frame", 2, 8, 4), ("cfg3_5frame_B32", 5, 32, 2)):
-                    sweep[name] = sub_record(fr, bb, H, W, K, ITERS[0], stp, 1, 4321, dev, fence, args.reserved)
-                if not args.no_sweep_large:      # 161 GB of inputs in the 288 GB of HBM; ~12 s including synthesis
-                    sweep["B256_2frame"] = sub_record(2, 256, H, W, K, ITERS[0], 2, 1, 4321, dev, fence, args.reserved)
+                par = not args.no_parity
+                #            name                frames B   H    W     K   iters steps warm scales
+                entries = [("cfg1_160x120_K32_B1", 2,   1,  120, 160,  32,  3,   20,   3,   [1]),
+                           ("B1_2frame",           2,   1,  H,   W,    K,   10,  5,    1,   None),
+                           ("B8_2frame",           2,   8,  H,   W,    K,   10,  5,    1,   None),
+                           ("cfg3_5frame_B32",     5,   32, H,   W,    K,   10,  5,    1,   None)]
+                if not args.no_sweep_large:      # 161 GB / 67 GB of inputs in the 288 GB of HBM
+                    entries += [("B256_2frame",    2,   256, H,  W,    K,   10,  2,    1,   None),
+                                ("cfg5_8frame_1280x960_K256_B8", 8, 8, 960, 1280, 256, 15, 2, 1, None)]
+                for name, fr, bb, hh, ww, kk, it, stp, wu, sc in entries:
+                    sweep[name] = sub_record(fr, bb, hh, ww, kk, it, stp, wu, 4321, dev, fence, args.reserved, sc, par)
                 out["sweep"] = sweep
+                out["co_headline"] = {"cfg3_5frame_B32": {k: sweep["cfg3_5frame_B32"][k] for k in ("value", "unit", "ms_per_step", "steps")},
+                                      "note": "configs[2] is the only configuration BASELINE.json quotes literally at batch 32 on one "
+                                              "MI355X; reported beside the 2-frame headline"}
         print(json.dumps(out), flush=True)
+        bad = []
         if "parity" in out and not out["parity"]["ok"]:
-            print("bench.py: parity against the oracle FAILED: %s" % json.dumps(out["parity"]), file=sys.stderr, flush=True)
+            bad.append(("headline", out["parity"]))
+        for name, rec in out.get("sweep", {}).items():
+            if "parity" in rec and not rec["parity"]["ok"]:
+                bad.append((name, rec["parity"]))
+        if bad:
+            for name, rec in bad:
+                print("bench.py: parity against the oracle FAILED (%s): %s" % (name, json.dumps(rec)), file=sys.stderr, flush=True)
             if world > 1:
                 dist.destroy_process_group()
             sys.exit(3)

@@ -280,6 +280,14 @@ int banet_target_map_adjoint_f32(const float* dmap3, float* dimg, int B, int H, 
 int banet_profile_begin(int max_launches);
 int banet_profile_end(int max_tags, int32_t* tag_points, int32_t* tag_launches, double* tag_ms,
                       int32_t* ntags);
+/*   banet_build_id: a 16-hex-digit digest of the kernel sources + compile flags this library was built from (build.sh).
+ *     Measurement provenance only: bench.py refuses a PMC traffic file (profiles/pmc_traffic.json) recorded on another build.
+ *   banet_profile_ranges: 1 = wrap every kernel launch of the assembly / solve path in a roctx range ("banet.gather N=...",
+ *     "banet.syrk", "banet.fold", "banet.reduce", "banet.solve") so that `rocprofv3 --marker-trace` groups the kernels by
+ *     role (the reference has no tracing hooks at all).  Returns 0 when the roctx library could not be
+ *     loaded.  Off by default; also enabled by the environment variable BANET_ROCTX=1.                                     */
+const char* banet_build_id(void);
+int banet_profile_ranges(int enable);
 
 #ifdef __cplusplus
 }

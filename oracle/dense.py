@@ -246,3 +246,39 @@ def parity_failures(per_level, tol=1e-4):
         if "step_lam" in r and not r["step_lam"] <= tol:
             bad.append((li, "step_lam", r["step_lam"]))
     return bad
+
+
+def chain_repeat_timer(intr, levels, mlps, R0, T0, W0, engine, warmups, repeats, iters_per_level=1, l2_base=1000.0):
+    """BASELINE.md section 2's CPU protocol: the coarse->fine chain with `iters_per_level` BundleIterations at every level,
+    run `warmups` untimed + `repeats` timed times from the SAME start state (identical work every repeat); per-level
+    preparation (rays, the [f|gx|gy] target map -- once per level in the reference too, bundlenet.py:376-385) is done once
+    and excluded.  engine "numpy" = banet_oracle.bundle_iteration (GEMM-arranged normal equations), "torch" =
+    torch_port.bundle_iteration (float32, all intra-op threads).  Returns (seconds_per_repeat list, LM iterations per repeat)."""
+    import time
+    dtype = np.float32
+    if engine == "numpy":
+        preps = [level_inputs(intr, lv, True, dtype) for lv in levels]
+    else:
+        import torch
+        from . import torch_port
+        f = lambda x: torch.from_numpy(np.ascontiguousarray(x))  # noqa: E731
+        preps = [torch_port.prepare_level(f(intr), float(lv["scale"]), f(lv["src"]), f(lv["tgt"]), f(lv["D0"]), f(lv["basis"]))
+                 for lv in levels]
+    secs = []
+    for rep in range(warmups + repeats):
+        t0 = time.perf_counter()
+        if engine == "numpy":
+            R, T, W = R0.astype(dtype), T0.astype(dtype), W0.astype(dtype)
+            for a, mlp in zip(preps, mlps):
+                for _ in range(iters_per_level):
+                    R, T, W, _dbg = orc.bundle_iteration(a["conv1"], a["conv2"], a["fx"], a["fy"], a["ox"], a["oy"], a["p"], a["D"],
+                                                         a["Bs"], R, T, W, mlp, l2_base, eq=orc.equation_construction_gemm)
+        else:
+            R, T, W = f(R0.astype(dtype)), f(T0.astype(dtype)), f(W0.astype(dtype))
+            for L, mlp in zip(preps, mlps):
+                for _ in range(iters_per_level):
+                    R, T, W, _dbg = torch_port.bundle_iteration(None, None, None, None, None, None, R, T, W, mlp, l2_base, level=L)
+        dt = time.perf_counter() - t0
+        if rep >= warmups:
+            secs.append(dt)
+    return secs, iters_per_level * len(levels)

@@ -160,3 +160,62 @@ def bundle_iteration(intr, scale, src, tgt, depth, basis, R, T, Wc, mlp, l2_base
     Tn = torch.matmul(V, sol[:, 3:6]) + torch.matmul(Rw, T)
     Wn = Wc.to(dtype).reshape(B, -1, 1) + sol[:, 6:]
     return Rn, Tn, Wn, dict(lam=lam.reshape(-1), solution=sol)
+
+
+# --------------------------------------------------------------------------------------
+# multi-frame windows (restated in banet_oracle.bundle_window_iteration)
+# --------------------------------------------------------------------------------------
+def window_assemble(intr, scale, src, tgts, depth, basis, Rs, Ts, Wc, normalize_rays=True, dtype=torch.float64):
+    """Normal equations of one multi-frame window at the poses (Rs, Ts) and depth coefficients Wc, composed from the
+    per-pair assemblies exactly as banet_oracle.bundle_window_iteration stacks its rows: parameter order
+    [pose_1 .. pose_pairs, depth]; pose blocks on the diagonal, each pair's pose/depth cross block, the depth block and
+    Atb_depth summed over the pairs (block-arrowhead).  tgts [B,pairs,H,W,C]; Rs [B,pairs,3,3]; Ts [B,pairs,3,1].
+    -> AtA [B,P,P], Atb [B,P], absres [B,C] (sum over pairs and pixels), nvalid [B,pairs].  One pair at a time, so the
+    full BASELINE sizes (640x480 x 4 pairs, 1280x960 x 7 pairs with K = 256) fit in memory in float64."""
+    B, pairs = tgts.shape[0], tgts.shape[1]
+    K = basis.shape[-1]
+    C = src.shape[-1]
+    P = 6 * pairs + K
+    dev = src.device
+    AtA = torch.zeros(B, P, P, dtype=dtype, device=dev)
+    Atb = torch.zeros(B, P, dtype=dtype, device=dev)
+    absres = torch.zeros(B, C, dtype=dtype, device=dev)
+    nvalid = torch.zeros(B, pairs, dtype=dtype, device=dev)
+    o = 6 * pairs
+    for i in range(pairs):
+        L = prepare_level(intr, scale, src, tgts[:, i], depth, basis, normalize_rays, dtype)
+        A, b, ab, nv = assemble_prepared(L, Rs[:, i], Ts[:, i], Wc, True)
+        del L
+        AtA[:, 6 * i:6 * i + 6, 6 * i:6 * i + 6] = A[:, :6, :6]
+        AtA[:, 6 * i:6 * i + 6, o:] = A[:, :6, 6:]
+        AtA[:, o:, 6 * i:6 * i + 6] = A[:, 6:, :6]
+        AtA[:, o:, o:] += A[:, 6:, 6:]
+        Atb[:, 6 * i:6 * i + 6] = b[:, :6]
+        Atb[:, o:] += b[:, 6:]
+        absres += ab
+        nvalid[:, i] = nv
+    return AtA, Atb, absres, nvalid
+
+
+def window_iteration(intr, scale, src, tgts, depth, basis, Rs, Ts, Wc, mlp, l2_base=1000.0, dtype=torch.float64):
+    """One multi-frame BundleIteration (banet_oracle.bundle_window_iteration: lambda from the residual averaged over all
+    pairs, last coefficient undamped, LU solve, per-frame SE(3) update) -> (Rs', Ts', W', dict(lam, solution, AtA, Atb))."""
+    B, pairs = tgts.shape[0], tgts.shape[1]
+    N = src.shape[1] * src.shape[2]
+    AtA, Atb, absres, _nv = window_assemble(intr, scale, src, tgts, depth, basis, Rs, Ts, Wc, True, dtype)
+    avg = (absres / (N * pairs)).unsqueeze(1)
+    mlp = [(torch.as_tensor(w).cpu().numpy() if not hasattr(w, "numpy") else w.cpu().numpy(),
+            torch.as_tensor(b).cpu().numpy() if not hasattr(b, "numpy") else b.cpu().numpy()) for w, b in mlp]
+    y = lambda_mlp(avg.cpu(), mlp).to(avg.device)
+    lam = l2_base * torch.sqrt((avg * avg).sum(-1, keepdim=True)) ** (2.0 + y)
+    diag = torch.diagonal(AtA, dim1=1, dim2=2)
+    damp = torch.cat([(diag[:, :-1] + 1e-5) * lam[:, 0], torch.zeros(B, 1, dtype=dtype, device=AtA.device)], dim=-1)
+    sol = torch.linalg.solve(AtA + torch.diag_embed(damp), Atb.unsqueeze(-1))
+    Rn, Tn = [], []
+    for i in range(pairs):
+        Rw, V = _rodrigues(sol[:, 6 * i:6 * i + 3, 0].cpu())
+        Rw, V = Rw.to(AtA.device), V.to(AtA.device)
+        Rn.append(torch.matmul(Rw, Rs[:, i].to(dtype)))
+        Tn.append(torch.matmul(V, sol[:, 6 * i + 3:6 * i + 6]) + torch.matmul(Rw, Ts[:, i].to(dtype).reshape(B, 3, 1)))
+    Wn = Wc.to(dtype).reshape(B, -1, 1) + sol[:, 6 * pairs:]
+    return torch.stack(Rn, 1), torch.stack(Tn, 1), Wn, dict(lam=lam.reshape(-1), solution=sol[..., 0], AtA=AtA, Atb=Atb)

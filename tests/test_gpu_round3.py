@@ -1,0 +1,160 @@
+"""Round-3 GPU parity tests (`-m gpu`, all through the C ABI of libbanet_hip.so).
+
+* BASELINE.json's multi-frame configurations at THEIR full size, with the production kernel selection (no forced
+  switches): one 640x480 level of cfg-3's 5-frame windows (C = K = 128, P = 152) and one 1280x960 level of cfg-5's
+  8-frame windows (K = 256, P = 298) against the float64 twin of the oracle's window iteration
+  (oracle/torch_port.window_iteration, pinned to banet_oracle.bundle_window_iteration on the CPU in
+  tests/test_torch_ref_cpu.py): normal equations, lambda, and ONE update from an identical state per coefficient group;
+* the SYRK's bf16x6 emulation with basis columns spanning 2^12 in magnitude (a dropped cross term of the split shows up
+  as an error of 2^-16 .. 2^-8 of an entry's own scale, far above the gate);
+* the losses and rotation2quaternion of bundlenet.py:6-15,401-463 ON THE GPU against the reference's own golden output;
+* the second scene of bench.py's in-line parity record (another seed, stronger motion).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import banet_oracle as orc, torch_port
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from banet_amd import _capi
+    _capi.lib()                                   # fail loudly if the HIP library is missing
+
+
+def n(x):
+    return x.detach().cpu().numpy()
+
+
+def relerr(got, want):
+    want = np.asarray(want, np.float64)
+    got = np.asarray(got, np.float64)
+    return float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-30))
+
+
+def _window_level_check(B, H, W, C, K, pairs, seed, tol_step=1e-4):
+    """one full-resolution level of B multi-frame windows: assembly and one LM update vs the float64 twin"""
+    from banet_amd import dense as bdense, ops, synth as bsynth
+    from banet_amd.bundlenet import he_normal_lambda_weights
+    torch.manual_seed(seed)
+    intr, levels, gt = bsynth.make_dense_windows(B, H, W, C, K, [1], seed, DEV, trans_mag=0.06, pairs=pairs)
+    lv = levels[0]
+    mlps = [he_normal_lambda_weights(C, 100)]
+    ba = bdense.DenseBA(intr, levels, mlps, "bundle", 1000.0)
+    assert ba.pairs == pairs and ba.problems[0].P == 6 * pairs + K
+    g = torch.Generator().manual_seed(seed + 1)
+    R = torch.stack([torch.stack([bsynth._rodrigues((torch.rand(3, generator=g) * 2 - 1) * 0.003) for _ in range(pairs)])
+                     for _ in range(B)]).to(DEV)
+    T = (gt["T"] * 0.7).reshape(B, pairs, 3, 1).to(DEV)
+    Wc = (torch.randn(B, K, 1, generator=g) * 0.004).to(DEV)
+    AtA, Atb, absres, nvalid = ops.ba_assemble(ba.problems[0], R, T, Wc)
+    st = ba.step_from(0, R.reshape(B * pairs, 3, 3).clone(), T.reshape(B * pairs, 3, 1).clone(), Wc.clone())
+    torch.cuda.synchronize()
+    out = []
+    for b in range(B):                              # one window at a time (float64 memory)
+        sl = slice(b, b + 1)
+        R2, T2, W2, d = torch_port.window_iteration(intr[sl], lv.scale, lv.src[sl], lv.tgt[sl], lv.depth[sl], lv.basis[sl],
+                                                    R[sl], T[sl], Wc[sl], [(n(w), n(bb)) for w, bb in mlps[0]], 1000.0)
+        A64, b64 = n(d["AtA"][0]), n(d["Atb"][0])
+        eA, eb = relerr(n(AtA[b]), A64), relerr(n(Atb[b]), b64)
+        assert eA < 3e-5 and eb < 3e-5, (b, eA, eb)
+        got = n(AtA[b])
+        np.testing.assert_array_equal(got, got.T)
+        sol = n(d["solution"][0])
+        dl = n(st.delta[b])
+        o = 6 * pairs
+        e_lam = relerr(n(st.lambda_out[b:b + 1]), n(d["lam"]))
+        e_pose, e_depth, e_last = relerr(dl[:o], sol[:o]), relerr(dl[o:-1], sol[o:-1]), relerr(dl[-1:], sol[-1:])
+        out.append((eA, eb, e_lam, e_pose, e_depth, e_last))
+        assert e_lam < 1e-4 and e_pose < tol_step and e_depth < tol_step and e_last < tol_step, (b, out[-1])
+        assert relerr(n(st.R[b]), n(R2[0])) < 1e-5 and relerr(n(st.T[b]), n(T2[0])) < 1e-4 and relerr(n(st.Wc[b]), n(W2[0])) < 1e-4
+        del d, R2, T2, W2
+        torch.cuda.empty_cache()
+    print("window level %dx%d K=%d pairs=%d: (AtA, Atb, lam, pose, depth, last) =" % (W, H, K, pairs), out)
+    return ba
+
+
+def test_cfg3_full_size_level_matches_float64_twin():
+    """configs[2]: 5-frame windows, 640x480, C = K = 128 -- the finest level at full size, two windows so that the
+    production selection is the one bench.py's cfg-3 record runs (patch gather with the pair loop inside a tile)."""
+    ba = _window_level_check(2, 480, 640, 128, 128, 4, 4711)
+    assert ba.problems[0].N == 640 * 480
+
+
+def test_cfg5_full_size_level_matches_float64_twin():
+    """configs[4]: 8-frame windows, 1280x960, K = 256 (P = 298) -- the finest level at full size (K = 256 patch gather,
+    syrk_wide.hip jobs, the solve with its matrix in the caller's workspace)."""
+    ba = _window_level_check(1, 960, 1280, 128, 256, 7, 4712)
+    assert ba.problems[0].N == 1280 * 960 and ba.problems[0].P == 298
+
+
+@pytest.mark.parametrize("K,H,W", [(128, 96, 128), (64, 48, 64)])
+def test_syrk_bf16x6_with_basis_columns_spanning_4096x(K, H, W):
+    """The depth block runs on the bf16 pipe as six products of an exact three-way split (syrk.hip).  A dropped or
+    mis-scaled cross term (hi x mid, hi x lo, mid x mid) is relative to the PRODUCT of two entries' own scales, so basis
+    columns of very different magnitude expose it: column k is scaled by 2^(12 k / (K-1)).  Every entry of AtA / Atb must
+    agree with the float64 twin to 3e-5 of sqrt(A_ii A_jj) -- its own scale, not the matrix maximum."""
+    from banet_amd import dense as bdense, ops, synth as bsynth
+    B, C = 2, 128
+    intr, levels, gt = bsynth.make_dense_windows(B, H, W, C, K, [1], 91, DEV, trans_mag=0.06)
+    lv = levels[0]
+    scale = torch.pow(2.0, 12.0 * torch.arange(K, dtype=torch.float64) / (K - 1)).to(torch.float32).to(DEV)
+    perm = torch.randperm(K, generator=torch.Generator().manual_seed(5)).to(DEV)
+    lv.basis = (lv.basis * scale[perm]).contiguous()          # large and small columns interleaved across the 16-wide blocks
+    ba = bdense.DenseBA(intr, levels, [orc.he_normal_mlp_weights(C, 5)], "bundle", 1000.0)
+    R = torch.eye(3, device=DEV).repeat(B, 1, 1)
+    T = (gt["T"] * 0.7).reshape(B, 3, 1).to(DEV)
+    Wc = torch.zeros(B, K, 1, device=DEV)
+    AtA, Atb, absres, nvalid = ops.ba_assemble(ba.problems[0], R, T, Wc)
+    for b in range(B):
+        r = torch_port.dense_assemble(intr[b:b + 1], lv.scale, lv.src[b:b + 1], lv.tgt[b:b + 1], lv.depth[b:b + 1],
+                                      lv.basis[b:b + 1], R[b:b + 1], T[b:b + 1], Wc[b:b + 1], True, True)
+        A64, b64 = n(r[0][0]), n(r[1][0])
+        dg = np.sqrt(np.maximum(np.diag(A64), 1e-300))
+        eA = np.abs(n(AtA[b]).astype(np.float64) - A64) / np.outer(dg, dg)
+        assert eA.max() < 3e-5, (b, eA.max(), np.unravel_index(eA.argmax(), eA.shape))
+        # Atb_i against its Cauchy-Schwarz scale sqrt(A_ii) * |residual|
+        rs = float(np.sqrt((n(absres[b]).astype(np.float64) ** 2).sum()))
+        eb = np.abs(n(Atb[b]).astype(np.float64) - b64) / (dg * max(rs, 1e-30))
+        assert eb.max() < 3e-5, (b, eb.max())
+        assert dg[6:].max() / dg[6:].min() > 1000.0           # the dynamic range really is in the matrix
+
+
+def test_losses_and_quaternion_on_the_gpu_match_the_reference(golden_dir):
+    """SURVEY 8(f) rank 4 (bundlenet.py:6-15,401-463) on cuda:0 against the reference's own output
+    (tests/golden/golden_losses.npz, golden_bundle_fns.npz), and their gradients against the CPU result."""
+    from banet_amd.bundlenet import BundleNet, rotation2quaternion
+    c = cases.case_losses()
+    g = np.load(os.path.join(golden_dir, "golden_losses.npz"))
+    tt = {k: torch.from_numpy(v).to(DEV) for k, v in c.items()}
+    net = BundleNet()
+    np.testing.assert_allclose(float(net.lossR(tt["predQ"], tt["gtQ"])), g["lossR"], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(float(net.lossT(tt["predT"], tt["gtT"])), g["lossT"], rtol=1e-6)
+    lf = net.lossF(tt["intr"], tt["depth"], tt["mask"], tt["predR"], tt["predT"], tt["gtR"], tt["gtT"])
+    assert lf.device.type == "cuda"
+    np.testing.assert_allclose(float(lf), g["lossF"], rtol=2e-5)
+    q = rotation2quaternion(tt["predR"])
+    assert q.device.type == "cuda"
+    np.testing.assert_allclose(n(q), orc.rotation2quaternion(c["predR"]), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(n((q * q).sum(1)), 1.0, rtol=1e-5)
+    # gradients on the GPU == gradients on the CPU
+    grads = {}
+    for dev in ("cpu", DEV):
+        t2 = {k: torch.from_numpy(v).to(dev) for k, v in c.items()}
+        pT, pR = t2["predT"].clone().requires_grad_(True), t2["predR"].clone().requires_grad_(True)
+        loss = net.lossF(t2["intr"], t2["depth"], t2["mask"], pR, pT, t2["gtR"], t2["gtT"]) + net.lossT(pT, t2["gtT"]) \
+            + net.lossR(rotation2quaternion(pR), t2["gtQ"])
+        loss.backward()
+        grads[dev] = (n(pT.grad), n(pR.grad))
+    np.testing.assert_allclose(grads[DEV][0], grads["cpu"][0], rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(grads[DEV][1], grads["cpu"][1], rtol=2e-4, atol=1e-7)

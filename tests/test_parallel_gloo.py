@@ -60,3 +60,21 @@ def test_gather_results_world_size_2_gloo():
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == [0, 1] and all(r[1] for r in res)
     assert sorted((r[2], r[3]) for r in res) == [(0, 4), (4, 7)]
+
+
+def test_bench_self_launches_its_ranks_without_a_torchrun_environment():
+    """`python bench.py --gpus 2` outside torch.distributed.run (the driver's command shape) becomes the launcher of 2 ranks.
+    There is no GPU here, so both ranks must stop at bench.py's own "needs a GPU" assertion -- which proves that two ranks
+    were started with RANK / WORLD_SIZE set (the product path has no CPU fallback to fall through to)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HIP_VISIBLE_DEVICES"] = ""
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-2000:]
+    assert "local_rank: 1" in r.stderr or "rank      : 1" in r.stderr or "rank: 1" in r.stderr, r.stderr[-2000:]

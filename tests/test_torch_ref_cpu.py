@@ -104,3 +104,34 @@ def test_bundle_chain_engines_agree_and_parity_record_shape():
     # the gate trips on a wrong update
     steps[1]["delta"] = steps[1]["delta"] * 1.01
     assert odense.parity_failures(odense.chain_parity(b, a, steps), 1e-4) != []
+
+
+def test_window_twin_matches_oracle_window_iteration():
+    """oracle.torch_port.window_assemble / window_iteration (the float64 twin the full-size multi-frame GPU checks use)
+    against banet_oracle.bundle_window_iteration: same normal equations, lambda, solution and updated state."""
+    from oracle import torch_port
+    C, K, pairs, H, W = 6, 5, 3, 20, 28
+    sc = synth.make_window_scene(H, W, C, K, [1], 9, pairs, rot_mag=0.012, trans_mag=0.04)
+    intr, levels = odense.batch_window_scene([sc])
+    lv = levels[0]
+    one = dict(lv)
+    one["tgt"] = lv["tgt"][:, 0]
+    a = odense.level_inputs(intr, one, True, np.float64)
+    conv2s = [orc.target_map(lv["tgt"][:, i].astype(np.float64)) for i in range(pairs)]
+    rng = np.random.RandomState(4)
+    Rs = [synth.rodrigues(rng.uniform(-0.004, 0.004, 3))[None] for _ in range(pairs)]
+    Ts = [(np.asarray(sc["T_gt"])[i] * 0.8).reshape(1, 3, 1) for i in range(pairs)]
+    Wc = rng.uniform(-0.01, 0.01, (1, K, 1))
+    mlp = orc.he_normal_mlp_weights(C, 1)
+    Rn, Tn, Wn, dbg = orc.bundle_window_iteration(a["conv1"], conv2s, a["fx"], a["fy"], a["ox"], a["oy"], a["p"], a["D"],
+                                                  a["Bs"], Rs, Ts, Wc, mlp, 1000.0)
+    tt = lambda x: torch.from_numpy(np.ascontiguousarray(np.asarray(x, np.float64)))  # noqa: E731
+    R2, T2, W2, d2 = torch_port.window_iteration(tt(intr), 1.0, tt(lv["src"]), tt(lv["tgt"]), tt(lv["D0"]), tt(lv["basis"]),
+                                                 tt(np.stack(Rs, 1)), tt(np.stack(Ts, 1)), tt(Wc), mlp, 1000.0)
+    np.testing.assert_allclose(d2["AtA"].numpy(), dbg["AtA"], rtol=1e-9, atol=1e-9 * np.abs(dbg["AtA"]).max())
+    np.testing.assert_allclose(d2["Atb"].numpy()[..., None], dbg["Atb"], rtol=1e-9, atol=1e-9 * np.abs(dbg["Atb"]).max())
+    np.testing.assert_allclose(d2["lam"].numpy(), np.asarray(dbg["lam"]).reshape(-1), rtol=1e-9)
+    np.testing.assert_allclose(d2["solution"].numpy(), dbg["solution"][:, :, 0], rtol=1e-7, atol=1e-9 * np.abs(dbg["solution"]).max())
+    np.testing.assert_allclose(R2.numpy(), np.stack(Rn, 1), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(T2.numpy(), np.stack(Tn, 1), rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(W2.numpy(), Wn, rtol=1e-8, atol=1e-12)

@@ -16,6 +16,15 @@ def per_kernel(d, counter):
     return acc
 
 
+def build_id():
+    """banet_build_id() of the in-tree library (bench.py refuses a traffic file recorded on another build)"""
+    import ctypes
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    lib = ctypes.CDLL(os.environ.get("BANET_HIP_LIB") or os.path.join(root, "banet_amd", "lib", "libbanet_hip.so"))
+    lib.banet_build_id.restype = ctypes.c_char_p
+    return lib.banet_build_id().decode()
+
+
 def main(fetch_dir, write_dir, windows, out):
     fe, wr = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
     g = lambda acc: [(k, v) for k, v in acc.items() if "ba_gather128" in k]
@@ -29,7 +38,7 @@ def main(fetch_dir, write_dir, windows, out):
     rec = {"kernel": "; ".join("%s x %d" % (k.split("(")[0].replace("void ", ""), len(v)) for k, v in g(fe)),
            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 0 --no-sweep "
                      "--no-parity --no-cpu-baseline` (headline workload): mean over its %d gather launches, all 5 levels" % nl,
-           "windows": int(windows), "fetch_size_kb_per_launch": round(fetch_kb, 1), "write_size_kb_per_launch": round(write_kb, 1),
+           "build_id": build_id(), "windows": int(windows), "fetch_size_kb_per_launch": round(fetch_kb, 1), "write_size_kb_per_launch": round(write_kb, 1),
            "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B -> x2 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE "
                          "uncalibrated, taken at face value",
            "hbm_bytes_per_launch": int(round(hbm)), "algorithmic_bytes_per_launch": int(round(alg)),
