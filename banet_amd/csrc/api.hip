@@ -361,6 +361,13 @@ const char* banet_build_id(void) { return BANET_BUILD_ID; }
 
 int banet_profile_ranges(int enable) { return profile_ranges(enable); }
 
+int banet_gather_selection(const banet_level_t* lv) {
+  GatherPlan pl;
+  const int rc = plan_gather(lv, &pl);
+  if (rc != BANET_OK) return rc;
+  return pl.strip ? 3 : pl.patch ? 2 : pl.c128 ? 1 : 0;
+}
+
 int banet_profile_begin(int max_launches) { return profile_begin(max_launches); }
 
 int banet_profile_end(int max_tags, int32_t* tag_points, int32_t* tag_launches, double* tag_ms, int32_t* ntags) {

@@ -431,6 +431,7 @@ __global__ __launch_bounds__(kBlock, BANET_GATHER_WAVES) void ba_gather_kernel(c
 // host side
 // --------------------------------------------------------------------------------------
 constexpr int kCUs = 256;
+constexpr int kStripSegW = 16, kStripSegH = 32, kStripMinW = 21;   // = kStripW, kStripH, kWinTex of strip_plan.hpp (gather128s.hip)
 constexpr int kGenericBlocksPerCU = BANET_GATHER_WAVES;  // ba_gather_kernel: launch bounds
 constexpr int kC128BlocksPerCU = BANET_G128_WAVES;       // ba_gather128_kernel: launch bounds (LDS: 18 KB)
 
@@ -453,6 +454,40 @@ int plan_gather(const banet_level_t* lv, GatherPlan* pl) {
   }
   pl->groups = (pl->tiles + 3) / 4;
   pl->c128 = use_c128(lv) ? 1 : 0;
+  // The strip gather (gather128s.hip: 16 x 32-pixel segments, rolling LDS window, target map fetched 1.44 x instead of 2.15 x)
+  // where a launch has at least 4 segments per resident wave (coarser items than the 8x8 tiles: below that the tail of the
+  // last round costs more than the halo saves).  reserved_ bit 18: force it at any size (parity tests); bit 19: off (A/B).
+  pl->strip = 0;
+  if (pl->c128 && lv->dense && !(lv->reserved_ & 524288) && lv->W >= kStripMinW && lv->W < 4096 && lv->H < 4096 &&
+      (size_t)lv->N * lv->C * 4 < ((size_t)1 << 31)) {
+    const int sxn = (lv->W + kStripSegW - 1) / kStripSegW, syn = (lv->H + kStripSegH - 1) / kStripSegH;
+    if ((long long)sxn * syn * lv->B >= 4LL * kCUs * 8 || (lv->reserved_ & 262144)) {
+      pl->strip = 1;
+      pl->tiles_x = sxn;
+      pl->tiles_y = syn;
+      pl->tiles = sxn * syn;
+      pl->patch = 0;
+      pl->pairloop = 1;
+      pl->qshift = 0;
+      const int resident = kCUs * 4;                 // 128-thread workgroups, 4 per CU (2 waves per SIMD)
+      int G = (resident + lv->B - 1) / lv->B;
+      const int want = (pl->tiles + 1) / 2;          // one item per wave at least
+      if (G > want) G = want;
+      if (G < 1) G = 1;
+      pl->G = G;
+      pl->nbands = 1;
+      pl->pstride = kGHdr + lv->C;
+      pl->rows = pl->tiles;
+      pl->frows = pl->rows > kFoldRows ? (pl->rows + kFoldRows - 1) / kFoldRows : pl->rows;
+      const int VBs = lv->B * npairs(lv);
+      const size_t row_bytes_s = (size_t)VBs * pl->pstride * sizeof(float);
+      pl->off_fold = align_up(row_bytes_s * pl->rows, 256);
+      pl->off_queue = pl->off_fold + (pl->frows != pl->rows ? align_up(row_bytes_s * pl->frows, 256) : 0);
+      pl->partial_bytes = pl->off_queue + align_up((size_t)VBs * 8 * sizeof(int), 256);
+      pl->rec_bytes = lv->K > 0 ? align_up((size_t)VBs * lv->N * 8 * sizeof(float), 256) : 0;
+      return BANET_OK;
+    }
+  }
   // One resident round: the gather is latency-bound per wave (measured: a second, partial round of
   // workgroups takes as long as the first), so the grid is what the chip holds at once, split
   // across the windows.
@@ -592,7 +627,7 @@ int launch_gather(const banet_level_t* lv, const GatherPlan& pl, const float* R,
   a.pairloop = pl.pairloop;
   int rc;
   if (pl.c128)
-    rc = pl.patch ? launch_gather128p(a, lv->K, s) : launch_gather128(a, lv->K, s);
+    rc = pl.strip ? launch_gather128s(a, lv->K, s) : pl.patch ? launch_gather128p(a, lv->K, s) : launch_gather128(a, lv->K, s);
   else
     rc = lv->tgt_has_grad ? launch_c<true>(a, lv->C, lv->K, s) : launch_c<false>(a, lv->C, lv->K, s);
   if (rc != BANET_OK) return rc;

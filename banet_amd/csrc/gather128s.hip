@@ -1,0 +1,637 @@
+// ba_gather128s_kernel -- the strip gather: the gather pass for C = 128 on large dense levels with the target map read
+// (almost) once.  The patch kernel (gather128p.hip) runs at the fabric's practical rate but fetches the target map 2.15 x:
+// a wave's 8x8 tile touches (8 + 3)^2 texels and nothing of that halo survives in the L2 until a neighbouring tile wants it.
+// Here a wave owns a STRIP SEGMENT of 16 x 32 source pixels and shares the halo with itself:
+//
+//   * the channel loop is outermost: four passes over the segment, one per 32-channel slice (a texel's slice is one full
+//     128-byte line), each with a ROLLING WINDOW of the last 7 texel rows x 21 texels of the target map in the wave's own LDS
+//     (18.4 KB), filled by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write) as far ahead as the ring allows and
+//     consumed behind COUNTED s_waitcnt vmcnt(n) -- the per-step row counts and wait counts depend only on the segment's
+//     geometry, so they are planned once per segment (strip_plan.hpp, unit-tested on the host) and replayed by the 4 slices;
+//     target fetch = 21/16 x 35/32 = 1.44 texels per pixel instead of 2.15 (launch: 1.15 x its algorithmic bytes, was 1.38);
+//   * what has to live across the slices is per-pixel state of the whole segment (tap parameters, depth, the five channel
+//     sums): 9 registers x 8 chunks of 64 pixels, held as lane = pixel in a TRANSPOSED order (lane 8g + q <-> pixel 8q + g of
+//     a chunk), so that the tap phase (lane = (pixel g of the instruction group, channel quad q)) finds a pixel's parameters
+//     inside its own 8-lane octet (ds_bpermute, no LDS storage) and leaves the pixel's sums -- after a 3-step DPP reduction
+//     over the octet -- on exactly the lane that owns the pixel: no staging tables, no transposition through LDS;
+//   * still no workgroup barrier (a workgroup is 2 independent waves), still one partial row per work item in a fixed place
+//     and fixed summation orders: bit-reproducible run to run;
+//   * pixel rows whose footprint does not fit the window (local scale > ~1.12, a depth discontinuity) read their taps
+//     directly; pixels on the image rim take the generic slow routine (as in the other C = 128 kernels).
+// Same arithmetic per pixel as ba_gather128_kernel; the channel sums are added slice by slice (different rounding order).
+#include "gather_common.hpp"
+#include "strip_plan.hpp"
+
+namespace banet {
+
+constexpr int kC128s = 128;
+constexpr int kSBlock = 128;                       // 2 waves per workgroup, 4 workgroups per CU (LDS: 2 x 19.9 KB)
+constexpr int kSWaves = kSBlock / kWave;
+constexpr int kWinFloats = kWinRows * kWinTex * 32;
+constexpr int kWinPitchF = kWinTex * 32;           // floats per window row
+
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef float v2fs __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int brev5s(int t) { return (int)(__brev((unsigned)t) >> 27); }
+
+template <int NL, int S0>
+__device__ __forceinline__ void carry_push_s(float (&pend)[NL + 1], float v, int t) {
+  bool done = false;
+#pragma unroll
+  for (int L = 0; L < NL; ++L) {
+    if (!done) {
+      if (((t >> L) & 1) == 0) {
+        pend[L] = v;
+        done = true;
+      } else {
+        v = bfly_merge(pend[L], v, S0 >> L);
+      }
+    }
+  }
+  if (!done) pend[NL] = v;
+}
+
+// channel maths of one pixel's 4-channel slice (packed fp32), accumulated into q[5] / absd[4]  (= tap_math_p)
+__device__ __forceinline__ void tap_math_s(const float4& f1, const float4& a0, const float4& a1, const float4& a2,
+                                           const float4& a3, const float4& b0, const float4& b1, const float4& b2,
+                                           const float4& b3, const float4& m1, const float4& m2, const float4& p1,
+                                           const float4& p2, float w00, float w01, float w10, float w11, float mk,
+                                           float (&q)[5], float (&absd)[4]) {
+  const float h00 = 0.5f * w00, h01 = 0.5f * w01, h10 = 0.5f * w10, h11 = 0.5f * w11;
+  v2fs qm11 = {0.f, 0.f}, qm12 = {0.f, 0.f}, qm22 = {0.f, 0.f}, qg1 = {0.f, 0.f}, qg2 = {0.f, 0.f};
+#define BANET_V2S(v, k) (v2fs){(k) ? (v).z : (v).x, (k) ? (v).w : (v).y}
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const v2fs F1 = BANET_V2S(f1, k);
+    const v2fs A0 = BANET_V2S(a0, k), A1 = BANET_V2S(a1, k), A2 = BANET_V2S(a2, k), A3 = BANET_V2S(a3, k);
+    const v2fs B0 = BANET_V2S(b0, k), B1 = BANET_V2S(b1, k), B2 = BANET_V2S(b2, k), B3 = BANET_V2S(b3, k);
+    const v2fs M1 = BANET_V2S(m1, k), M2 = BANET_V2S(m2, k), P1 = BANET_V2S(p1, k), P2 = BANET_V2S(p2, k);
+    const v2fs f = ((A1 * w00 + A2 * w01) + B1 * w10) + B2 * w11;
+    const v2fs gx = (((A2 - A0) * h00 + (A3 - A1) * h01) + (B2 - B0) * h10) + (B3 - B1) * h11;
+    const v2fs gy = (((B1 - M1) * h00 + (B2 - M2) * h01) + (P1 - A1) * h10) + (P2 - A2) * h11;
+    const v2fs d = f - F1 * mk;
+    qm11 += gx * gx;
+    qm12 += gx * gy;
+    qm22 += gy * gy;
+    qg1 += gx * d;
+    qg2 += gy * d;
+    absd[2 * k] += fabsf(d.x);
+    absd[2 * k + 1] += fabsf(d.y);
+  }
+#undef BANET_V2S
+  q[0] += qm11.x + qm11.y;
+  q[1] += qm12.x + qm12.y;
+  q[2] += qm22.x + qm22.y;
+  q[3] += qg1.x + qg1.y;
+  q[4] += qg2.x + qg2.y;
+}
+
+// sum over the 8 lanes of an octet (lanes 8g .. 8g + 7); every lane of the octet gets the total, fixed order
+__device__ __forceinline__ float oct_sum(float v) {
+  v += dpp_mov<kDppXor1>(v);
+  v += dpp_mov<kDppXor2>(v);
+  v += dpp_mov<kDppHalfMirror>(v);
+  return v;
+}
+
+// ---- asynchronous loads the compiler does not see (its s_waitcnt bookkeeping would drain them) ----------------------
+// 1 KB from global memory straight into LDS: lane i's 16 bytes go to lds_dst + 16 i (wave-uniform M0 base + lane x 16)
+__device__ __forceinline__ void glds16(const float* gbase, unsigned voff_bytes, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff_bytes), "s"(gbase), "s"(lds_dst)
+               : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wait_vmcnt(int n) {   // n wave-uniform, 0 .. kMaxWait (a smaller count is always safe)
+  switch (n) {
+    case 0: wait_vm<0>(); break;
+    case 1: wait_vm<1>(); break;
+    case 2: wait_vm<2>(); break;
+    case 3: wait_vm<3>(); break;
+    case 4: wait_vm<4>(); break;
+    case 5: wait_vm<5>(); break;
+    case 6: wait_vm<6>(); break;
+    case 7: wait_vm<7>(); break;
+    case 8: wait_vm<8>(); break;
+    case 9: wait_vm<9>(); break;
+    case 10: wait_vm<10>(); break;
+    case 11: wait_vm<11>(); break;
+    case 12: wait_vm<12>(); break;
+    case 13: wait_vm<13>(); break;
+    case 14: wait_vm<14>(); break;
+    default: wait_vm<15>(); break;
+  }
+}
+static_assert(kMaxWait == 15, "wait_vmcnt implements counts up to 15");
+
+// The source features of the next steps travel in VGPRs v224 .. v255 that the compiler never allocates (the kernel is limited
+// to 224 registers with amdgpu_num_vgpr; these asm statements name the other 32 in their text and clobber lists, which also
+// makes them part of the wave's allocation): a load whose destination the compiler knew about could be copied or spilled by
+// it while the data is still in flight (its loop-carried v_mov copies did exactly that to a first version).  Slot j
+// (0..3 = step mod 4), group t: v[224 + 8 j + 4 t .. + 3]; issued by buffer_load, copied out with v_mov after the counted wait.
+constexpr int kStripVgprs = 224;   // the attribute counts in units of (1 VGPR + 1 AGPR) on the unified register file: 112
+#define BANET_SRC_ISSUE_(A0, A1, A2, A3, voff, rs, soff)                                                            \
+  asm volatile("buffer_load_dwordx4 v[" #A0 ":" #A3 "], %0, %1, %2 offen" ::"v"(voff), "s"(rs), "s"(soff)           \
+               : "memory", "v" #A0, "v" #A1, "v" #A2, "v" #A3)
+#define BANET_SRC_READ_(A0, A1, A2, A3, d)                                                                          \
+  asm volatile("v_mov_b32 %0, v" #A0 "\n\tv_mov_b32 %1, v" #A1 "\n\tv_mov_b32 %2, v" #A2 "\n\tv_mov_b32 %3, v" #A3 \
+               : "=v"(d.x), "=v"(d.y), "=v"(d.z), "=v"(d.w))
+template <int SLOT, int T>
+__device__ __forceinline__ void src_issue(unsigned voff, __amdgpu_buffer_rsrc_t rs, unsigned soff) {
+  if constexpr (SLOT == 0 && T == 0) BANET_SRC_ISSUE_(224, 225, 226, 227, voff, rs, soff);
+  if constexpr (SLOT == 0 && T == 1) BANET_SRC_ISSUE_(228, 229, 230, 231, voff, rs, soff);
+  if constexpr (SLOT == 1 && T == 0) BANET_SRC_ISSUE_(232, 233, 234, 235, voff, rs, soff);
+  if constexpr (SLOT == 1 && T == 1) BANET_SRC_ISSUE_(236, 237, 238, 239, voff, rs, soff);
+  if constexpr (SLOT == 2 && T == 0) BANET_SRC_ISSUE_(240, 241, 242, 243, voff, rs, soff);
+  if constexpr (SLOT == 2 && T == 1) BANET_SRC_ISSUE_(244, 245, 246, 247, voff, rs, soff);
+  if constexpr (SLOT == 3 && T == 0) BANET_SRC_ISSUE_(248, 249, 250, 251, voff, rs, soff);
+  if constexpr (SLOT == 3 && T == 1) BANET_SRC_ISSUE_(252, 253, 254, 255, voff, rs, soff);
+}
+template <int SLOT, int T>
+__device__ __forceinline__ float4 src_read() {
+  float4 d;
+  if constexpr (SLOT == 0 && T == 0) BANET_SRC_READ_(224, 225, 226, 227, d);
+  if constexpr (SLOT == 0 && T == 1) BANET_SRC_READ_(228, 229, 230, 231, d);
+  if constexpr (SLOT == 1 && T == 0) BANET_SRC_READ_(232, 233, 234, 235, d);
+  if constexpr (SLOT == 1 && T == 1) BANET_SRC_READ_(236, 237, 238, 239, d);
+  if constexpr (SLOT == 2 && T == 0) BANET_SRC_READ_(240, 241, 242, 243, d);
+  if constexpr (SLOT == 2 && T == 1) BANET_SRC_READ_(244, 245, 246, 247, d);
+  if constexpr (SLOT == 3 && T == 0) BANET_SRC_READ_(248, 249, 250, 251, d);
+  if constexpr (SLOT == 3 && T == 1) BANET_SRC_READ_(252, 253, 254, 255, d);
+  return d;
+}
+template <int V>
+struct IC {
+  static constexpr int value = V;
+};
+
+struct SGeo {
+  float dx, dy, jd0, jd1;
+  float jc[12];
+  int x0, y0, flags;   // flags: 1 = in the mask, 2 = fast (stencil inside the image), 4 = in the mask but on the rim
+};
+
+// the pixel's projection, tap fractions and Jacobian rows from (pixel, D, R, T): statement for statement the geometry
+// phase of ba_gather128_kernel (gather128.hip)
+__device__ __forceinline__ void strip_geometry(const banet_level_t& lv, int b, const float* __restrict__ Rm,
+                                               const float* __restrict__ Tv, bool valid, int px, int py, float D, SGeo& o) {
+  const int W = lv.W, H = lv.H;
+  o.dx = o.dy = o.jd0 = o.jd1 = 0.f;
+  float p0 = 0.f, p1 = 0.f, p2 = 1.f, fx = 1.f, fy = 1.f, ox = 0.f, oy = 0.f;
+  if (valid) {
+    const float fx0 = lv.intr[b * 4 + 0], fy0 = lv.intr[b * 4 + 1], ox0 = lv.intr[b * 4 + 2], oy0 = lv.intr[b * 4 + 3];
+    p0 = ((float)px * lv.scale - ox0) / fx0;
+    p1 = ((float)py * lv.scale - oy0) / fy0;
+    p2 = 1.f;
+    if (lv.normalize_rays) {
+      const float ss = p0 * p0 + p1 * p1 + p2 * p2;
+      const float inv = 1.f / sqrtf(fmaxf(ss, 1e-12f));
+      p0 *= inv;
+      p1 *= inv;
+      p2 *= inv;
+    }
+    fx = fx0 / lv.scale;
+    fy = fy0 / lv.scale;
+    ox = ox0 / lv.scale;
+    oy = oy0 / lv.scale;
+  }
+  const float rx = Rm[0] * p0 + Rm[1] * p1 + Rm[2] * p2;
+  const float ry = Rm[3] * p0 + Rm[4] * p1 + Rm[5] * p2;
+  const float rz = Rm[6] * p0 + Rm[7] * p1 + Rm[8] * p2;
+  const float X = rx * D + Tv[0], Y = ry * D + Tv[1], Z = rz * D + Tv[2];
+  const float x = X / Z, y = Y / Z;
+  const float pxl = fx * x + ox, pyl = fy * y + oy;
+  const bool m = valid && (pxl >= 0.f) && (pxl <= (float)(W - 1)) && (pyl >= 0.f) && (pyl <= (float)(H - 1));
+#pragma unroll
+  for (int i = 0; i < 12; ++i) o.jc[i] = 0.f;
+  int x0 = 0, y0 = 0;
+  if (m) {
+    const float xf = floorf(pxl), yf = floorf(pyl);
+    o.dx = pxl - xf;
+    o.dy = pyl - yf;
+    x0 = (int)xf;
+    y0 = (int)yf;
+    const float iz = 1.f / Z;
+    o.jc[0] = fx * (x * y);
+    o.jc[1] = fx * (-1.f - x * x);
+    o.jc[2] = fx * y;
+    o.jc[3] = fx * (-iz);
+    o.jc[4] = 0.f;
+    o.jc[5] = fx * (x / Z);
+    o.jc[6] = fy * (1.f + y * y);
+    o.jc[7] = fy * (-(x * y));
+    o.jc[8] = fy * (-x);
+    o.jc[9] = 0.f;
+    o.jc[10] = fy * (-iz);
+    o.jc[11] = fy * (y / Z);
+    o.jd0 = fx * ((rx - rz * x) / Z);
+    o.jd1 = fy * ((ry - rz * y) / Z);
+  }
+  const bool interior = (x0 >= 1) && (x0 + 2 <= W - 1) && (y0 >= 1) && (y0 + 2 <= H - 1);
+  const bool fast = m && interior;
+  o.flags = (m ? 1 : 0) | (fast ? 2 : 0) | ((m && !fast) ? 4 : 0);
+  o.x0 = x0;
+  o.y0 = y0;
+}
+
+// KV4 = number of 128-coefficient chunks of a basis row (0: pose only; K % 4 == 0, K <= 128 KV4)
+template <int KV4>
+__global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVgprs / 2))) void ba_gather128s_kernel(const GatherArgs a) {
+  __shared__ __attribute__((aligned(16))) float sWin[kSWaves][kWinFloats];    // the rolling window: [slot][texel][32 channels]
+  __shared__ __attribute__((aligned(16))) StripStep sPlan[kSWaves][kStripH];
+  __shared__ __attribute__((aligned(16))) float sScr[kSWaves][kC128s];        // row statistics (plan input), later C x sum|d|
+  __shared__ int sRing[kSWaves][8];
+  const banet_level_t& lv = a.lv;
+  const int b = blockIdx.y;
+  if (a.active != nullptr && a.active[(size_t)b * a.active_stride] == 0) return;
+  const int lane = threadIdx.x & 63;
+  const int w = wave_id();
+  const int N = lv.N, K = lv.K, H = lv.H, W = lv.W;
+  constexpr int C = kC128s;
+  const float* __restrict__ src_b = lv.src + (size_t)b * N * C;
+  const float* __restrict__ dep_b = lv.depth + (size_t)b * N;
+  const float* __restrict__ bas_b = KV4 ? lv.basis + (size_t)b * N * K : nullptr;
+  const int nitems = a.tiles, segs_y = a.tiles_y;
+  const int g = lane >> 3, q = lane & 7;          // tap phase: pixel g of the instruction group, channel quad q
+  const int half = lane >> 5, li = lane & 31;     // depth dot: one basis row per half wave
+  // lane = pixel phases: this lane owns pixel 8 q + g of a chunk (4 pixel rows x 16): row q >> 1, column 8 (q & 1) + g
+  const int pk = q >> 1, pcol = 8 * (q & 1) + g;
+  const unsigned win_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&sWin[w][0];
+  const unsigned lane_off = (unsigned)(g * 512 + q * 16);   // byte offset of (texel / pixel g, channel quad q) in a global row run
+  StripRowStat* sStat = reinterpret_cast<StripRowStat*>(&sScr[w][0]);
+
+  float wreg[KV4 ? KV4 : 1][4];  // this lane's slice of the depth coefficients
+  if constexpr (KV4 > 0) {
+#pragma unroll
+    for (int kc = 0; kc < KV4; ++kc)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = kc * 128 + li * 4 + e;
+        wreg[kc][e] = (k < K) ? a.Wc[(size_t)b * K + k] : 0.f;
+      }
+  }
+  [[maybe_unused]] const auto rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src_b), 0, N * C * 4, 0x00020000);
+
+  int* __restrict__ queue = a.queue + blockIdx.y * 8;
+  auto pop_raw = [&]() {
+    int v = 0;
+    if (lane == 0) v = atomicAdd(&queue[0], 1);
+    return v;
+  };
+  int raw_next = pop_raw();
+
+  while (true) {
+    const int wi = rfl(raw_next);
+    if (wi >= nitems) return;
+    raw_next = pop_raw();  // issued now, read at the top of the next item
+    const int sx = wi / segs_y, sy = wi - sx * segs_y;
+    const int px = sx * kStripW + pcol;                       // this lane's pixel column (all chunks)
+    const int py0 = sy * kStripH + pk;                        // its pixel row in chunk 0 (+ 4 per chunk)
+
+    // ---- 1. depth of every pixel of the segment: D = D0 + b . W, chunk by chunk (once per window) ----------------------
+    f32x8 Dv;
+#pragma unroll 1
+    for (int c = 0; c < 8; ++c) {
+      const int py = py0 + 4 * c;
+      const bool valid = (px < W) && (py < H);
+      float D = valid ? dep_b[py * W + px] : 0.f;
+      if constexpr (KV4 > 0) {
+        float pend[6];
+        // 2 x 16 basis rows: the 16 (x KV4) loads of a batch are issued back to back into registers of their own, then
+        // consumed -- written as two loops so that the scheduler keeps them in flight together
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+          f32x4 bv[16][KV4];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            // leaf i of half h ends on lane 32 h + brev5(i), which owns pixel 8 q' + g' of the chunk
+            const int ld = half * 32 + brev5s(16 * hb + i);
+            const int jq = ld & 7, jg = ld >> 3;
+            const int jx = sx * kStripW + 8 * (jq & 1) + jg, jy = sy * kStripH + 4 * c + (jq >> 1);
+            const bool vj = (jx < W) && (jy < H);
+            const float* row = bas_b + (size_t)(vj ? jy * W + jx : 0) * K;
+#pragma unroll
+            for (int kc = 0; kc < KV4; ++kc) {
+              const int k = kc * 128 + li * 4;
+              bv[i][kc] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row + (k < K ? k : 0)));
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            float acc = 0.f;
+#pragma unroll
+            for (int kc = 0; kc < KV4; ++kc)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc = fmaf(bv[i][kc][e], wreg[kc][e], acc);   // k >= K: wreg is 0
+            carry_push_s<5, 16>(pend, acc, 16 * hb + i);
+          }
+        }
+        D += pend[5];
+      }
+      Dv[c] = D;
+    }
+
+#pragma unroll 1
+    for (int pr = 0; pr < a.pairs; ++pr) {   // target frames of the window: same pixels, depth and source features
+      const int vb = b * a.pairs + pr;
+      const float* __restrict__ tgt_b = lv.tgt + (size_t)vb * H * W * C;
+      float* __restrict__ rec_b = KV4 ? a.rec + (size_t)vb * N * 8 : nullptr;
+      float* __restrict__ part = a.partials + ((size_t)vb * nitems + wi) * (kGHdr + C);
+      const float* Rm = a.R + vb * 9;
+      const float* Tv = a.T + vb * 3;
+
+      // ---- 2. geometry (lane = pixel): tap parameters of the whole segment + the row statistics the plan needs ----------
+      i32x8 P0v;       // x0 | y0 << 12 | ((y0 - 1) mod 7) << 24 | fast << 27
+      f32x8 DXv, DYv;
+#pragma unroll 1
+      for (int c = 0; c < 8; ++c) {
+        const int py = py0 + 4 * c;
+        const bool valid = (px < W) && (py < H);
+        SGeo ge;
+        strip_geometry(lv, b, Rm, Tv, valid, px, py, Dv[c], ge);
+        const bool fast = (ge.flags & 2) != 0;
+        const int m7 = fast ? (ge.y0 - 1) % kWinRows : 0;
+        P0v[c] = (fast ? (ge.x0 | (ge.y0 << 12)) : 0) | (m7 << 24) | (fast ? (1 << 27) : 0);
+        DXv[c] = ge.dx;
+        DYv[c] = ge.dy;
+        // min / max of (x0, y0) over the 16 fast pixels of this lane's pixel row (lanes that agree in q >> 1)
+        const int big = 0x3fffffff;
+        int ymn = fast ? ge.y0 : big, ymx = fast ? ge.y0 : -big, xmn = fast ? ge.x0 : big, xmx = fast ? ge.x0 : -big;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int sh = s == 0 ? 1 : (4 << s);   // lane bits 0, 3, 4, 5
+          ymn = min(ymn, __shfl_xor(ymn, sh, 64));
+          ymx = max(ymx, __shfl_xor(ymx, sh, 64));
+          xmn = min(xmn, __shfl_xor(xmn, sh, 64));
+          xmx = max(xmx, __shfl_xor(xmx, sh, 64));
+        }
+        if (g == 0 && (q & 1) == 0) {
+          StripRowStat st;
+          st.ymin = ymn;
+          st.ymax = ymx;
+          st.xmin = xmn;
+          st.xmax = xmx;
+          sStat[4 * c + pk] = st;
+        }
+      }
+      // the plan: every lane computes the same values (wave-uniform addresses, identical stores)
+      const int xl = rfl(strip_plan(sStat, kStripH, W, &sPlan[w][0], &sRing[w][0]));
+      if (lv.reserved_ & (1 << 20)) {   // parity tests: every pixel row takes the direct (window-less) path
+        if (lane < kStripH && step_mode(sPlan[w][lane].ctl) == kStepWindow) sPlan[w][lane].ctl = kStepDirect;
+      }
+
+      // ---- 3. the four channel slices ---------------------------------------------------------------------------------------
+      f32x8 Q0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, Q1 = Q0, Q2 = Q0, Q3 = Q0, Q4 = Q0;   // per chunk: m11 m12 m22 g1 g2
+      const int rowC = W * C;
+#pragma unroll 1
+      for (int s = 0; s < 4; ++s) {
+        float absd[4] = {0.f, 0.f, 0.f, 0.f};   // |d| of channels 32 s + 4 q + e over every pixel this lane touches
+        const float* tgt_s = tgt_b + 32 * s;
+        // byte offset of (pixel row r, group t) of this segment's source rows, slice s: lane_off is added per lane
+        auto src_soff = [&](int r, int t) { return (unsigned)((((sy * kStripH + r) * W + sx * kStripW + 8 * t) * C + 32 * s) * 4); };
+        auto issue_row = [&](int Y) __attribute__((always_inline)) {     // texel row Y, columns xl .. xl + 20 -> its ring slot
+          const float* gb = tgt_s + ((size_t)Y * W + xl) * C;
+          const unsigned dst = win_base + (unsigned)(Y % kWinRows) * (unsigned)kWinPitchB;
+          glds16(gb, lane_off, dst);
+          glds16(gb + 8 * C, lane_off, dst + 1024u);
+          if (lane < 8 * (kWinTex - 16)) glds16(gb + 16 * C, lane_off, dst + 2048u);
+        };
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the counted section starts with nothing in flight
+        {
+          const int c0 = rfl(sPlan[w][0].ctl), c1 = rfl(sPlan[w][1].ctl);
+          if (step_src_pre(c0)) {
+            src_issue<0, 0>(lane_off, rs_src, src_soff(0, 0));
+            src_issue<0, 1>(lane_off, rs_src, src_soff(0, 1));
+          }
+          if (step_src_pre(c1)) {
+            src_issue<1, 0>(lane_off, rs_src, src_soff(1, 0));
+            src_issue<1, 1>(lane_off, rs_src, src_soff(1, 1));
+          }
+        }
+#pragma unroll 1
+        for (int c = 0; c < 8; ++c) {
+          const int p0c = P0v[c];
+          const float dxc = DXv[c], dyc = DYv[c];
+          float qacc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};    // this lane's pixel of chunk c, slice s
+          // step r = 4 c + k: one pixel row = instruction groups 2 k, 2 k + 1 of the chunk (k is a compile-time constant:
+          // the AGPR slots of the source features are named in the instruction text)
+          auto do_step = [&](auto kconst) __attribute__((always_inline)) {
+            constexpr int k = decltype(kconst)::value;
+            const int r = 4 * c + k;
+            const int ctl = rfl(sPlan[w][r].ctl);
+            const int mode = step_mode(ctl);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the previous step's window reads are done (WAR)
+            if (step_src_next(ctl)) {
+              src_issue<(k + 2) & 3, 0>(lane_off, rs_src, src_soff(r + kSrcAhead, 0));
+              src_issue<(k + 2) & 3, 1>(lane_off, rs_src, src_soff(r + kSrcAhead, 1));
+            }
+            if (mode == kStepSkip) return;
+            float4 fsrc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+            if (mode == kStepWindow) {
+              const int y0r = rfl(sPlan[w][r].yfirst), nr = step_nrows(ctl);
+              for (int i = 0; i < nr; ++i) issue_row(y0r + i);
+              wait_vmcnt(step_wait(ctl));
+              fsrc[0] = src_read<k, 0>();      // landed: behind the counted wait
+              fsrc[1] = src_read<k, 1>();
+            }
+            const int mtop = step_mtop(ctl);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const int gi = 2 * k + t;
+              // parameters of pixel 8 gi + g live on lane 8 g + gi: inside this lane's octet
+              const int sl = ((lane & ~7) | gi) << 2;
+              const int p0 = __builtin_amdgcn_ds_bpermute(sl, p0c);
+              const float dx = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sl, __builtin_bit_cast(int, dxc)));
+              const float dy = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sl, __builtin_bit_cast(int, dyc)));
+              const bool fast = (p0 >> 27) & 1;
+              const float mk = fast ? 1.f : 0.f;
+              const float w00 = mk * ((1.f - dx) * (1.f - dy)), w01 = mk * (dx * (1.f - dy)), w10 = mk * ((1.f - dx) * dy),
+                          w11 = mk * (dx * dy);
+              float qq[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+              if (mode == kStepWindow) {
+                const int xr = fast ? (p0 & 0xfff) - 1 - xl : 0;             // window column of texel x0 - 1
+                const int m0 = fast ? (p0 >> 24) & 7 : mtop;                 // ring slot of texel row y0 - 1
+                const int m1i = m0 + 1 >= kWinRows ? m0 + 1 - kWinRows : m0 + 1;
+                const int m2i = m1i + 1 >= kWinRows ? m1i + 1 - kWinRows : m1i + 1;
+                const int m3i = m2i + 1 >= kWinRows ? m2i + 1 - kWinRows : m2i + 1;
+                const float* l = &sWin[w][0] + xr * 32 + 4 * q;
+                const float* l0 = l + m0 * kWinPitchF;
+                const float* l1 = l + m1i * kWinPitchF;
+                const float* l2 = l + m2i * kWinPitchF;
+                const float* l3 = l + m3i * kWinPitchF;
+                const float4 f1 = fsrc[t];
+                const float4 a0 = *reinterpret_cast<const float4*>(l1), a1 = *reinterpret_cast<const float4*>(l1 + 32),
+                             a2 = *reinterpret_cast<const float4*>(l1 + 64), a3 = *reinterpret_cast<const float4*>(l1 + 96);
+                const float4 b0 = *reinterpret_cast<const float4*>(l2), b1 = *reinterpret_cast<const float4*>(l2 + 32),
+                             b2 = *reinterpret_cast<const float4*>(l2 + 64), b3 = *reinterpret_cast<const float4*>(l2 + 96);
+                const float4 m1 = *reinterpret_cast<const float4*>(l0 + 32), m2 = *reinterpret_cast<const float4*>(l0 + 64);
+                const float4 p1 = *reinterpret_cast<const float4*>(l3 + 32), p2 = *reinterpret_cast<const float4*>(l3 + 64);
+                tap_math_s(f1, a0, a1, a2, a3, b0, b1, b2, b3, m1, m2, p1, p2, w00, w01, w10, w11, mk, qq, absd);
+              } else {   // kStepDirect: the footprint of this pixel row does not fit the window -- taps straight from memory
+                const int x0 = fast ? (p0 & 0xfff) : 1, y0 = fast ? (p0 >> 12) & 0xfff : 1;
+                const int gpx = sx * kStripW + 8 * t + g, gpy = sy * kStripH + r;
+                const bool gv = (gpx < W) && (gpy < H);
+                const unsigned osrc = (unsigned)((gv ? gpy * W + gpx : 0) * C + 32 * s + 4 * q);
+                const unsigned oa = (unsigned)((y0 * W + x0) * C + 32 * s + 4 * q);
+                const float* ra = tgt_b + (size_t)oa;
+                const float* rb = ra + rowC;
+                const float* rm = ra - rowC;
+                const float* rp = rb + rowC;
+                const f32x4 f1v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src_b + (size_t)osrc));
+                const float4 f1 = make_float4(f1v[0], f1v[1], f1v[2], f1v[3]);
+                const float4 a0 = *reinterpret_cast<const float4*>(ra - C), a1 = *reinterpret_cast<const float4*>(ra),
+                             a2 = *reinterpret_cast<const float4*>(ra + C), a3 = *reinterpret_cast<const float4*>(ra + 2 * C);
+                const float4 b0 = *reinterpret_cast<const float4*>(rb - C), b1 = *reinterpret_cast<const float4*>(rb),
+                             b2 = *reinterpret_cast<const float4*>(rb + C), b3 = *reinterpret_cast<const float4*>(rb + 2 * C);
+                const float4 m1 = *reinterpret_cast<const float4*>(rm), m2 = *reinterpret_cast<const float4*>(rm + C);
+                const float4 p1 = *reinterpret_cast<const float4*>(rp), p2 = *reinterpret_cast<const float4*>(rp + C);
+                tap_math_s(f1, a0, a1, a2, a3, b0, b1, b2, b3, m1, m2, p1, p2, w00, w01, w10, w11, mk, qq, absd);
+              }
+#pragma unroll
+              for (int i = 0; i < 5; ++i) {
+                const float tot = oct_sum(qq[i]);
+                qacc[i] += (q == gi) ? tot : 0.f;       // the lane that owns pixel 8 gi + g keeps it
+              }
+            }
+          };
+          do_step(IC<0>{});
+          do_step(IC<1>{});
+          do_step(IC<2>{});
+          do_step(IC<3>{});
+          Q0[c] += qacc[0];
+          Q1[c] += qacc[1];
+          Q2[c] += qacc[2];
+          Q3[c] += qacc[3];
+          Q4[c] += qacc[4];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the slice's 32 x sum|d|: fold the 8 pixel lanes of every channel quad (fixed order), octet 0 publishes
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = absd[e];
+          v += __shfl_xor(v, 8, 64);
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
+          if (g == 0) sScr[w][32 * s + 4 * q + e] = v;
+        }
+      }
+
+      // ---- 4. per-pixel 6x6 algebra (lane = pixel), records, the segment's 28 pose sums ------------------------------------
+      float absd2[1][2] = {{0.f, 0.f}};  // rim pixels (generic routine: channels 2 lane, 2 lane + 1)
+      float tot_acc = 0.f;
+#pragma unroll 1
+      for (int c = 0; c < 8; ++c) {
+        const int py = py0 + 4 * c;
+        const bool valid = (px < W) && (py < H);
+        const int pt = valid ? py * W + px : 0;
+        SGeo ge;
+        strip_geometry(lv, b, Rm, Tv, valid, px, py, Dv[c], ge);
+        Q5 qv;
+        qv.m11 = Q0[c];
+        qv.m12 = Q1[c];
+        qv.m22 = Q2[c];
+        qv.g1 = Q3[c];
+        qv.g2 = Q4[c];
+        {
+          // patch the pixels whose stencil touches the image rim (rare): generic slow routine
+          unsigned long long slow = __ballot((ge.flags & 4) != 0);
+          while (slow) {  // wave-uniform
+            const int j = __builtin_ctzll(slow);
+            slow &= slow - 1;
+            const float jdx = rdl(ge.dx, j), jdy = rdl(ge.dy, j);
+            Q5 e = border_pixel_q5<2, 1>(rdl(ge.x0, j), rdl(ge.y0, j), (1.f - jdx) * (1.f - jdy), jdx * (1.f - jdy),
+                                         (1.f - jdx) * jdy, jdx * jdy, src_b + (size_t)rdl(pt, j) * C, tgt_b, C, H, W, lane,
+                                         absd2);
+            e.m11 = wave_sum(e.m11);
+            e.m12 = wave_sum(e.m12);
+            e.m22 = wave_sum(e.m22);
+            e.g1 = wave_sum(e.g1);
+            e.g2 = wave_sum(e.g2);
+            if (lane == j) {
+              qv.m11 += e.m11;
+              qv.m12 += e.m12;
+              qv.m22 += e.m22;
+              qv.g1 += e.g1;
+              qv.g2 += e.g2;
+            }
+          }
+        }
+        const float* jc = ge.jc;
+        float mj[12];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          mj[i] = qv.m11 * jc[i] + qv.m12 * jc[6 + i];
+          mj[6 + i] = qv.m12 * jc[i] + qv.m22 * jc[6 + i];
+        }
+        // leaves 0..20: upper triangle of Jc^T M Jc, 21..26: Jc^T g, 27: valid count, 28..31: zero.
+        // 5 levels (lane distance 32..2) + one xor-1 add: lane l ends with leaf brev5(l >> 1).
+        float pend[6];
+        int o = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+          for (int jj = i; jj < 6; ++jj) {
+            carry_push_s<5, 32>(pend, jc[i] * mj[jj] + jc[6 + i] * mj[6 + jj], o);
+            ++o;
+          }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) carry_push_s<5, 32>(pend, jc[i] * qv.g1 + jc[6 + i] * qv.g2, 21 + i);
+        carry_push_s<5, 32>(pend, (float)(ge.flags & 1), 27);
+#pragma unroll
+        for (int i = 28; i < 32; ++i) carry_push_s<5, 32>(pend, 0.f, i);
+        float tot = pend[5];
+        tot += dpp_mov<kDppXor1>(tot);
+        tot_acc += tot;                       // chunks in order 0..7: fixed summation order
+
+        if constexpr (KV4 > 0) {
+          if (valid) {
+            const float md0 = qv.m11 * ge.jd0 + qv.m12 * ge.jd1, md1 = qv.m12 * ge.jd0 + qv.m22 * ge.jd1;
+            float4 ua, ub;
+            ua.x = jc[0] * md0 + jc[6] * md1;
+            ua.y = jc[1] * md0 + jc[7] * md1;
+            ua.z = jc[2] * md0 + jc[8] * md1;
+            ua.w = jc[3] * md0 + jc[9] * md1;
+            ub.x = jc[4] * md0 + jc[10] * md1;
+            ub.y = jc[5] * md0 + jc[11] * md1;
+            ub.z = ge.jd0 * md0 + ge.jd1 * md1;      // s_n
+            ub.w = ge.jd0 * qv.g1 + ge.jd1 * qv.g2;  // r_n
+            float4* rp = reinterpret_cast<float4*>(rec_b + (size_t)pt * 8);
+            rp[0] = ua;
+            rp[1] = ub;
+          }
+        }
+      }
+      {
+        const int leaf = brev5s(lane >> 1);
+        if ((lane & 1) == 0 && leaf < 28) part[leaf] = tot_acc;
+      }
+      // ---- 5. the segment's C x sum|d| ----------------------------------------------------------------------------------------
+      sScr[w][2 * lane] += absd2[0][0];       // same wave: LDS operations retire in program order
+      sScr[w][2 * lane + 1] += absd2[0][1];
+      part[kGHdr + lane] = sScr[w][lane];
+      part[kGHdr + 64 + lane] = sScr[w][64 + lane];
+    }  // pairs
+  }  // items
+}
+
+int launch_gather128s(const GatherArgs& a, int K, hipStream_t s) {
+  dim3 grid(a.G, a.lv.B), block(kSBlock);
+  if (K == 0)
+    hipLaunchKernelGGL((ba_gather128s_kernel<0>), grid, block, 0, s, a);
+  else if ((K & 3) == 0 && K <= 128)
+    hipLaunchKernelGGL((ba_gather128s_kernel<1>), grid, block, 0, s, a);
+  else if ((K & 3) == 0 && K <= 256)
+    hipLaunchKernelGGL((ba_gather128s_kernel<2>), grid, block, 0, s, a);
+  else
+    return BANET_ERR_UNSUPPORTED;
+  return BANET_OK;
+}
+
+}  // namespace banet

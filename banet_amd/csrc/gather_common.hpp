@@ -194,6 +194,7 @@ __device__ __noinline__ Q5 border_pixel_q5(int x0, int y0, float w00, float w01,
 #define BANET_G128_WAVES 3   // ba_gather128_kernel: workgroups per CU (= waves per SIMD) of its launch bounds
 #endif
 int launch_gather128(const GatherArgs& a, int K, hipStream_t s);
-int launch_gather128p(const GatherArgs& a, int K, hipStream_t s);   // gather128p.hip: wave-private LDS patches  // gather128.hip
+int launch_gather128p(const GatherArgs& a, int K, hipStream_t s);   // gather128p.hip: wave-private LDS patches
+int launch_gather128s(const GatherArgs& a, int K, hipStream_t s);   // gather128s.hip: strip segments, rolling LDS window
 
 }  // namespace banet

@@ -251,6 +251,18 @@ class LevelProblem:
         self.device = tgt.device
 
 
+GATHER_KERNELS = {0: "ba_gather_kernel", 1: "ba_gather128_kernel", 2: "ba_gather128p_kernel", 3: "ba_gather128s_kernel"}
+FORCE_PATCH_GATHER, FORCE_STRIP_GATHER = 512, 262144     # banet_level_t.reserved_ bits (parity checks at small batch sizes)
+
+
+def gather_selection(level):
+    """banet_gather_selection: 0 generic / 1 C=128 direct / 2 LDS patches / 3 strip segments, for this level AND batch size"""
+    rc = capi.lib().banet_gather_selection(ctypes.byref(level.c))
+    if rc < 0:
+        capi.check(rc)
+    return rc
+
+
 def ba_assemble(level, R, T, Wc=None):
     """banet_ba_assemble_f32 -> (AtA [B,P,P], Atb [B,P], absres [B,C], nvalid [B])."""
     L = capi.lib()

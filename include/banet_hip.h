@@ -287,6 +287,12 @@ int banet_profile_end(int max_tags, int32_t* tag_points, int32_t* tag_launches, 
  *     role (the reference has no tracing hooks at all).  Returns 0 when the roctx library could not be
  *     loaded.  Off by default; also enabled by the environment variable BANET_ROCTX=1.                                     */
 const char* banet_build_id(void);
+/*   banet_gather_selection: which assembly (gather) kernel a level of this shape runs -- 0 = ba_gather_kernel (generic),
+ *     1 = ba_gather128_kernel (C = 128, 8x8 tiles, direct taps), 2 = ba_gather128p_kernel (wave-private LDS patches),
+ *     3 = ba_gather128s_kernel (16x32 strip segments, rolling LDS window); negative = error code.  The selection depends on
+ *     the batch (work items per resident wave), so bench.py / the tests use this to run a one-window parity check on the
+ *     kernel the full batch runs (banet_level_t.reserved_ bits 9 / 18 force the patch / strip kernel at any size).        */
+int banet_gather_selection(const banet_level_t* lv);
 int banet_profile_ranges(int enable);
 
 #ifdef __cplusplus

@@ -202,7 +202,7 @@ def window_iteration(intr, scale, src, tgts, depth, basis, Rs, Ts, Wc, mlp, l2_b
     pairs, last coefficient undamped, LU solve, per-frame SE(3) update) -> (Rs', Ts', W', dict(lam, solution, AtA, Atb))."""
     B, pairs = tgts.shape[0], tgts.shape[1]
     N = src.shape[1] * src.shape[2]
-    AtA, Atb, absres, _nv = window_assemble(intr, scale, src, tgts, depth, basis, Rs, Ts, Wc, True, dtype)
+    AtA, Atb, absres, nv = window_assemble(intr, scale, src, tgts, depth, basis, Rs, Ts, Wc, True, dtype)
     avg = (absres / (N * pairs)).unsqueeze(1)
     mlp = [(torch.as_tensor(w).cpu().numpy() if not hasattr(w, "numpy") else w.cpu().numpy(),
             torch.as_tensor(b).cpu().numpy() if not hasattr(b, "numpy") else b.cpu().numpy()) for w, b in mlp]
@@ -218,4 +218,5 @@ def window_iteration(intr, scale, src, tgts, depth, basis, Rs, Ts, Wc, mlp, l2_b
         Rn.append(torch.matmul(Rw, Rs[:, i].to(dtype)))
         Tn.append(torch.matmul(V, sol[:, 6 * i + 3:6 * i + 6]) + torch.matmul(Rw, Ts[:, i].to(dtype).reshape(B, 3, 1)))
     Wn = Wc.to(dtype).reshape(B, -1, 1) + sol[:, 6 * pairs:]
-    return torch.stack(Rn, 1), torch.stack(Tn, 1), Wn, dict(lam=lam.reshape(-1), solution=sol[..., 0], AtA=AtA, Atb=Atb)
+    return torch.stack(Rn, 1), torch.stack(Tn, 1), Wn, dict(lam=lam.reshape(-1), solution=sol[..., 0], AtA=AtA, Atb=Atb,
+                                                             nvalid=nv.sum(1))

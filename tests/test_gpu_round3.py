@@ -158,3 +158,112 @@ def test_losses_and_quaternion_on_the_gpu_match_the_reference(golden_dir):
         grads[dev] = (n(pT.grad), n(pR.grad))
     np.testing.assert_allclose(grads[DEV][0], grads["cpu"][0], rtol=2e-4, atol=1e-7)
     np.testing.assert_allclose(grads[DEV][1], grads["cpu"][1], rtol=2e-4, atol=1e-7)
+
+
+# ======================================================================================
+# the strip gather (gather128s.hip)
+# ======================================================================================
+def t(x, dtype=np.float32):
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype))).to(DEV)
+
+
+def _torch_levels(levels):
+    from banet_amd import dense as bdense
+    return [bdense.DenseLevel(lv["scale"], t(lv["src"]), t(lv["tgt"]), t(lv["D0"]),
+                              t(lv["basis"]) if lv["basis"].shape[-1] else None) for lv in levels]
+
+
+STRIP, DIRECT, STRIP_ALL_DIRECT = 262144, 64 | 524288, 262144 | (1 << 20)
+
+
+@pytest.mark.parametrize("H,W,K,big,pairs", [(48, 64, 128, False, 1),      # whole segments, unit-scale footprints: all from the window
+                                             (40, 56, 16, True, 1),        # large motion: fallback rows, rim, masked pixels
+                                             (37, 53, 0, True, 2),         # ragged strips and segments, pose only, 2 target frames
+                                             (64, 96, 64, False, 3),       # 3 target frames share the depth dot
+                                             (70, 45, 256, False, 1),      # K = 256 (two basis chunks per row)
+                                             (33, 21, 32, False, 1)])      # the narrowest map the window fits (21 texels)
+def test_strip_gather_kernel_matches_oracle(H, W, K, big, pairs):
+    """ba_gather128s_kernel forced at oracle-sized inputs, against the direct C = 128 kernel (same arithmetic per pixel, the
+    channel sums added slice by slice), against itself with every pixel row on the window-less path, and against the
+    float64 oracle."""
+    from banet_amd import dense as bdense, ops
+    from oracle import dense as odense, synth
+    B, C = 2, 128
+    scenes = [synth.make_window_scene(H, W, C, K, [1], 300 + b, pairs, rot_mag=0.012 * (6 if big else 1),
+                                      trans_mag=0.05 * (6 if big else 1)) for b in range(B)]
+    intr, levels = odense.batch_window_scene(scenes)
+    lv = levels[0]
+    rng = np.random.RandomState(8)
+    R = np.stack([[synth.rodrigues(rng.uniform(-1, 1, 3) * 0.004) for _ in range(pairs)] for _ in range(B)]).astype(np.float32)
+    T = (np.stack([s["T_gt"] for s in scenes]) * 0.8).reshape(B, pairs, 3, 1).astype(np.float32)
+    Wc = (rng.standard_normal((B, K, 1)) * 0.01).astype(np.float32)
+    mlps = [orc.he_normal_mlp_weights(C, 9)]
+    ba = bdense.DenseBA(t(intr), _torch_levels(levels), mlps, "bundle" if K else "bundle_camera", 1000.0)
+    outs = {}
+    for bits in (STRIP, DIRECT, STRIP_ALL_DIRECT):
+        ba.problems[0].c.reserved_ = bits
+        assert ops.gather_selection(ba.problems[0]) == (1 if bits == DIRECT else 3)
+        outs[bits] = [n(x) for x in ops.ba_assemble(ba.problems[0], t(R), t(T), t(Wc) if K else None)]
+        again = [n(x) for x in ops.ba_assemble(ba.problems[0], t(R), t(T), t(Wc) if K else None)]
+        for x, y in zip(outs[bits], again):                       # bit-reproducible run to run
+            np.testing.assert_array_equal(x, y)
+    ba.problems[0].c.reserved_ = 0
+    for name, x, y in zip(("AtA", "Atb", "absres", "nvalid"), outs[STRIP], outs[DIRECT]):
+        assert relerr(x, y) < 3e-6, (name, relerr(x, y))
+    for name, x, y in zip(("AtA", "Atb", "absres", "nvalid"), outs[STRIP_ALL_DIRECT], outs[STRIP]):
+        assert relerr(x, y) < 1e-6, (name, relerr(x, y))          # window and direct taps read the same texels
+    np.testing.assert_array_equal(outs[STRIP][3], outs[DIRECT][3])
+    one = dict(lv)
+    one["tgt"] = lv["tgt"][:, 0]
+    a = odense.level_inputs(intr, one, True, np.float64)
+    R64 = [R[:, i].astype(np.float64) for i in range(pairs)]
+    T64 = [T[:, i].astype(np.float64) for i in range(pairs)]
+    if K:
+        conv2s = [orc.target_map(lv["tgt"][:, i].astype(np.float64)) for i in range(pairs)]
+        dbg = orc.bundle_window_iteration(a["conv1"], conv2s, a["fx"], a["fy"], a["ox"], a["oy"], a["p"], a["D"], a["Bs"],
+                                          R64, T64, Wc.astype(np.float64), mlps[0], 1000.0)[3]
+        assert relerr(outs[STRIP][0], dbg["AtA"]) < 3e-5 and relerr(outs[STRIP][1][..., None], dbg["Atb"]) < 3e-5
+        nv = sum(m.sum(axis=(1, 2)) for m in dbg["mask"])
+        assert np.abs(outs[STRIP][3] - nv).max() <= 1
+        assert relerr(outs[STRIP][2] / (H * W * pairs), dbg["avg"][:, 0]) < 1e-5
+        if big:
+            assert (nv < H * W * pairs).all()                     # some pixels really leave the image
+    else:
+        for i in range(pairs):
+            d = orc.bundle_camera_iteration(a["conv1"], orc.target_map(lv["tgt"][:, i].astype(np.float64)), a["fx"], a["fy"],
+                                            a["ox"], a["oy"], a["p"], a["D"], R64[i], T64[i], mlps[0], 1.0)[2]
+            assert relerr(outs[STRIP][0][:, 6 * i:6 * i + 6, 6 * i:6 * i + 6], d["AtA"]) < 3e-5
+
+
+def test_strip_gather_full_size_batch_selection_and_twin():
+    """The production selection: at the metric's batch (32 windows) the 640x480 level runs the strip gather; window 0 and
+    window 31 of the batch against the float64 twin (normal equations and one LM update), and a whole 5-level solve of the
+    batch is bit-identical run to run."""
+    from banet_amd import dense as bdense, ops, synth as bsynth
+    from banet_amd.bundlenet import he_normal_lambda_weights
+    B, H, W, C, K = 32, 480, 640, 128, 128
+    torch.manual_seed(5)
+    intr, levels, gt = bsynth.make_dense_windows(B, H, W, C, K, [4, 1], 990, DEV, trans_mag=0.06)
+    mlps = [he_normal_lambda_weights(C, 100 + i) for i in range(2)]
+    ba = bdense.DenseBA(intr, levels, mlps, "bundle", 1000.0)
+    assert ops.gather_selection(ba.problems[1]) == 3
+    R = torch.eye(3, device=DEV).repeat(B, 1, 1)
+    T = (gt["T"] * 0.7).reshape(B, 3, 1).to(DEV)
+    Wc = torch.zeros(B, K, 1, device=DEV)
+    lv = levels[1]
+    AtA, Atb, absres, nvalid = ops.ba_assemble(ba.problems[1], R, T, Wc)
+    st = ba.step_from(1, R.clone(), T.clone(), Wc.clone())
+    for b in (0, 31):
+        sl = slice(b, b + 1)
+        R2, T2, W2, d = torch_port.window_iteration(intr[sl], lv.scale, lv.src[sl], lv.tgt[sl].unsqueeze(1), lv.depth[sl], lv.basis[sl],
+                                                    R[sl].unsqueeze(1), T[sl].unsqueeze(1), Wc[sl], [(n(w_), n(b_)) for w_, b_ in mlps[1]], 1000.0)
+        assert relerr(n(AtA[b]), n(d["AtA"][0])) < 3e-5 and relerr(n(Atb[b]), n(d["Atb"][0])) < 3e-5
+        assert float(nvalid[b]) == float(d["nvalid"][0])
+        sol, dl = n(d["solution"][0]), n(st.delta[b])
+        assert relerr(dl[:6], sol[:6]) < 1e-4 and relerr(dl[6:-1], sol[6:-1]) < 1e-4 and relerr(dl[-1:], sol[-1:]) < 1e-4
+        assert relerr(n(st.lambda_out[b:b + 1]), n(d["lam"])) < 1e-4
+    T0 = (gt["T"] * 0.7).reshape(B, 3, 1).to(DEV)
+    a = ba.solve([3, 3], ba.new_state(T=T0.clone()))[0]
+    ra, ta, wa = a.R.clone(), a.T.clone(), a.Wc.clone()
+    b2 = ba.solve([3, 3], ba.new_state(T=T0.clone()))[0]
+    assert torch.equal(ra, b2.R) and torch.equal(ta, b2.T) and torch.equal(wa, b2.Wc)
