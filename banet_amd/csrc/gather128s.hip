@@ -295,6 +295,10 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
     const int px = sx * kStripW + pcol;                       // this lane's pixel column (all chunks)
     const int py0 = sy * kStripH + pk;                        // its pixel row in chunk 0 (+ 4 per chunk)
 
+    BANET_TICK(ts0);
+#ifdef BANET_TIMING
+    float ts_wait = 0.f, ts_taps = 0.f;
+#endif
     // ---- 1. depth of every pixel of the segment: D = D0 + b . W, chunk by chunk (once per window) ----------------------
     f32x8 Dv;
 #pragma unroll 1
@@ -338,6 +342,7 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
       Dv[c] = D;
     }
 
+    BANET_TICK(ts1);
 #pragma unroll 1
     for (int pr = 0; pr < a.pairs; ++pr) {   // target frames of the window: same pixels, depth and source features
       const int vb = b * a.pairs + pr;
@@ -387,6 +392,7 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
         if (lane < kStripH && step_mode(sPlan[w][lane].ctl) == kStepWindow) sPlan[w][lane].ctl = kStepDirect;
       }
 
+      BANET_TICK(ts2);
       // ---- 3. the four channel slices ---------------------------------------------------------------------------------------
       f32x8 Q0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, Q1 = Q0, Q2 = Q0, Q3 = Q0, Q4 = Q0;   // per chunk: m11 m12 m22 g1 g2
       const int rowC = W * C;
@@ -437,7 +443,14 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
             if (mode == kStepWindow) {
               const int y0r = rfl(sPlan[w][r].yfirst), nr = step_nrows(ctl);
               for (int i = 0; i < nr; ++i) issue_row(y0r + i);
+#if defined(BANET_TIMING) && BANET_TIMING == 1
+              BANET_TICK(tw0);
+#endif
               wait_vmcnt(step_wait(ctl));
+#if defined(BANET_TIMING) && BANET_TIMING == 1
+              BANET_TICK(tw1);
+              BANET_TACC(ts_wait, tw0, tw1);
+#endif
               fsrc[0] = src_read<k, 0>();      // landed: behind the counted wait
               fsrc[1] = src_read<k, 1>();
             }
@@ -523,6 +536,7 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
         }
       }
 
+      BANET_TICK(ts3);
       // ---- 4. per-pixel 6x6 algebra (lane = pixel), records, the segment's 28 pose sums ------------------------------------
       float absd2[1][2] = {{0.f, 0.f}};  // rim pixels (generic routine: channels 2 lane, 2 lane + 1)
       float tot_acc = 0.f;
@@ -617,6 +631,23 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
       sScr[w][2 * lane + 1] += absd2[0][1];
       part[kGHdr + lane] = sScr[w][lane];
       part[kGHdr + 64 + lane] = sScr[w][64 + lane];
+#ifdef BANET_TIMING   // tools/time_strip.py: cycles of this segment (the last target frame of the window)
+      {
+        BANET_TICK(ts9);
+        if (lane == 0) {
+#if BANET_TIMING == 1
+          part[28] = ts_wait;                  // parked in the counted waits (window rows / source features not landed)
+          part[29] = (float)(ts3 - ts2);       // the four slice passes
+#else
+          part[28] = (float)(ts1 - ts0);       // depth dot
+          part[29] = (float)(ts2 - ts1);       // geometry + plan
+#endif
+          part[30] = (float)(ts9 - ts3);       // rim, algebra, records, partial row
+          part[31] = (float)(ts9 - ts0);       // whole segment
+          (void)ts_taps;
+        }
+      }
+#endif
     }  // pairs
   }  // items
 }
