@@ -10,10 +10,13 @@
 //     geometry, so they are planned once per segment (strip_plan.hpp, unit-tested on the host) and replayed by the 4 slices;
 //     target fetch = 21/16 x 35/32 = 1.44 texels per pixel instead of 2.15 (launch: 1.15 x its algorithmic bytes, was 1.38);
 //   * what has to live across the slices is per-pixel state of the whole segment (tap parameters, depth, the five channel
-//     sums): 9 registers x 8 chunks of 64 pixels, held as lane = pixel in a TRANSPOSED order (lane 8g + q <-> pixel 8q + g of
-//     a chunk), so that the tap phase (lane = (pixel g of the instruction group, channel quad q)) finds a pixel's parameters
-//     inside its own 8-lane octet (ds_bpermute, no LDS storage) and leaves the pixel's sums -- after a 3-step DPP reduction
-//     over the octet -- on exactly the lane that owns the pixel: no staging tables, no transposition through LDS;
+//     sums): 9 registers x 8 chunks of 64 pixels, held as lane = pixel in a TRANSPOSED order (lane 4 p + k <-> pixel (row k,
+//     column p) of a chunk of 4 rows x 16), so that the tap phase -- one pixel ROW per step, 4 lanes per pixel, 8 channels per
+//     lane -- finds a pixel's parameters inside its own quad (one DPP quad_perm broadcast, no LDS) and leaves the pixel's
+//     sums, after a 2-step DPP reduction over the quad, on exactly the lane that owns the pixel: no staging tables, no
+//     transposition through LDS.  (A first version ran 8 lanes per pixel, 4 channels per lane, two instruction groups per
+//     step: parity-green, 1.12 x the algorithmic bytes by the counters -- and VALU-bound at 433 instructions per step, because
+//     the per-group overhead (weights, addresses, reductions) was paid per 4 channels: profiles/r03_run3_*.)
 //   * still no workgroup barrier (a workgroup is 2 independent waves), still one partial row per work item in a fixed place
 //     and fixed summation orders: bit-reproducible run to run;
 //   * pixel rows whose footprint does not fit the window (local scale > ~1.12, a depth discontinuity) read their taps
@@ -88,13 +91,41 @@ __device__ __forceinline__ void tap_math_s(const float4& f1, const float4& a0, c
   q[4] += qg2.x + qg2.y;
 }
 
-// sum over the 8 lanes of an octet (lanes 8g .. 8g + 7); every lane of the octet gets the total, fixed order
-__device__ __forceinline__ float oct_sum(float v) {
+// sum over the 4 lanes of a quad; every lane of the quad gets the total, fixed order
+__device__ __forceinline__ float quad_sum(float v) {
   v += dpp_mov<kDppXor1>(v);
   v += dpp_mov<kDppXor2>(v);
-  v += dpp_mov<kDppHalfMirror>(v);
   return v;
 }
+// lane k of every quad -> all four lanes of the quad
+template <int K4>
+__device__ __forceinline__ int quad_bcast(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, K4 * 0x55, 0xF, 0xF, true);   // quad_perm:[k,k,k,k]
+}
+template <int K4>
+__device__ __forceinline__ float quad_bcast(float v) {
+  return __builtin_bit_cast(float, quad_bcast<K4>(__builtin_bit_cast(int, v)));
+}
+
+// lane `l` of `old` replaced by the wave-uniform value `v` (v_writelane_b32 cannot take two different SGPR operands:
+// constant-bus limit; a compare + select does it)
+__device__ __forceinline__ int write_lane(int v, int l, int old) { return lane_id() == l ? v : old; }
+
+// the rolling-window plan with one pixel row per lane (lanes 0..31) and the replay loop on the scalar unit
+struct StripLaneEnv {
+  int modev, ytv, ybv;     // static mode, lowest / highest texel row read (lane r = pixel row r)
+  int ctlv, yfv;           // result: StripStep.ctl / .yfirst of row r on lane r
+  int ringv;               // ring slot i -> sequence number of its last load, on lane i
+  __device__ __forceinline__ int mode(int r) const { return __builtin_amdgcn_readlane(modev, r); }
+  __device__ __forceinline__ int yt(int r) const { return __builtin_amdgcn_readlane(ytv, r); }
+  __device__ __forceinline__ int yb(int r) const { return __builtin_amdgcn_readlane(ybv, r); }
+  __device__ __forceinline__ void set_step(int r, int ctl, int yfirst) {
+    ctlv = write_lane(ctl, r, ctlv);
+    yfv = write_lane(yfirst, r, yfv);
+  }
+  __device__ __forceinline__ int ring_get(int i) const { return __builtin_amdgcn_readlane(ringv, i); }
+  __device__ __forceinline__ void ring_set(int i, int v) { ringv = write_lane(v, i, ringv); }
+};
 
 // ---- asynchronous loads the compiler does not see (its s_waitcnt bookkeeping would drain them) ----------------------
 // 1 KB from global memory straight into LDS: lane i's 16 bytes go to lds_dst + 16 i (wave-uniform M0 base + lane x 16)
@@ -247,7 +278,6 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
   __shared__ __attribute__((aligned(16))) float sWin[kSWaves][kWinFloats];    // the rolling window: [slot][texel][32 channels]
   __shared__ __attribute__((aligned(16))) StripStep sPlan[kSWaves][kStripH];
   __shared__ __attribute__((aligned(16))) float sScr[kSWaves][kC128s];        // row statistics (plan input), later C x sum|d|
-  __shared__ int sRing[kSWaves][8];
   const banet_level_t& lv = a.lv;
   const int b = blockIdx.y;
   if (a.active != nullptr && a.active[(size_t)b * a.active_stride] == 0) return;
@@ -259,12 +289,17 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
   const float* __restrict__ dep_b = lv.depth + (size_t)b * N;
   const float* __restrict__ bas_b = KV4 ? lv.basis + (size_t)b * N * K : nullptr;
   const int nitems = a.tiles, segs_y = a.tiles_y;
-  const int g = lane >> 3, q = lane & 7;          // tap phase: pixel g of the instruction group, channel quad q
+  // tap phase: a step is one pixel row; lane = (pixel column pc, channel octet oc): 4 lanes per pixel, 8 channels per lane
+  // as two 16-byte pieces of the texel's 128-byte slice -- pieces 4 hA + oc and 4 (1 - hA) + oc with hA = bit 1 of pc, which
+  // keeps the ds_read_b128 lane groups (4 pixels x 4 lanes) on 64 distinct banks when neighbouring pixels hit neighbouring
+  // texels (a texel is 32 banks wide)
+  const int pc = lane >> 2, oc = lane & 3, hA = (lane >> 3) & 1;
+  const int jA = 4 * hA + oc, jB = 4 * (1 - hA) + oc;
   const int half = lane >> 5, li = lane & 31;     // depth dot: one basis row per half wave
-  // lane = pixel phases: this lane owns pixel 8 q + g of a chunk (4 pixel rows x 16): row q >> 1, column 8 (q & 1) + g
-  const int pk = q >> 1, pcol = 8 * (q & 1) + g;
+  // lane = pixel phases: this lane owns pixel (row oc, column pc) of a chunk (4 pixel rows x 16)
   const unsigned win_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&sWin[w][0];
-  const unsigned lane_off = (unsigned)(g * 512 + q * 16);   // byte offset of (texel / pixel g, channel quad q) in a global row run
+  const unsigned dma_off = (unsigned)((lane >> 3) * 512 + (lane & 7) * 16);   // LDS-DMA: (texel lane >> 3 of an 8-texel run, piece lane & 7)
+  const unsigned srcA_off = (unsigned)(pc * 512 + jA * 16), srcB_off = (unsigned)(pc * 512 + jB * 16);
   StripRowStat* sStat = reinterpret_cast<StripRowStat*>(&sScr[w][0]);
 
   float wreg[KV4 ? KV4 : 1][4];  // this lane's slice of the depth coefficients
@@ -292,12 +327,12 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
     if (wi >= nitems) return;
     raw_next = pop_raw();  // issued now, read at the top of the next item
     const int sx = wi / segs_y, sy = wi - sx * segs_y;
-    const int px = sx * kStripW + pcol;                       // this lane's pixel column (all chunks)
-    const int py0 = sy * kStripH + pk;                        // its pixel row in chunk 0 (+ 4 per chunk)
+    const int px = sx * kStripW + pc;                         // this lane's pixel column (all chunks)
+    const int py0 = sy * kStripH + oc;                        // its pixel row in chunk 0 (+ 4 per chunk)
 
     BANET_TICK(ts0);
 #ifdef BANET_TIMING
-    float ts_wait = 0.f, ts_taps = 0.f;
+    float ts_wait = 0.f;
 #endif
     // ---- 1. depth of every pixel of the segment: D = D0 + b . W, chunk by chunk (once per window) ----------------------
     f32x8 Dv;
@@ -308,17 +343,17 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
       float D = valid ? dep_b[py * W + px] : 0.f;
       if constexpr (KV4 > 0) {
         float pend[6];
-        // 2 x 16 basis rows: the 16 (x KV4) loads of a batch are issued back to back into registers of their own, then
-        // consumed -- written as two loops so that the scheduler keeps them in flight together
+        // the basis rows of a batch are issued back to back into registers of their own, then consumed (two loops, so that
+        // the scheduler keeps them in flight together): all 32 rows of the half wave at K <= 128, 2 x 16 at K = 256
+        constexpr int NB = KV4 == 1 ? 1 : 2, BS = 32 / NB;
 #pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {
-          f32x4 bv[16][KV4];
+        for (int hb = 0; hb < NB; ++hb) {
+          f32x4 bv[BS][KV4];
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            // leaf i of half h ends on lane 32 h + brev5(i), which owns pixel 8 q' + g' of the chunk
-            const int ld = half * 32 + brev5s(16 * hb + i);
-            const int jq = ld & 7, jg = ld >> 3;
-            const int jx = sx * kStripW + 8 * (jq & 1) + jg, jy = sy * kStripH + 4 * c + (jq >> 1);
+          for (int i = 0; i < BS; ++i) {
+            // leaf i of half h ends on lane 32 h + brev5(i), which owns pixel (row ld & 3, column ld >> 2) of the chunk
+            const int ld = half * 32 + brev5s(BS * hb + i);
+            const int jx = sx * kStripW + (ld >> 2), jy = sy * kStripH + 4 * c + (ld & 3);
             const bool vj = (jx < W) && (jy < H);
             const float* row = bas_b + (size_t)(vj ? jy * W + jx : 0) * K;
 #pragma unroll
@@ -328,13 +363,13 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
             }
           }
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
+          for (int i = 0; i < BS; ++i) {
             float acc = 0.f;
 #pragma unroll
             for (int kc = 0; kc < KV4; ++kc)
 #pragma unroll
               for (int e = 0; e < 4; ++e) acc = fmaf(bv[i][kc][e], wreg[kc][e], acc);   // k >= K: wreg is 0
-            carry_push_s<5, 16>(pend, acc, 16 * hb + i);
+            carry_push_s<5, 16>(pend, acc, BS * hb + i);
           }
         }
         D += pend[5];
@@ -366,30 +401,54 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
         P0v[c] = (fast ? (ge.x0 | (ge.y0 << 12)) : 0) | (m7 << 24) | (fast ? (1 << 27) : 0);
         DXv[c] = ge.dx;
         DYv[c] = ge.dy;
-        // min / max of (x0, y0) over the 16 fast pixels of this lane's pixel row (lanes that agree in q >> 1)
+        // min / max of (x0, y0) over the 16 fast pixels of this lane's pixel row (lanes that agree in lane & 3)
         const int big = 0x3fffffff;
         int ymn = fast ? ge.y0 : big, ymx = fast ? ge.y0 : -big, xmn = fast ? ge.x0 : big, xmx = fast ? ge.x0 : -big;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int sh = s == 0 ? 1 : (4 << s);   // lane bits 0, 3, 4, 5
+        for (int sh = 4; sh < 64; sh <<= 1) {
           ymn = min(ymn, __shfl_xor(ymn, sh, 64));
           ymx = max(ymx, __shfl_xor(ymx, sh, 64));
           xmn = min(xmn, __shfl_xor(xmn, sh, 64));
           xmx = max(xmx, __shfl_xor(xmx, sh, 64));
         }
-        if (g == 0 && (q & 1) == 0) {
+        if (lane < 4) {
           StripRowStat st;
           st.ymin = ymn;
           st.ymax = ymx;
           st.xmin = xmn;
           st.xmax = xmx;
-          sStat[4 * c + pk] = st;
+          sStat[4 * c + lane] = st;
         }
       }
-      // the plan: every lane computes the same values (wave-uniform addresses, identical stores)
-      const int xl = rfl(strip_plan(sStat, kStripH, W, &sPlan[w][0], &sRing[w][0]));
-      if (lv.reserved_ & (1 << 20)) {   // parity tests: every pixel row takes the direct (window-less) path
-        if (lane < kStripH && step_mode(sPlan[w][lane].ctl) == kStepWindow) sPlan[w][lane].ctl = kStepDirect;
+      // the plan (strip_plan.hpp): lane r < 32 owns pixel row r for the static part, the replay loop is scalar
+      int xl;
+      {
+        StripRowStat st = sStat[lane & (kStripH - 1)];
+        if (lane >= kStripH) st.ymin = 1, st.ymax = 0;                    // lanes 32..63: no row
+        int xm = st.ymin <= st.ymax ? st.xmin : 0x3fffffff;
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) xm = min(xm, __shfl_xor(xm, sh, 64));
+        xl = rfl(strip_window_origin(xm, W));
+        StripLaneEnv env;
+        env.modev = strip_static_mode(st, xl, W);
+        env.ytv = st.ymin - 1;
+        env.ybv = st.ymax + 2;
+        env.ctlv = env.yfv = env.ringv = 0;
+        int ye = env.modev == kStepWindow ? env.ybv : -0x3fffffff;
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) ye = max(ye, __shfl_xor(ye, sh, 64));
+        strip_plan_dynamic(env, kStripH, rfl(ye));
+        if (lv.reserved_ & (1 << 20)) {   // parity tests: every pixel row takes the direct (window-less) path
+          if (step_mode(env.ctlv) == kStepWindow) env.ctlv = kStepDirect;
+        }
+        if (lane < kStripH) {
+          StripStep sp;
+          sp.ctl = env.ctlv;
+          sp.yfirst = env.yfv;
+          sp.ytop = env.ytv;
+          sp.pad = 0;
+          sPlan[w][lane] = sp;
+        }
       }
 
       BANET_TICK(ts2);
@@ -398,27 +457,27 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
       const int rowC = W * C;
 #pragma unroll 1
       for (int s = 0; s < 4; ++s) {
-        float absd[4] = {0.f, 0.f, 0.f, 0.f};   // |d| of channels 32 s + 4 q + e over every pixel this lane touches
+        float absA[4] = {0.f, 0.f, 0.f, 0.f}, absB[4] = {0.f, 0.f, 0.f, 0.f};   // |d| of this lane's two channel pieces
         const float* tgt_s = tgt_b + 32 * s;
-        // byte offset of (pixel row r, group t) of this segment's source rows, slice s: lane_off is added per lane
-        auto src_soff = [&](int r, int t) { return (unsigned)((((sy * kStripH + r) * W + sx * kStripW + 8 * t) * C + 32 * s) * 4); };
+        // byte offset of pixel row r of this segment's source rows, slice s (the lane's pixel and piece are added per lane)
+        auto src_soff = [&](int r) { return (unsigned)((((sy * kStripH + r) * W + sx * kStripW) * C + 32 * s) * 4); };
         auto issue_row = [&](int Y) __attribute__((always_inline)) {     // texel row Y, columns xl .. xl + 20 -> its ring slot
           const float* gb = tgt_s + ((size_t)Y * W + xl) * C;
           const unsigned dst = win_base + (unsigned)(Y % kWinRows) * (unsigned)kWinPitchB;
-          glds16(gb, lane_off, dst);
-          glds16(gb + 8 * C, lane_off, dst + 1024u);
-          if (lane < 8 * (kWinTex - 16)) glds16(gb + 16 * C, lane_off, dst + 2048u);
+          glds16(gb, dma_off, dst);
+          glds16(gb + 8 * C, dma_off, dst + 1024u);
+          if (lane < 8 * (kWinTex - 16)) glds16(gb + 16 * C, dma_off, dst + 2048u);
         };
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the counted section starts with nothing in flight
         {
           const int c0 = rfl(sPlan[w][0].ctl), c1 = rfl(sPlan[w][1].ctl);
           if (step_src_pre(c0)) {
-            src_issue<0, 0>(lane_off, rs_src, src_soff(0, 0));
-            src_issue<0, 1>(lane_off, rs_src, src_soff(0, 1));
+            src_issue<0, 0>(srcA_off, rs_src, src_soff(0));
+            src_issue<0, 1>(srcB_off, rs_src, src_soff(0));
           }
           if (step_src_pre(c1)) {
-            src_issue<1, 0>(lane_off, rs_src, src_soff(1, 0));
-            src_issue<1, 1>(lane_off, rs_src, src_soff(1, 1));
+            src_issue<1, 0>(srcA_off, rs_src, src_soff(1));
+            src_issue<1, 1>(srcB_off, rs_src, src_soff(1));
           }
         }
 #pragma unroll 1
@@ -426,8 +485,8 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
           const int p0c = P0v[c];
           const float dxc = DXv[c], dyc = DYv[c];
           float qacc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};    // this lane's pixel of chunk c, slice s
-          // step r = 4 c + k: one pixel row = instruction groups 2 k, 2 k + 1 of the chunk (k is a compile-time constant:
-          // the AGPR slots of the source features are named in the instruction text)
+          // step r = 4 c + k: pixel row k of the chunk (k is a compile-time constant: the registers of the source features
+          // are named in the instruction text, the parameter broadcast is a DPP quad_perm)
           auto do_step = [&](auto kconst) __attribute__((always_inline)) {
             constexpr int k = decltype(kconst)::value;
             const int r = 4 * c + k;
@@ -435,11 +494,18 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
             const int mode = step_mode(ctl);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the previous step's window reads are done (WAR)
             if (step_src_next(ctl)) {
-              src_issue<(k + 2) & 3, 0>(lane_off, rs_src, src_soff(r + kSrcAhead, 0));
-              src_issue<(k + 2) & 3, 1>(lane_off, rs_src, src_soff(r + kSrcAhead, 1));
+              src_issue<(k + 2) & 3, 0>(srcA_off, rs_src, src_soff(r + kSrcAhead));
+              src_issue<(k + 2) & 3, 1>(srcB_off, rs_src, src_soff(r + kSrcAhead));
             }
             if (mode == kStepSkip) return;
-            float4 fsrc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+            // parameters of pixel (row k, column pc) live on lane 4 pc + k: inside this lane's quad
+            const int p0 = quad_bcast<k>(p0c);
+            const float dx = quad_bcast<k>(dxc), dy = quad_bcast<k>(dyc);
+            const bool fast = (p0 >> 27) & 1;
+            const float mk = fast ? 1.f : 0.f;
+            const float w00 = mk * ((1.f - dx) * (1.f - dy)), w01 = mk * (dx * (1.f - dy)), w10 = mk * ((1.f - dx) * dy),
+                        w11 = mk * (dx * dy);
+            float qq[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
             if (mode == kStepWindow) {
               const int y0r = rfl(sPlan[w][r].yfirst), nr = step_nrows(ctl);
               for (int i = 0; i < nr; ++i) issue_row(y0r + i);
@@ -451,48 +517,42 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
               BANET_TICK(tw1);
               BANET_TACC(ts_wait, tw0, tw1);
 #endif
-              fsrc[0] = src_read<k, 0>();      // landed: behind the counted wait
-              fsrc[1] = src_read<k, 1>();
-            }
-            const int mtop = step_mtop(ctl);
+              const float4 fA = src_read<k, 0>(), fB = src_read<k, 1>();      // landed: behind the counted wait
+              const int mtop = step_mtop(ctl);
+              const int xr = fast ? (p0 & 0xfff) - 1 - xl : 0;             // window column of texel x0 - 1
+              const int m0 = fast ? (p0 >> 24) & 7 : mtop;                 // ring slot of texel row y0 - 1
+              const int m1i = m0 + 1 >= kWinRows ? m0 + 1 - kWinRows : m0 + 1;
+              const int m2i = m1i + 1 >= kWinRows ? m1i + 1 - kWinRows : m1i + 1;
+              const int m3i = m2i + 1 >= kWinRows ? m2i + 1 - kWinRows : m2i + 1;
+              const float* l = &sWin[w][0] + xr * 32;
+              const float* l0 = l + m0 * kWinPitchF;
+              const float* l1 = l + m1i * kWinPitchF;
+              const float* l2 = l + m2i * kWinPitchF;
+              const float* l3 = l + m3i * kWinPitchF;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-              const int gi = 2 * k + t;
-              // parameters of pixel 8 gi + g live on lane 8 g + gi: inside this lane's octet
-              const int sl = ((lane & ~7) | gi) << 2;
-              const int p0 = __builtin_amdgcn_ds_bpermute(sl, p0c);
-              const float dx = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sl, __builtin_bit_cast(int, dxc)));
-              const float dy = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sl, __builtin_bit_cast(int, dyc)));
-              const bool fast = (p0 >> 27) & 1;
-              const float mk = fast ? 1.f : 0.f;
-              const float w00 = mk * ((1.f - dx) * (1.f - dy)), w01 = mk * (dx * (1.f - dy)), w10 = mk * ((1.f - dx) * dy),
-                          w11 = mk * (dx * dy);
-              float qq[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-              if (mode == kStepWindow) {
-                const int xr = fast ? (p0 & 0xfff) - 1 - xl : 0;             // window column of texel x0 - 1
-                const int m0 = fast ? (p0 >> 24) & 7 : mtop;                 // ring slot of texel row y0 - 1
-                const int m1i = m0 + 1 >= kWinRows ? m0 + 1 - kWinRows : m0 + 1;
-                const int m2i = m1i + 1 >= kWinRows ? m1i + 1 - kWinRows : m1i + 1;
-                const int m3i = m2i + 1 >= kWinRows ? m2i + 1 - kWinRows : m2i + 1;
-                const float* l = &sWin[w][0] + xr * 32 + 4 * q;
-                const float* l0 = l + m0 * kWinPitchF;
-                const float* l1 = l + m1i * kWinPitchF;
-                const float* l2 = l + m2i * kWinPitchF;
-                const float* l3 = l + m3i * kWinPitchF;
-                const float4 f1 = fsrc[t];
-                const float4 a0 = *reinterpret_cast<const float4*>(l1), a1 = *reinterpret_cast<const float4*>(l1 + 32),
-                             a2 = *reinterpret_cast<const float4*>(l1 + 64), a3 = *reinterpret_cast<const float4*>(l1 + 96);
-                const float4 b0 = *reinterpret_cast<const float4*>(l2), b1 = *reinterpret_cast<const float4*>(l2 + 32),
-                             b2 = *reinterpret_cast<const float4*>(l2 + 64), b3 = *reinterpret_cast<const float4*>(l2 + 96);
-                const float4 m1 = *reinterpret_cast<const float4*>(l0 + 32), m2 = *reinterpret_cast<const float4*>(l0 + 64);
-                const float4 p1 = *reinterpret_cast<const float4*>(l3 + 32), p2 = *reinterpret_cast<const float4*>(l3 + 64);
-                tap_math_s(f1, a0, a1, a2, a3, b0, b1, b2, b3, m1, m2, p1, p2, w00, w01, w10, w11, mk, qq, absd);
-              } else {   // kStepDirect: the footprint of this pixel row does not fit the window -- taps straight from memory
-                const int x0 = fast ? (p0 & 0xfff) : 1, y0 = fast ? (p0 >> 12) & 0xfff : 1;
-                const int gpx = sx * kStripW + 8 * t + g, gpy = sy * kStripH + r;
-                const bool gv = (gpx < W) && (gpy < H);
-                const unsigned osrc = (unsigned)((gv ? gpy * W + gpx : 0) * C + 32 * s + 4 * q);
-                const unsigned oa = (unsigned)((y0 * W + x0) * C + 32 * s + 4 * q);
+              for (int hp = 0; hp < 2; ++hp) {      // the lane's two 16-byte pieces of every tap
+                const int po = 4 * (hp ? jB : jA);
+                const float4 f1 = hp ? fB : fA;
+                const float4 a0 = *reinterpret_cast<const float4*>(l1 + po), a1 = *reinterpret_cast<const float4*>(l1 + po + 32),
+                             a2 = *reinterpret_cast<const float4*>(l1 + po + 64), a3 = *reinterpret_cast<const float4*>(l1 + po + 96);
+                const float4 b0 = *reinterpret_cast<const float4*>(l2 + po), b1 = *reinterpret_cast<const float4*>(l2 + po + 32),
+                             b2 = *reinterpret_cast<const float4*>(l2 + po + 64), b3 = *reinterpret_cast<const float4*>(l2 + po + 96);
+                const float4 m1 = *reinterpret_cast<const float4*>(l0 + po + 32), m2 = *reinterpret_cast<const float4*>(l0 + po + 64);
+                const float4 p1 = *reinterpret_cast<const float4*>(l3 + po + 32), p2 = *reinterpret_cast<const float4*>(l3 + po + 64);
+                if (hp)
+                  tap_math_s(f1, a0, a1, a2, a3, b0, b1, b2, b3, m1, m2, p1, p2, w00, w01, w10, w11, mk, qq, absB);
+                else
+                  tap_math_s(f1, a0, a1, a2, a3, b0, b1, b2, b3, m1, m2, p1, p2, w00, w01, w10, w11, mk, qq, absA);
+              }
+            } else {   // kStepDirect: the footprint of this pixel row does not fit the window -- taps straight from memory
+              const int x0 = fast ? (p0 & 0xfff) : 1, y0 = fast ? (p0 >> 12) & 0xfff : 1;
+              const int gpx = sx * kStripW + pc, gpy = sy * kStripH + r;
+              const bool gv = (gpx < W) && (gpy < H);
+#pragma unroll
+              for (int hp = 0; hp < 2; ++hp) {
+                const int po = 32 * s + 4 * (hp ? jB : jA);
+                const unsigned osrc = (unsigned)((gv ? gpy * W + gpx : 0) * C + po);
+                const unsigned oa = (unsigned)((y0 * W + x0) * C + po);
                 const float* ra = tgt_b + (size_t)oa;
                 const float* rb = ra + rowC;
                 const float* rm = ra - rowC;
@@ -505,13 +565,16 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
                              b2 = *reinterpret_cast<const float4*>(rb + C), b3 = *reinterpret_cast<const float4*>(rb + 2 * C);
                 const float4 m1 = *reinterpret_cast<const float4*>(rm), m2 = *reinterpret_cast<const float4*>(rm + C);
                 const float4 p1 = *reinterpret_cast<const float4*>(rp), p2 = *reinterpret_cast<const float4*>(rp + C);
-                tap_math_s(f1, a0, a1, a2, a3, b0, b1, b2, b3, m1, m2, p1, p2, w00, w01, w10, w11, mk, qq, absd);
+                if (hp)
+                  tap_math_s(f1, a0, a1, a2, a3, b0, b1, b2, b3, m1, m2, p1, p2, w00, w01, w10, w11, mk, qq, absB);
+                else
+                  tap_math_s(f1, a0, a1, a2, a3, b0, b1, b2, b3, m1, m2, p1, p2, w00, w01, w10, w11, mk, qq, absA);
               }
+            }
 #pragma unroll
-              for (int i = 0; i < 5; ++i) {
-                const float tot = oct_sum(qq[i]);
-                qacc[i] += (q == gi) ? tot : 0.f;       // the lane that owns pixel 8 gi + g keeps it
-              }
+            for (int i = 0; i < 5; ++i) {
+              const float tot = quad_sum(qq[i]);
+              qacc[i] += (oc == k) ? tot : 0.f;       // the lane that owns pixel (row k, column pc) keeps it
             }
           };
           do_step(IC<0>{});
@@ -525,14 +588,20 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
           Q4[c] += qacc[4];
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // the slice's 32 x sum|d|: fold the 8 pixel lanes of every channel quad (fixed order), octet 0 publishes
+        // the slice's 32 x sum|d|: piece oc (channels 4 oc + e) and piece 4 + oc of every lane, folded over the 16 pixel
+        // columns (fixed order); lanes 0..3 publish
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float v = absd[e];
-          v += __shfl_xor(v, 8, 64);
-          v += __shfl_xor(v, 16, 64);
-          v += __shfl_xor(v, 32, 64);
-          if (g == 0) sScr[w][32 * s + 4 * q + e] = v;
+          float lo = hA ? absB[e] : absA[e], hi = hA ? absA[e] : absB[e];
+#pragma unroll
+          for (int sh = 4; sh < 64; sh <<= 1) {
+            lo += __shfl_xor(lo, sh, 64);
+            hi += __shfl_xor(hi, sh, 64);
+          }
+          if (lane < 4) {
+            sScr[w][32 * s + 4 * oc + e] = lo;
+            sScr[w][32 * s + 16 + 4 * oc + e] = hi;
+          }
         }
       }
 
@@ -644,7 +713,6 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
 #endif
           part[30] = (float)(ts9 - ts3);       // rim, algebra, records, partial row
           part[31] = (float)(ts9 - ts0);       // whole segment
-          (void)ts_taps;
         }
       }
 #endif

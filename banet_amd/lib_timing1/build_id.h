@@ -1,1 +1,1 @@
-#define BANET_BUILD_ID "d2d19c1a2b8c7123"
+#define BANET_BUILD_ID "c5a9043dde3d5b89"

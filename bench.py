@@ -113,6 +113,15 @@ class Problem:
                 "lambda_last_mean": round(float(st.lambda_out.mean()), 3)}
 
 
+def gather_kernel_names(ba):
+    """which gather kernel every level of this batch runs (banet_gather_selection)"""
+    try:
+        from banet_amd import ops
+        return " / ".join("%dx%d: %s" % (p.c.W, p.c.H, ops.GATHER_KERNELS[ops.gather_selection(p)]) for p in ba.problems)
+    except Exception:      # a stand-in problem object (tests/test_capi_cpu.py)
+        return "ba_gather128s_kernel / ba_gather128p_kernel / ba_gather128_kernel by level size (banet_gather_selection)"
+
+
 def roofline_record(prob, prof, elapsed_s, traffic=None):
     """Roofline of the dominant kernel (the gather): algorithmic bytes of the pass it streams / its measured time,
     summed over every launch of the timed region (all levels), per-level breakdown included."""
@@ -151,8 +160,7 @@ def roofline_record(prob, prof, elapsed_s, traffic=None):
             # kernel runs to what a streaming copy reaches on this part (MI355X_MICROARCH.md: ~6.3 of the 8 TB/s)
             "traffic_GBps": round(traffic / max(kern_ms / max(nlaunch, 1), 1e-9) / 1e6, 1) if traffic else None,
             "streaming_copy_GBps": HBM_STREAM_GBS,
-            "kernel": " / ".join("%dx%d: %s" % (p.c.W, p.c.H, __import__("banet_amd.ops", fromlist=["x"]).GATHER_KERNELS[
-                __import__("banet_amd.ops", fromlist=["x"]).gather_selection(p)]) for p in ba.problems),
+            "kernel": gather_kernel_names(ba),
             "launches": nlaunch, "avg_launch_us": round(1e3 * kern_ms / max(nlaunch, 1), 2),
             "algorithmic_bytes_per_launch": round(alg_bytes / max(nlaunch, 1)),
             "kernel_time_share": round(kern_ms / (1e3 * elapsed_s), 4),
