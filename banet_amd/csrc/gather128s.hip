@@ -140,24 +140,23 @@ template <int N>
 __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-__device__ __forceinline__ void wait_vmcnt(int n) {   // n wave-uniform, 0 .. kMaxWait (a smaller count is always safe)
-  switch (n) {
-    case 0: wait_vm<0>(); break;
-    case 1: wait_vm<1>(); break;
-    case 2: wait_vm<2>(); break;
-    case 3: wait_vm<3>(); break;
-    case 4: wait_vm<4>(); break;
-    case 5: wait_vm<5>(); break;
-    case 6: wait_vm<6>(); break;
-    case 7: wait_vm<7>(); break;
-    case 8: wait_vm<8>(); break;
-    case 9: wait_vm<9>(); break;
-    case 10: wait_vm<10>(); break;
-    case 11: wait_vm<11>(); break;
-    case 12: wait_vm<12>(); break;
-    case 13: wait_vm<13>(); break;
-    case 14: wait_vm<14>(); break;
-    default: wait_vm<15>(); break;
+__device__ __forceinline__ void wait_vmcnt(int n) {   // n wave-uniform, 0 .. kMaxWait; rounds DOWN to an even count (a smaller
+  if (n >= 8) {                                        // count is always safe): 3 scalar branches instead of a 16-way switch
+    if (n >= 12) {
+      if (n >= 14) wait_vm<14>();
+      else wait_vm<12>();
+    } else {
+      if (n >= 10) wait_vm<10>();
+      else wait_vm<8>();
+    }
+  } else {
+    if (n >= 4) {
+      if (n >= 6) wait_vm<6>();
+      else wait_vm<4>();
+    } else {
+      if (n >= 2) wait_vm<2>();
+      else wait_vm<0>();
+    }
   }
 }
 static_assert(kMaxWait == 15, "wait_vmcnt implements counts up to 15");
@@ -276,7 +275,6 @@ __device__ __forceinline__ void strip_geometry(const banet_level_t& lv, int b, c
 template <int KV4>
 __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVgprs / 2))) void ba_gather128s_kernel(const GatherArgs a) {
   __shared__ __attribute__((aligned(16))) float sWin[kSWaves][kWinFloats];    // the rolling window: [slot][texel][32 channels]
-  __shared__ __attribute__((aligned(16))) StripStep sPlan[kSWaves][kStripH];
   __shared__ __attribute__((aligned(16))) float sScr[kSWaves][kC128s];        // row statistics (plan input), later C x sum|d|
   const banet_level_t& lv = a.lv;
   const int b = blockIdx.y;
@@ -336,45 +334,70 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
 #endif
     // ---- 1. depth of every pixel of the segment: D = D0 + b . W, chunk by chunk (once per window) ----------------------
     f32x8 Dv;
-#pragma unroll 1
-    for (int c = 0; c < 8; ++c) {
-      const int py = py0 + 4 * c;
-      const bool valid = (px < W) && (py < H);
-      float D = valid ? dep_b[py * W + px] : 0.f;
-      if constexpr (KV4 > 0) {
-        float pend[6];
-        // the basis rows of a batch are issued back to back into registers of their own, then consumed (two loops, so that
-        // the scheduler keeps them in flight together): all 32 rows of the half wave at K <= 128, 2 x 16 at K = 256
-        constexpr int NB = KV4 == 1 ? 1 : 2, BS = 32 / NB;
+    if constexpr (KV4 > 0) {
+      // batches of RB basis rows (16 at K <= 128, 8 at K = 256: 64 registers per buffer): batch n + 1 is in flight while
+      // batch n is reduced (two register buffers, sched_barrier keeps the issue order), so the depth dot exposes one memory
+      // latency per segment instead of one per batch
+      constexpr int RB = KV4 == 1 ? 16 : 8, NB = 32 / RB;
+      f32x4 bv[2][RB][KV4];
+      auto issue_batch = [&](auto bufc, int c, int hb) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(bufc)::value;
 #pragma unroll
-        for (int hb = 0; hb < NB; ++hb) {
-          f32x4 bv[BS][KV4];
+        for (int i = 0; i < RB; ++i) {
+          // leaf i of half h ends on lane 32 h + brev5(i), which owns pixel (row ld & 3, column ld >> 2) of the chunk
+          const int ld = half * 32 + brev5s(RB * hb + i);
+          const int jx = sx * kStripW + (ld >> 2), jy = sy * kStripH + 4 * c + (ld & 3);
+          const bool vj = (jx < W) && (jy < H);
+          const float* row = bas_b + (size_t)(vj ? jy * W + jx : 0) * K;
 #pragma unroll
-          for (int i = 0; i < BS; ++i) {
-            // leaf i of half h ends on lane 32 h + brev5(i), which owns pixel (row ld & 3, column ld >> 2) of the chunk
-            const int ld = half * 32 + brev5s(BS * hb + i);
-            const int jx = sx * kStripW + (ld >> 2), jy = sy * kStripH + 4 * c + (ld & 3);
-            const bool vj = (jx < W) && (jy < H);
-            const float* row = bas_b + (size_t)(vj ? jy * W + jx : 0) * K;
-#pragma unroll
-            for (int kc = 0; kc < KV4; ++kc) {
-              const int k = kc * 128 + li * 4;
-              bv[i][kc] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row + (k < K ? k : 0)));
-            }
-          }
-#pragma unroll
-          for (int i = 0; i < BS; ++i) {
-            float acc = 0.f;
-#pragma unroll
-            for (int kc = 0; kc < KV4; ++kc)
-#pragma unroll
-              for (int e = 0; e < 4; ++e) acc = fmaf(bv[i][kc][e], wreg[kc][e], acc);   // k >= K: wreg is 0
-            carry_push_s<5, 16>(pend, acc, BS * hb + i);
+          for (int kc = 0; kc < KV4; ++kc) {
+            const int k = kc * 128 + li * 4;
+            bv[BUF][i][kc] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row + (k < K ? k : 0)));
           }
         }
+      };
+      auto reduce_batch = [&](auto bufc, float (&pend)[6], int hb) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(bufc)::value;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+          float acc = 0.f;
+#pragma unroll
+          for (int kc = 0; kc < KV4; ++kc)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = fmaf(bv[BUF][i][kc][e], wreg[kc][e], acc);   // k >= K: wreg is 0
+          carry_push_s<5, 16>(pend, acc, RB * hb + i);
+        }
+      };
+      issue_batch(IC<0>{}, 0, 0);
+#pragma unroll 1
+      for (int c = 0; c < 8; ++c) {
+        const int py = py0 + 4 * c;
+        const bool valid = (px < W) && (py < H);
+        float D = valid ? dep_b[py * W + px] : 0.f;
+        float pend[6];
+#pragma unroll
+        for (int hb = 0; hb < NB; ++hb) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (hb + 1 < NB) {                       // the next batch of this chunk ...
+            if ((hb & 1) == 0) issue_batch(IC<1>{}, c, hb + 1);
+            else issue_batch(IC<0>{}, c, hb + 1);
+          } else if (c < 7) {                      // ... or the first one of the next chunk (NB is even: buffer 0)
+            issue_batch(IC<0>{}, c + 1, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if ((hb & 1) == 0) reduce_batch(IC<0>{}, pend, hb);
+          else reduce_batch(IC<1>{}, pend, hb);
+        }
         D += pend[5];
+        Dv[c] = D;
       }
-      Dv[c] = D;
+    } else {
+#pragma unroll 1
+      for (int c = 0; c < 8; ++c) {
+        const int py = py0 + 4 * c;
+        const bool valid = (px < W) && (py < H);
+        Dv[c] = valid ? dep_b[py * W + px] : 0.f;
+      }
     }
 
     BANET_TICK(ts1);
@@ -421,7 +444,7 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
         }
       }
       // the plan (strip_plan.hpp): lane r < 32 owns pixel row r for the static part, the replay loop is scalar
-      int xl;
+      int xl, ncol3, plan_ctl, plan_yf;       // the plan: StripStep.ctl / .yfirst of pixel row r on lane r (read with v_readlane)
       {
         StripRowStat st = sStat[lane & (kStripH - 1)];
         if (lane >= kStripH) st.ymin = 1, st.ymax = 0;                    // lanes 32..63: no row
@@ -435,20 +458,22 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
         env.ybv = st.ymax + 2;
         env.ctlv = env.yfv = env.ringv = 0;
         int ye = env.modev == kStepWindow ? env.ybv : -0x3fffffff;
+        int xe = env.modev == kStepWindow ? st.xmax + 2 - xl : 0;      // last window column any row served from the window reads
 #pragma unroll
-        for (int sh = 1; sh < 64; sh <<= 1) ye = max(ye, __shfl_xor(ye, sh, 64));
+        for (int sh = 1; sh < 64; sh <<= 1) {
+          ye = max(ye, __shfl_xor(ye, sh, 64));
+          xe = max(xe, __shfl_xor(xe, sh, 64));
+        }
+        // lanes of the third LDS-DMA instruction of a window row (texels 16 .. xe, 8 lanes each): the 21-texel pitch is the
+        // capacity, a unit-scale segment reads 19 or 20 of them -- the rest is not fetched.  At least one texel: the plan
+        // counts kRowOps = 3 operations per row, and an instruction whose lanes are all off is branched around.
+        ncol3 = 8 * max(rfl(xe) + 1 - 16, 1);
         strip_plan_dynamic(env, kStripH, rfl(ye));
         if (lv.reserved_ & (1 << 20)) {   // parity tests: every pixel row takes the direct (window-less) path
           if (step_mode(env.ctlv) == kStepWindow) env.ctlv = kStepDirect;
         }
-        if (lane < kStripH) {
-          StripStep sp;
-          sp.ctl = env.ctlv;
-          sp.yfirst = env.yfv;
-          sp.ytop = env.ytv;
-          sp.pad = 0;
-          sPlan[w][lane] = sp;
-        }
+        plan_ctl = env.ctlv;
+        plan_yf = env.yfv;
       }
 
       BANET_TICK(ts2);
@@ -461,16 +486,16 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
         const float* tgt_s = tgt_b + 32 * s;
         // byte offset of pixel row r of this segment's source rows, slice s (the lane's pixel and piece are added per lane)
         auto src_soff = [&](int r) { return (unsigned)((((sy * kStripH + r) * W + sx * kStripW) * C + 32 * s) * 4); };
-        auto issue_row = [&](int Y) __attribute__((always_inline)) {     // texel row Y, columns xl .. xl + 20 -> its ring slot
+        auto issue_row = [&](int Y, int slot) __attribute__((always_inline)) {     // texel row Y, columns xl .. xl + 20 -> ring slot Y mod 7
           const float* gb = tgt_s + ((size_t)Y * W + xl) * C;
-          const unsigned dst = win_base + (unsigned)(Y % kWinRows) * (unsigned)kWinPitchB;
+          const unsigned dst = win_base + (unsigned)slot * (unsigned)kWinPitchB;
           glds16(gb, dma_off, dst);
           glds16(gb + 8 * C, dma_off, dst + 1024u);
-          if (lane < 8 * (kWinTex - 16)) glds16(gb + 16 * C, dma_off, dst + 2048u);
+          if (lane < ncol3) glds16(gb + 16 * C, dma_off, dst + 2048u);
         };
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the counted section starts with nothing in flight
         {
-          const int c0 = rfl(sPlan[w][0].ctl), c1 = rfl(sPlan[w][1].ctl);
+          const int c0 = __builtin_amdgcn_readlane(plan_ctl, 0), c1 = __builtin_amdgcn_readlane(plan_ctl, 1);
           if (step_src_pre(c0)) {
             src_issue<0, 0>(srcA_off, rs_src, src_soff(0));
             src_issue<0, 1>(srcB_off, rs_src, src_soff(0));
@@ -490,7 +515,7 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
           auto do_step = [&](auto kconst) __attribute__((always_inline)) {
             constexpr int k = decltype(kconst)::value;
             const int r = 4 * c + k;
-            const int ctl = rfl(sPlan[w][r].ctl);
+            const int ctl = __builtin_amdgcn_readlane(plan_ctl, r);
             const int mode = step_mode(ctl);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the previous step's window reads are done (WAR)
             if (step_src_next(ctl)) {
@@ -507,8 +532,12 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
                         w11 = mk * (dx * dy);
             float qq[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
             if (mode == kStepWindow) {
-              const int y0r = rfl(sPlan[w][r].yfirst), nr = step_nrows(ctl);
-              for (int i = 0; i < nr; ++i) issue_row(y0r + i);
+              const int y0r = __builtin_amdgcn_readlane(plan_yf, r), nr = step_nrows(ctl);
+              int slot = y0r % kWinRows;
+              for (int i = 0; i < nr; ++i) {
+                issue_row(y0r + i, slot);
+                slot = slot + 1 == kWinRows ? 0 : slot + 1;
+              }
 #if defined(BANET_TIMING) && BANET_TIMING == 1
               BANET_TICK(tw0);
 #endif
@@ -608,7 +637,9 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
       BANET_TICK(ts3);
       // ---- 4. per-pixel 6x6 algebra (lane = pixel), records, the segment's 28 pose sums ------------------------------------
       float absd2[1][2] = {{0.f, 0.f}};  // rim pixels (generic routine: channels 2 lane, 2 lane + 1)
-      float tot_acc = 0.f;
+      float accp[28];                     // this lane's 8 pixels: upper triangle of Jc^T M Jc (21), Jc^T g (6), valid count
+#pragma unroll
+      for (int i = 0; i < 28; ++i) accp[i] = 0.f;
 #pragma unroll 1
       for (int c = 0; c < 8; ++c) {
         const int py = py0 + 4 * c;
@@ -653,25 +684,19 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
           mj[i] = qv.m11 * jc[i] + qv.m12 * jc[6 + i];
           mj[6 + i] = qv.m12 * jc[i] + qv.m22 * jc[6 + i];
         }
-        // leaves 0..20: upper triangle of Jc^T M Jc, 21..26: Jc^T g, 27: valid count, 28..31: zero.
-        // 5 levels (lane distance 32..2) + one xor-1 add: lane l ends with leaf brev5(l >> 1).
-        float pend[6];
-        int o = 0;
+        {   // chunks in order 0..7: fixed summation order
+          int o = 0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+          for (int i = 0; i < 6; ++i)
 #pragma unroll
-          for (int jj = i; jj < 6; ++jj) {
-            carry_push_s<5, 32>(pend, jc[i] * mj[jj] + jc[6 + i] * mj[6 + jj], o);
-            ++o;
-          }
+            for (int jj = i; jj < 6; ++jj) {
+              accp[o] += jc[i] * mj[jj] + jc[6 + i] * mj[6 + jj];
+              ++o;
+            }
 #pragma unroll
-        for (int i = 0; i < 6; ++i) carry_push_s<5, 32>(pend, jc[i] * qv.g1 + jc[6 + i] * qv.g2, 21 + i);
-        carry_push_s<5, 32>(pend, (float)(ge.flags & 1), 27);
-#pragma unroll
-        for (int i = 28; i < 32; ++i) carry_push_s<5, 32>(pend, 0.f, i);
-        float tot = pend[5];
-        tot += dpp_mov<kDppXor1>(tot);
-        tot_acc += tot;                       // chunks in order 0..7: fixed summation order
+          for (int i = 0; i < 6; ++i) accp[21 + i] += jc[i] * qv.g1 + jc[6 + i] * qv.g2;
+          accp[27] += (float)(ge.flags & 1);
+        }
 
         if constexpr (KV4 > 0) {
           if (valid) {
@@ -692,8 +717,17 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
         }
       }
       {
+        // the segment's 28 pose sums: leaves 0..27 = accp, 28..31 zero; 5 levels of the transposing butterfly (lane distance
+        // 32..2) + one xor-1 add: lane l ends with leaf brev5(l >> 1)
+        float pend[6];
+#pragma unroll
+        for (int i = 0; i < 28; ++i) carry_push_s<5, 32>(pend, accp[i], i);
+#pragma unroll
+        for (int i = 28; i < 32; ++i) carry_push_s<5, 32>(pend, 0.f, i);
+        float tot = pend[5];
+        tot += dpp_mov<kDppXor1>(tot);
         const int leaf = brev5s(lane >> 1);
-        if ((lane & 1) == 0 && leaf < 28) part[leaf] = tot_acc;
+        if ((lane & 1) == 0 && leaf < 28) part[leaf] = tot;
       }
       // ---- 5. the segment's C x sum|d| ----------------------------------------------------------------------------------------
       sScr[w][2 * lane] += absd2[0][0];       // same wave: LDS operations retire in program order

@@ -1,1 +1,1 @@
-#define BANET_BUILD_ID "c5a9043dde3d5b89"
+#define BANET_BUILD_ID "be40c2ceddc8e865"

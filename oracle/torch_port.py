@@ -45,8 +45,11 @@ def prepare_level(intr, scale, src, tgt, depth, basis, normalize_rays=True, dtyp
                 tmap=tmap, src=src.reshape(B, N, C), depth=depth, basis=f(basis).reshape(B, N, K) if K > 0 else None)
 
 
-def assemble_prepared(L, R, T, Wc, bundle):
-    """-> AtA [B,P,P], Atb [B,P], absres [B,C], nvalid [B] at the pose (R, T, Wc); L = prepare_level(...)"""
+def assemble_prepared(L, R, T, Wc, bundle, stats=None):
+    """-> AtA [B,P,P], Atb [B,P], absres [B,C], nvalid [B] at the pose (R, T, Wc); L = prepare_level(...).
+    stats: optional dict; receives "borderline" [B] = pixels whose projection lies within 4e-6 x max(W, H) pixels of the
+    in-image mask's boundary (bundlenet.py:155,231): at such a state float32 and float64 arithmetic can legitimately disagree
+    on the pixel's mask bit, which changes every sum by one pixel's worth (the parity gates account for it)."""
     B, H, W, C, N, K = L["B"], L["H"], L["W"], L["C"], L["N"], L["K"]
     dtype = L["tmap"].dtype
     p, fx, fy, ox, oy = L["p"], L["fx"], L["fy"], L["ox"], L["oy"]
@@ -60,6 +63,11 @@ def assemble_prepared(L, R, T, Wc, bundle):
     x, y, Z = X[:, 0] / X[:, 2], X[:, 1] / X[:, 2], X[:, 2]
     px, py = fx * x + ox, fy * y + oy
     mask = ((px >= 0) & (px <= W - 1) & (py >= 0) & (py <= H - 1)).to(dtype)
+    if stats is not None:
+        e = 4e-6 * max(W, H)
+        inx, iny = (px >= -e) & (px <= W - 1 + e), (py >= -e) & (py <= H - 1 + e)
+        near = (((px.abs() < e) | ((px - (W - 1)).abs() < e)) & iny) | (((py.abs() < e) | ((py - (H - 1)).abs() < e)) & inx)
+        stats["borderline"] = stats.get("borderline", 0) + near.sum(1)
     pxs = torch.where(mask > 0, px, torch.zeros_like(px))
     pys = torch.where(mask > 0, py, torch.zeros_like(py))
     x0f, y0f = torch.floor(pxs), torch.floor(pys)
@@ -165,7 +173,7 @@ def bundle_iteration(intr, scale, src, tgt, depth, basis, R, T, Wc, mlp, l2_base
 # --------------------------------------------------------------------------------------
 # multi-frame windows (restated in banet_oracle.bundle_window_iteration)
 # --------------------------------------------------------------------------------------
-def window_assemble(intr, scale, src, tgts, depth, basis, Rs, Ts, Wc, normalize_rays=True, dtype=torch.float64):
+def window_assemble(intr, scale, src, tgts, depth, basis, Rs, Ts, Wc, normalize_rays=True, dtype=torch.float64, stats=None):
     """Normal equations of one multi-frame window at the poses (Rs, Ts) and depth coefficients Wc, composed from the
     per-pair assemblies exactly as banet_oracle.bundle_window_iteration stacks its rows: parameter order
     [pose_1 .. pose_pairs, depth]; pose blocks on the diagonal, each pair's pose/depth cross block, the depth block and
@@ -184,7 +192,7 @@ def window_assemble(intr, scale, src, tgts, depth, basis, Rs, Ts, Wc, normalize_
     o = 6 * pairs
     for i in range(pairs):
         L = prepare_level(intr, scale, src, tgts[:, i], depth, basis, normalize_rays, dtype)
-        A, b, ab, nv = assemble_prepared(L, Rs[:, i], Ts[:, i], Wc, True)
+        A, b, ab, nv = assemble_prepared(L, Rs[:, i], Ts[:, i], Wc, True, stats)
         del L
         AtA[:, 6 * i:6 * i + 6, 6 * i:6 * i + 6] = A[:, :6, :6]
         AtA[:, 6 * i:6 * i + 6, o:] = A[:, :6, 6:]
@@ -202,7 +210,8 @@ def window_iteration(intr, scale, src, tgts, depth, basis, Rs, Ts, Wc, mlp, l2_b
     pairs, last coefficient undamped, LU solve, per-frame SE(3) update) -> (Rs', Ts', W', dict(lam, solution, AtA, Atb))."""
     B, pairs = tgts.shape[0], tgts.shape[1]
     N = src.shape[1] * src.shape[2]
-    AtA, Atb, absres, nv = window_assemble(intr, scale, src, tgts, depth, basis, Rs, Ts, Wc, True, dtype)
+    stats = {}
+    AtA, Atb, absres, nv = window_assemble(intr, scale, src, tgts, depth, basis, Rs, Ts, Wc, True, dtype, stats)
     avg = (absres / (N * pairs)).unsqueeze(1)
     mlp = [(torch.as_tensor(w).cpu().numpy() if not hasattr(w, "numpy") else w.cpu().numpy(),
             torch.as_tensor(b).cpu().numpy() if not hasattr(b, "numpy") else b.cpu().numpy()) for w, b in mlp]
@@ -219,4 +228,4 @@ def window_iteration(intr, scale, src, tgts, depth, basis, Rs, Ts, Wc, mlp, l2_b
         Tn.append(torch.matmul(V, sol[:, 6 * i + 3:6 * i + 6]) + torch.matmul(Rw, Ts[:, i].to(dtype).reshape(B, 3, 1)))
     Wn = Wc.to(dtype).reshape(B, -1, 1) + sol[:, 6 * pairs:]
     return torch.stack(Rn, 1), torch.stack(Tn, 1), Wn, dict(lam=lam.reshape(-1), solution=sol[..., 0], AtA=AtA, Atb=Atb,
-                                                             nvalid=nv.sum(1))
+                                                             nvalid=nv.sum(1), borderline=stats["borderline"])
