@@ -460,9 +460,16 @@ int plan_gather(const banet_level_t* lv, GatherPlan* pl) {
   pl->strip = 0;
   if (pl->c128 && lv->dense && !(lv->reserved_ & 524288) && lv->W >= kStripMinW && lv->W < 4096 && lv->H < 4096 &&
       (size_t)lv->N * lv->C * 4 < ((size_t)1 << 31)) {
-    const int sxn = (lv->W + kStripSegW - 1) / kStripSegW, syn = (lv->H + kStripSegH - 1) / kStripSegH;
+    // segment height: 32 rows (target rows fetched 35/32 x) when that leaves >= 4 segments per resident wave, else 16 rows
+    // (19/16 x, twice as many items), else not this kernel.  reserved_ bit 21: 16-row segments (parity tests, A/B).
+    const int sxn = (lv->W + kStripSegW - 1) / kStripSegW;
+    int segh = kStripSegH, syn = (lv->H + segh - 1) / segh;
+    if ((long long)sxn * syn * lv->B < 4LL * kCUs * 8 || (lv->reserved_ & (1 << 21))) {
+      segh = kStripSegH / 2;
+      syn = (lv->H + segh - 1) / segh;
+    }
     if ((long long)sxn * syn * lv->B >= 4LL * kCUs * 8 || (lv->reserved_ & 262144)) {
-      pl->strip = 1;
+      pl->strip = segh;
       pl->tiles_x = sxn;
       pl->tiles_y = syn;
       pl->tiles = sxn * syn;
@@ -625,6 +632,7 @@ int launch_gather(const banet_level_t* lv, const GatherPlan& pl, const float* R,
   a.pairs = npairs(lv);
   a.qshift = pl.qshift;
   a.pairloop = pl.pairloop;
+  a.seg_h = pl.strip;
   int rc;
   if (pl.c128)
     rc = pl.strip ? launch_gather128s(a, lv->K, s) : pl.patch ? launch_gather128p(a, lv->K, s) : launch_gather128(a, lv->K, s);

@@ -33,8 +33,15 @@ constexpr int kSWaves = kSBlock / kWave;
 constexpr int kWinFloats = kWinRows * kWinTex * 32;
 constexpr int kWinPitchF = kWinTex * 32;           // floats per window row
 
-typedef float f32x8 __attribute__((ext_vector_type(8)));
-typedef int i32x8 __attribute__((ext_vector_type(8)));
+template <int NCH> struct ChunkVec;     // per-chunk state of a segment of NCH chunks (= 4 NCH pixel rows): one register per chunk
+template <> struct ChunkVec<8> {
+  typedef float f __attribute__((ext_vector_type(8)));
+  typedef int i __attribute__((ext_vector_type(8)));
+};
+template <> struct ChunkVec<4> {
+  typedef float f __attribute__((ext_vector_type(4)));
+  typedef int i __attribute__((ext_vector_type(4)));
+};
 typedef float v2fs __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int brev5s(int t) { return (int)(__brev((unsigned)t) >> 27); }
@@ -272,8 +279,13 @@ __device__ __forceinline__ void strip_geometry(const banet_level_t& lv, int b, c
 }
 
 // KV4 = number of 128-coefficient chunks of a basis row (0: pose only; K % 4 == 0, K <= 128 KV4)
-template <int KV4>
+// NCH = chunks per segment: 8 (16 x 32 pixels, target rows fetched 35/32 x) where a launch has enough of them to fill the
+// chip evenly, 4 (16 x 16 pixels, 19/16 x) on launches with fewer, coarser items (gather.hip::plan_gather)
+template <int KV4, int NCH>
 __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVgprs / 2))) void ba_gather128s_kernel(const GatherArgs a) {
+  constexpr int SEGH = 4 * NCH;          // pixel rows per segment
+  typedef typename ChunkVec<NCH>::f fvec;
+  typedef typename ChunkVec<NCH>::i ivec;
   __shared__ __attribute__((aligned(16))) float sWin[kSWaves][kWinFloats];    // the rolling window: [slot][texel][32 channels]
   __shared__ __attribute__((aligned(16))) float sScr[kSWaves][kC128s];        // row statistics (plan input), later C x sum|d|
   const banet_level_t& lv = a.lv;
@@ -326,14 +338,14 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
     raw_next = pop_raw();  // issued now, read at the top of the next item
     const int sx = wi / segs_y, sy = wi - sx * segs_y;
     const int px = sx * kStripW + pc;                         // this lane's pixel column (all chunks)
-    const int py0 = sy * kStripH + oc;                        // its pixel row in chunk 0 (+ 4 per chunk)
+    const int py0 = sy * SEGH + oc;                        // its pixel row in chunk 0 (+ 4 per chunk)
 
     BANET_TICK(ts0);
 #ifdef BANET_TIMING
     float ts_wait = 0.f;
 #endif
     // ---- 1. depth of every pixel of the segment: D = D0 + b . W, chunk by chunk (once per window) ----------------------
-    f32x8 Dv;
+    fvec Dv;
     if constexpr (KV4 > 0) {
       // batches of RB basis rows (16 at K <= 128, 8 at K = 256: 64 registers per buffer): batch n + 1 is in flight while
       // batch n is reduced (two register buffers, sched_barrier keeps the issue order), so the depth dot exposes one memory
@@ -346,7 +358,7 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
         for (int i = 0; i < RB; ++i) {
           // leaf i of half h ends on lane 32 h + brev5(i), which owns pixel (row ld & 3, column ld >> 2) of the chunk
           const int ld = half * 32 + brev5s(RB * hb + i);
-          const int jx = sx * kStripW + (ld >> 2), jy = sy * kStripH + 4 * c + (ld & 3);
+          const int jx = sx * kStripW + (ld >> 2), jy = sy * SEGH + 4 * c + (ld & 3);
           const bool vj = (jx < W) && (jy < H);
           const float* row = bas_b + (size_t)(vj ? jy * W + jx : 0) * K;
 #pragma unroll
@@ -370,7 +382,7 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
       };
       issue_batch(IC<0>{}, 0, 0);
 #pragma unroll 1
-      for (int c = 0; c < 8; ++c) {
+      for (int c = 0; c < NCH; ++c) {
         const int py = py0 + 4 * c;
         const bool valid = (px < W) && (py < H);
         float D = valid ? dep_b[py * W + px] : 0.f;
@@ -381,7 +393,7 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
           if (hb + 1 < NB) {                       // the next batch of this chunk ...
             if ((hb & 1) == 0) issue_batch(IC<1>{}, c, hb + 1);
             else issue_batch(IC<0>{}, c, hb + 1);
-          } else if (c < 7) {                      // ... or the first one of the next chunk (NB is even: buffer 0)
+          } else if (c < NCH - 1) {                      // ... or the first one of the next chunk (NB is even: buffer 0)
             issue_batch(IC<0>{}, c + 1, 0);
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -393,7 +405,7 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
       }
     } else {
 #pragma unroll 1
-      for (int c = 0; c < 8; ++c) {
+      for (int c = 0; c < NCH; ++c) {
         const int py = py0 + 4 * c;
         const bool valid = (px < W) && (py < H);
         Dv[c] = valid ? dep_b[py * W + px] : 0.f;
@@ -411,10 +423,10 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
       const float* Tv = a.T + vb * 3;
 
       // ---- 2. geometry (lane = pixel): tap parameters of the whole segment + the row statistics the plan needs ----------
-      i32x8 P0v;       // x0 | y0 << 12 | ((y0 - 1) mod 7) << 24 | fast << 27
-      f32x8 DXv, DYv;
+      ivec P0v;       // x0 | y0 << 12 | ((y0 - 1) mod 7) << 24 | fast << 27
+      fvec DXv, DYv;
 #pragma unroll 1
-      for (int c = 0; c < 8; ++c) {
+      for (int c = 0; c < NCH; ++c) {
         const int py = py0 + 4 * c;
         const bool valid = (px < W) && (py < H);
         SGeo ge;
@@ -446,8 +458,8 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
       // the plan (strip_plan.hpp): lane r < 32 owns pixel row r for the static part, the replay loop is scalar
       int xl, ncol3, plan_ctl, plan_yf;       // the plan: StripStep.ctl / .yfirst of pixel row r on lane r (read with v_readlane)
       {
-        StripRowStat st = sStat[lane & (kStripH - 1)];
-        if (lane >= kStripH) st.ymin = 1, st.ymax = 0;                    // lanes 32..63: no row
+        StripRowStat st = sStat[lane & (SEGH - 1)];
+        if (lane >= SEGH) st.ymin = 1, st.ymax = 0;                    // lanes SEGH..63: no row
         int xm = st.ymin <= st.ymax ? st.xmin : 0x3fffffff;
 #pragma unroll
         for (int sh = 1; sh < 64; sh <<= 1) xm = min(xm, __shfl_xor(xm, sh, 64));
@@ -468,7 +480,7 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
         // capacity, a unit-scale segment reads 19 or 20 of them -- the rest is not fetched.  At least one texel: the plan
         // counts kRowOps = 3 operations per row, and an instruction whose lanes are all off is branched around.
         ncol3 = 8 * max(rfl(xe) + 1 - 16, 1);
-        strip_plan_dynamic(env, kStripH, rfl(ye));
+        strip_plan_dynamic(env, SEGH, rfl(ye));
         if (lv.reserved_ & (1 << 20)) {   // parity tests: every pixel row takes the direct (window-less) path
           if (step_mode(env.ctlv) == kStepWindow) env.ctlv = kStepDirect;
         }
@@ -478,14 +490,14 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
 
       BANET_TICK(ts2);
       // ---- 3. the four channel slices ---------------------------------------------------------------------------------------
-      f32x8 Q0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, Q1 = Q0, Q2 = Q0, Q3 = Q0, Q4 = Q0;   // per chunk: m11 m12 m22 g1 g2
+      fvec Q0 = 0.f, Q1 = 0.f, Q2 = 0.f, Q3 = 0.f, Q4 = 0.f;   // per chunk: m11 m12 m22 g1 g2
       const int rowC = W * C;
 #pragma unroll 1
       for (int s = 0; s < 4; ++s) {
         float absA[4] = {0.f, 0.f, 0.f, 0.f}, absB[4] = {0.f, 0.f, 0.f, 0.f};   // |d| of this lane's two channel pieces
         const float* tgt_s = tgt_b + 32 * s;
         // byte offset of pixel row r of this segment's source rows, slice s (the lane's pixel and piece are added per lane)
-        auto src_soff = [&](int r) { return (unsigned)((((sy * kStripH + r) * W + sx * kStripW) * C + 32 * s) * 4); };
+        auto src_soff = [&](int r) { return (unsigned)((((sy * SEGH + r) * W + sx * kStripW) * C + 32 * s) * 4); };
         auto issue_row = [&](int Y, int slot) __attribute__((always_inline)) {     // texel row Y, columns xl .. xl + 20 -> ring slot Y mod 7
           const float* gb = tgt_s + ((size_t)Y * W + xl) * C;
           const unsigned dst = win_base + (unsigned)slot * (unsigned)kWinPitchB;
@@ -506,7 +518,7 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
           }
         }
 #pragma unroll 1
-        for (int c = 0; c < 8; ++c) {
+        for (int c = 0; c < NCH; ++c) {
           const int p0c = P0v[c];
           const float dxc = DXv[c], dyc = DYv[c];
           float qacc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};    // this lane's pixel of chunk c, slice s
@@ -575,7 +587,7 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
               }
             } else {   // kStepDirect: the footprint of this pixel row does not fit the window -- taps straight from memory
               const int x0 = fast ? (p0 & 0xfff) : 1, y0 = fast ? (p0 >> 12) & 0xfff : 1;
-              const int gpx = sx * kStripW + pc, gpy = sy * kStripH + r;
+              const int gpx = sx * kStripW + pc, gpy = sy * SEGH + r;
               const bool gv = (gpx < W) && (gpy < H);
 #pragma unroll
               for (int hp = 0; hp < 2; ++hp) {
@@ -641,7 +653,7 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
 #pragma unroll
       for (int i = 0; i < 28; ++i) accp[i] = 0.f;
 #pragma unroll 1
-      for (int c = 0; c < 8; ++c) {
+      for (int c = 0; c < NCH; ++c) {
         const int py = py0 + 4 * c;
         const bool valid = (px < W) && (py < H);
         const int pt = valid ? py * W + px : 0;
@@ -756,14 +768,18 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
 
 int launch_gather128s(const GatherArgs& a, int K, hipStream_t s) {
   dim3 grid(a.G, a.lv.B), block(kSBlock);
-  if (K == 0)
-    hipLaunchKernelGGL((ba_gather128s_kernel<0>), grid, block, 0, s, a);
-  else if ((K & 3) == 0 && K <= 128)
-    hipLaunchKernelGGL((ba_gather128s_kernel<1>), grid, block, 0, s, a);
-  else if ((K & 3) == 0 && K <= 256)
-    hipLaunchKernelGGL((ba_gather128s_kernel<2>), grid, block, 0, s, a);
-  else
-    return BANET_ERR_UNSUPPORTED;
+  const bool tall = a.seg_h == 32;
+  if (a.seg_h != 32 && a.seg_h != 16) return BANET_ERR_INVALID_ARG;
+#define BANET_LAUNCH_S(KV4)                                                                     \
+  do {                                                                                          \
+    if (tall) hipLaunchKernelGGL((ba_gather128s_kernel<KV4, 8>), grid, block, 0, s, a);         \
+    else hipLaunchKernelGGL((ba_gather128s_kernel<KV4, 4>), grid, block, 0, s, a);              \
+  } while (0)
+  if (K == 0) BANET_LAUNCH_S(0);
+  else if ((K & 3) == 0 && K <= 128) BANET_LAUNCH_S(1);
+  else if ((K & 3) == 0 && K <= 256) BANET_LAUNCH_S(2);
+  else return BANET_ERR_UNSUPPORTED;
+#undef BANET_LAUNCH_S
   return BANET_OK;
 }
 

@@ -20,6 +20,7 @@ struct GatherArgs {
   int pairs;        // target frames per window: blockIdx.y = window * pairs + pair
   int pairloop;     // ba_gather128p_kernel: 1 = grid y = window, the window's target frames are looped over inside a tile
   int qshift;       // ba_gather128_kernel: 0 = a work item is a tile, 2 = a quarter tile (small levels)
+  int seg_h;        // ba_gather128s_kernel: pixel rows per strip segment (32 or 16)
 };
 
 template <int VEC>

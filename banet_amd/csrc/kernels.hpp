@@ -14,8 +14,8 @@ struct GatherPlan {
   int G, tiles, tiles_x, tiles_y, groups, pstride;
   int c128;     // 1: ba_gather128_kernel (dynamic tile queue, one partial row per tile)
   int patch;    // 1: ba_gather128p_kernel (same interface; taps from wave-private LDS patches) for large levels
-  int strip;    // 1: ba_gather128s_kernel (work items = 16 x 32-pixel strip segments, rolling LDS window); tiles_x / tiles_y /
-                //    tiles then count segments
+  int strip;    // ba_gather128s_kernel (work items = 16-pixel-wide strip segments, rolling LDS window): pixel rows per segment
+                //    (32 or 16; 0 = another kernel); tiles_x / tiles_y / tiles then count segments
   int rows;     // partial rows per window written by the gather kernel (tiles or G)
   int frows;    // rows per window handed to ba_reduce2_kernel (after ba_fold_kernel when rows > kFoldRows)
   int nbands;   // tile-queue bands (8 = one per XCD)
