@@ -460,14 +460,13 @@ int plan_gather(const banet_level_t* lv, GatherPlan* pl) {
   pl->strip = 0;
   if (pl->c128 && lv->dense && !(lv->reserved_ & 524288) && lv->W >= kStripMinW && lv->W < 4096 && lv->H < 4096 &&
       (size_t)lv->N * lv->C * 4 < ((size_t)1 << 31)) {
-    // segment height: 32 rows (target rows fetched 35/32 x) when that leaves >= 4 segments per resident wave, else 16 rows
-    // (19/16 x, twice as many items), else not this kernel.  reserved_ bit 21: 16-row segments (parity tests, A/B).
+    // segment height: 16 rows.  32-row segments fetch less (target rows 35/32 x instead of 19/16 x: launch 1.12 x vs 1.16 x the
+    // algorithmic bytes) but lose 5 % at every size measured (640x480 x 32: 3396 vs 3230 us, x 256: 27.3 vs 26.1 ms, 5-frame
+    // windows 11.03 vs 10.77 ms; profiles/r03_run11_*, r03_run12_*): half as many, twice as long work items leave a longer
+    // tail in the last round of the queue.  reserved_ bit 21: 32-row segments (A/B, parity tests).
     const int sxn = (lv->W + kStripSegW - 1) / kStripSegW;
-    int segh = kStripSegH, syn = (lv->H + segh - 1) / segh;
-    if ((long long)sxn * syn * lv->B < 4LL * kCUs * 8 || (lv->reserved_ & (1 << 21))) {
-      segh = kStripSegH / 2;
-      syn = (lv->H + segh - 1) / segh;
-    }
+    const int segh = (lv->reserved_ & (1 << 21)) ? kStripSegH : kStripSegH / 2;
+    const int syn = (lv->H + segh - 1) / segh;
     if ((long long)sxn * syn * lv->B >= 4LL * kCUs * 8 || (lv->reserved_ & 262144)) {
       pl->strip = segh;
       pl->tiles_x = sxn;

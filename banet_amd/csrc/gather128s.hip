@@ -33,15 +33,12 @@ constexpr int kSWaves = kSBlock / kWave;
 constexpr int kWinFloats = kWinRows * kWinTex * 32;
 constexpr int kWinPitchF = kWinTex * 32;           // floats per window row
 
-template <int NCH> struct ChunkVec;     // per-chunk state of a segment of NCH chunks (= 4 NCH pixel rows): one register per chunk
-template <> struct ChunkVec<8> {
-  typedef float f __attribute__((ext_vector_type(8)));
-  typedef int i __attribute__((ext_vector_type(8)));
-};
-template <> struct ChunkVec<4> {
-  typedef float f __attribute__((ext_vector_type(4)));
-  typedef int i __attribute__((ext_vector_type(4)));
-};
+// per-chunk state of a segment (one register per chunk of 64 pixels) is held in groups of four chunks: inside a group the
+// chunk index is a run-time loop counter (4-way select chains, ~3 instructions per access), across groups a compile-time
+// one (the group loop is unrolled) -- an 8-wide register vector with a run-time index costs 7-8 v_cndmask per access, which
+// made 32-row segments slower than 16-row ones although they fetch less (profiles/r03_run11_*)
+typedef float fvec4 __attribute__((ext_vector_type(4)));
+typedef int ivec4 __attribute__((ext_vector_type(4)));
 typedef float v2fs __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int brev5s(int t) { return (int)(__brev((unsigned)t) >> 27); }
@@ -284,8 +281,7 @@ __device__ __forceinline__ void strip_geometry(const banet_level_t& lv, int b, c
 template <int KV4, int NCH>
 __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVgprs / 2))) void ba_gather128s_kernel(const GatherArgs a) {
   constexpr int SEGH = 4 * NCH;          // pixel rows per segment
-  typedef typename ChunkVec<NCH>::f fvec;
-  typedef typename ChunkVec<NCH>::i ivec;
+  constexpr int NH = NCH / 4;            // groups of four chunks
   __shared__ __attribute__((aligned(16))) float sWin[kSWaves][kWinFloats];    // the rolling window: [slot][texel][32 channels]
   __shared__ __attribute__((aligned(16))) float sScr[kSWaves][kC128s];        // row statistics (plan input), later C x sum|d|
   const banet_level_t& lv = a.lv;
@@ -345,7 +341,7 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
     float ts_wait = 0.f;
 #endif
     // ---- 1. depth of every pixel of the segment: D = D0 + b . W, chunk by chunk (once per window) ----------------------
-    fvec Dv;
+    fvec4 Dv[NH];
     if constexpr (KV4 > 0) {
       // batches of RB basis rows (16 at K <= 128, 8 at K = 256: 64 registers per buffer): batch n + 1 is in flight while
       // batch n is reduced (two register buffers, sched_barrier keeps the issue order), so the depth dot exposes one memory
@@ -381,8 +377,11 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
         }
       };
       issue_batch(IC<0>{}, 0, 0);
+#pragma unroll
+      for (int hh = 0; hh < NH; ++hh)
 #pragma unroll 1
-      for (int c = 0; c < NCH; ++c) {
+      for (int c4 = 0; c4 < 4; ++c4) {
+        const int c = 4 * hh + c4;
         const int py = py0 + 4 * c;
         const bool valid = (px < W) && (py < H);
         float D = valid ? dep_b[py * W + px] : 0.f;
@@ -401,14 +400,17 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
           else reduce_batch(IC<1>{}, pend, hb);
         }
         D += pend[5];
-        Dv[c] = D;
+        Dv[hh][c4] = D;
       }
     } else {
+#pragma unroll
+      for (int hh = 0; hh < NH; ++hh)
 #pragma unroll 1
-      for (int c = 0; c < NCH; ++c) {
+      for (int c4 = 0; c4 < 4; ++c4) {
+        const int c = 4 * hh + c4;
         const int py = py0 + 4 * c;
         const bool valid = (px < W) && (py < H);
-        Dv[c] = valid ? dep_b[py * W + px] : 0.f;
+        Dv[hh][c4] = valid ? dep_b[py * W + px] : 0.f;
       }
     }
 
@@ -423,19 +425,22 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
       const float* Tv = a.T + vb * 3;
 
       // ---- 2. geometry (lane = pixel): tap parameters of the whole segment + the row statistics the plan needs ----------
-      ivec P0v;       // x0 | y0 << 12 | ((y0 - 1) mod 7) << 24 | fast << 27
-      fvec DXv, DYv;
+      ivec4 P0v[NH];       // x0 | y0 << 12 | ((y0 - 1) mod 7) << 24 | fast << 27
+      fvec4 DXv[NH], DYv[NH];
+#pragma unroll
+      for (int hh = 0; hh < NH; ++hh)
 #pragma unroll 1
-      for (int c = 0; c < NCH; ++c) {
+      for (int c4 = 0; c4 < 4; ++c4) {
+        const int c = 4 * hh + c4;
         const int py = py0 + 4 * c;
         const bool valid = (px < W) && (py < H);
         SGeo ge;
-        strip_geometry(lv, b, Rm, Tv, valid, px, py, Dv[c], ge);
+        strip_geometry(lv, b, Rm, Tv, valid, px, py, Dv[hh][c4], ge);
         const bool fast = (ge.flags & 2) != 0;
         const int m7 = fast ? (ge.y0 - 1) % kWinRows : 0;
-        P0v[c] = (fast ? (ge.x0 | (ge.y0 << 12)) : 0) | (m7 << 24) | (fast ? (1 << 27) : 0);
-        DXv[c] = ge.dx;
-        DYv[c] = ge.dy;
+        P0v[hh][c4] = (fast ? (ge.x0 | (ge.y0 << 12)) : 0) | (m7 << 24) | (fast ? (1 << 27) : 0);
+        DXv[hh][c4] = ge.dx;
+        DYv[hh][c4] = ge.dy;
         // min / max of (x0, y0) over the 16 fast pixels of this lane's pixel row (lanes that agree in lane & 3)
         const int big = 0x3fffffff;
         int ymn = fast ? ge.y0 : big, ymx = fast ? ge.y0 : -big, xmn = fast ? ge.x0 : big, xmx = fast ? ge.x0 : -big;
@@ -490,7 +495,9 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
 
       BANET_TICK(ts2);
       // ---- 3. the four channel slices ---------------------------------------------------------------------------------------
-      fvec Q0 = 0.f, Q1 = 0.f, Q2 = 0.f, Q3 = 0.f, Q4 = 0.f;   // per chunk: m11 m12 m22 g1 g2
+      fvec4 Q0[NH], Q1[NH], Q2[NH], Q3[NH], Q4[NH];   // per chunk: m11 m12 m22 g1 g2
+#pragma unroll
+      for (int hh = 0; hh < NH; ++hh) Q0[hh] = Q1[hh] = Q2[hh] = Q3[hh] = Q4[hh] = 0.f;
       const int rowC = W * C;
 #pragma unroll 1
       for (int s = 0; s < 4; ++s) {
@@ -517,10 +524,13 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
             src_issue<1, 1>(srcB_off, rs_src, src_soff(1));
           }
         }
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh)
 #pragma unroll 1
-        for (int c = 0; c < NCH; ++c) {
-          const int p0c = P0v[c];
-          const float dxc = DXv[c], dyc = DYv[c];
+        for (int c4 = 0; c4 < 4; ++c4) {
+          const int c = 4 * hh + c4;
+          const int p0c = P0v[hh][c4];
+          const float dxc = DXv[hh][c4], dyc = DYv[hh][c4];
           float qacc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};    // this lane's pixel of chunk c, slice s
           // step r = 4 c + k: pixel row k of the chunk (k is a compile-time constant: the registers of the source features
           // are named in the instruction text, the parameter broadcast is a DPP quad_perm)
@@ -622,11 +632,11 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
           do_step(IC<1>{});
           do_step(IC<2>{});
           do_step(IC<3>{});
-          Q0[c] += qacc[0];
-          Q1[c] += qacc[1];
-          Q2[c] += qacc[2];
-          Q3[c] += qacc[3];
-          Q4[c] += qacc[4];
+          Q0[hh][c4] += qacc[0];
+          Q1[hh][c4] += qacc[1];
+          Q2[hh][c4] += qacc[2];
+          Q3[hh][c4] += qacc[3];
+          Q4[hh][c4] += qacc[4];
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // the slice's 32 x sum|d|: piece oc (channels 4 oc + e) and piece 4 + oc of every lane, folded over the 16 pixel
@@ -652,19 +662,22 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
       float accp[28];                     // this lane's 8 pixels: upper triangle of Jc^T M Jc (21), Jc^T g (6), valid count
 #pragma unroll
       for (int i = 0; i < 28; ++i) accp[i] = 0.f;
+#pragma unroll
+      for (int hh = 0; hh < NH; ++hh)
 #pragma unroll 1
-      for (int c = 0; c < NCH; ++c) {
+      for (int c4 = 0; c4 < 4; ++c4) {
+        const int c = 4 * hh + c4;
         const int py = py0 + 4 * c;
         const bool valid = (px < W) && (py < H);
         const int pt = valid ? py * W + px : 0;
         SGeo ge;
-        strip_geometry(lv, b, Rm, Tv, valid, px, py, Dv[c], ge);
+        strip_geometry(lv, b, Rm, Tv, valid, px, py, Dv[hh][c4], ge);
         Q5 qv;
-        qv.m11 = Q0[c];
-        qv.m12 = Q1[c];
-        qv.m22 = Q2[c];
-        qv.g1 = Q3[c];
-        qv.g2 = Q4[c];
+        qv.m11 = Q0[hh][c4];
+        qv.m12 = Q1[hh][c4];
+        qv.m22 = Q2[hh][c4];
+        qv.g1 = Q3[hh][c4];
+        qv.g2 = Q4[hh][c4];
         {
           // patch the pixels whose stencil touches the image rim (rare): generic slow routine
           unsigned long long slow = __ballot((ge.flags & 4) != 0);

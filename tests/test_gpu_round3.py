@@ -173,7 +173,7 @@ def _torch_levels(levels):
                               t(lv["basis"]) if lv["basis"].shape[-1] else None) for lv in levels]
 
 
-STRIP, DIRECT, STRIP_ALL_DIRECT, SEG16 = 262144, 64 | 524288, 262144 | (1 << 20), 1 << 21
+STRIP, DIRECT, STRIP_ALL_DIRECT, SEG32 = 262144, 64 | 524288, 262144 | (1 << 20), 1 << 21
 
 
 @pytest.mark.parametrize("H,W,K,big,pairs", [(48, 64, 128, False, 1),      # whole segments, unit-scale footprints: all from the window
@@ -200,7 +200,7 @@ def test_strip_gather_kernel_matches_oracle(H, W, K, big, pairs):
     mlps = [orc.he_normal_mlp_weights(C, 9)]
     ba = bdense.DenseBA(t(intr), _torch_levels(levels), mlps, "bundle" if K else "bundle_camera", 1000.0)
     outs = {}
-    for bits in (STRIP, DIRECT, STRIP_ALL_DIRECT, STRIP | SEG16):
+    for bits in (STRIP, DIRECT, STRIP_ALL_DIRECT, STRIP | SEG32):
         ba.problems[0].c.reserved_ = bits
         assert ops.gather_selection(ba.problems[0]) == (1 if bits == DIRECT else 3)
         outs[bits] = [n(x) for x in ops.ba_assemble(ba.problems[0], t(R), t(T), t(Wc) if K else None)]
@@ -212,8 +212,8 @@ def test_strip_gather_kernel_matches_oracle(H, W, K, big, pairs):
         assert relerr(x, y) < 3e-6, (name, relerr(x, y))
     for name, x, y in zip(("AtA", "Atb", "absres", "nvalid"), outs[STRIP_ALL_DIRECT], outs[STRIP]):
         assert relerr(x, y) < 1e-6, (name, relerr(x, y))          # window and direct taps read the same texels
-    for name, x, y in zip(("AtA", "Atb", "absres", "nvalid"), outs[STRIP | SEG16], outs[STRIP]):
-        assert relerr(x, y) < 3e-6, (name, relerr(x, y))          # 16-row segments: the same sums, other partial rows
+    for name, x, y in zip(("AtA", "Atb", "absres", "nvalid"), outs[STRIP | SEG32], outs[STRIP]):
+        assert relerr(x, y) < 3e-6, (name, relerr(x, y))          # 32-row segments: the same sums, other partial rows
     np.testing.assert_array_equal(outs[STRIP][3], outs[DIRECT][3])
     one = dict(lv)
     one["tgt"] = lv["tgt"][:, 0]
