@@ -1,5 +1,7 @@
 #!/bin/bash
-# Final artefacts of a round: GPU tests, smoke, bench line, rocprofv3 kernel stats of the bench command, PMC traffic passes.
+# Final artefacts of a round: GPU tests, smoke, PMC traffic passes (-> profiles/pmc_traffic.json, tied to this build by
+# banet_build_id), rocprofv3 kernel stats of the bench command, the full bench line (reads that traffic file), bench.py's own
+# 2-rank launch on this one-GPU box.
 set -u
 OUT=gpurun_out
 mkdir -p $OUT $OUT/prof
@@ -21,6 +23,17 @@ cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
 rm -rf /tmp/prof && mkdir -p /tmp/prof
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o fin -- python $REPO/bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-sweep > $REPO/$OUT/prof_run.log 2>&1)
 for f in $(find /tmp/prof -name "*kernel_stats.csv"); do cp "$f" $OUT/prof/; done
-( time timeout 900 python bench.py --gpus 1 --steps 5 --warmup 2 ) > $OUT/bench.log 2>&1; echo "bench exit $?" >> $OUT/bench.log
-tail -c 300 $OUT/bench.log
+( time timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 ) > $OUT/bench.log 2> $OUT/bench.err; echo "bench exit $?" >> $OUT/bench.err
+tail -3 $OUT/bench.err
+( BANET_BENCH_DEVICE=0 BANET_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 2 --warmup 1 --windows 8 ) > $OUT/bench_2rank.log 2> $OUT/bench_2rank.err; echo "2rank exit $?" >> $OUT/bench_2rank.err
+tail -1 $OUT/bench_2rank.err
+python - <<'PY'
+import json
+l=[x for x in open("gpurun_out/bench.log") if x.startswith("{")]
+d=json.loads(l[0]); r=d["roofline"]
+print(d["value"], d["ms_per_step"], "frac", r["frac"], "traffic", r["traffic"], r["traffic_note"])
+print("parity", d["parity"]["ok"], d["parity"]["max_rel_err"], "cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["median_s"])
+for k,v in d["sweep"].items():
+    print(k, v["value"], v["ms_per_step"], v["roofline"]["frac"], v["parity"]["ok"], v["parity"]["max_rel_err"])
+PY
 exit 0
