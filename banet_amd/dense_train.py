@@ -12,7 +12,11 @@ One autograd node per pyramid LEVEL (all of its fixed-count iterations, as bundl
             pose, accumulated over the iterations in place; (c) once per level banet_target_map_adjoint_f32 folds the
             [f|gx|gy] map adjoint into the target map's gradient.
 No J / G / d / samp tensors exist in either direction and nothing is scattered with float atomics: gradients are
-bit-reproducible.  Supported: the `bundle` variant, two-frame windows, K <= 128, C <= 256.
+bit-reproducible.  Supported: the `bundle` variant, K <= 128, C <= 256, two-frame AND multi-frame windows (round 3): a window's
+normal equations are the sum of its target frames' two-frame terms embedded in the block-arrowhead matrix (AtA = sum_i E_i AtA_i
+E_i^T), so its backward is the two-frame adjoint once per target frame on the sub-blocks
+dL/dAtA_i = E_i^T (dL/dAtA) E_i, dL/dAtb_i = E_i^T dL/dAtb -- the source / depth / basis gradients accumulate over the frames, every
+target frame gets its own map adjoint and pose gradient.
 """
 import ctypes
 
@@ -32,11 +36,13 @@ def _to_param(t, dev):
     return t.to(dev) if torch.is_tensor(t) else torch.as_tensor(t, dtype=torch.float32, device=dev)
 
 
-def solve_update_graph(AtA, Atb, absres, N, R, T, Wc, layers, l2_base, solve=torch.linalg.solve):
+def solve_update_graph(AtA, Atb, absres, N, R, T, Wc, layers, l2_base, solve=torch.linalg.solve, pairs=1):
     """bundlenet.py:241-276 after the EquationConstruction op, as differentiable torch statements on the small tensors:
-    avg -> lambda MLP -> damping (last coefficient undamped) -> matrix_solve -> SE(3) / W update."""
+    avg -> lambda MLP -> damping (last coefficient undamped) -> matrix_solve -> SE(3) / W update.  pairs > 1: the multi-frame
+    window of SURVEY.md 8(d) (banet_oracle.bundle_window_iteration): residual averaged over all frames, parameter order
+    [pose_1 .. pose_pairs, depth], R [B,pairs,3,3], T [B,pairs,3,1]."""
     nb = AtA.shape[0]
-    avg = (absres / float(N)).unsqueeze(1)                                           # :243
+    avg = (absres / float(N * pairs)).unsqueeze(1)                                   # :243
     h = avg
     for i, (w, b) in enumerate(layers):
         z = torch.matmul(h, w) + b
@@ -47,10 +53,17 @@ def solve_update_graph(AtA, Atb, absres, N, R, T, Wc, layers, l2_base, solve=tor
     damp = torch.cat([diag[:, :-1] + 1e-5, torch.zeros(nb, 1, device=diag.device, dtype=diag.dtype)], dim=-1)   # :266
     A = AtA + torch.diag_embed(damp * lam.squeeze(-1))
     sol = solve(A, Atb.unsqueeze(-1))                                                # :267
-    wx, wy, wz = sol[:, 0], sol[:, 1], sol[:, 2]
-    dr = AngleaAxisRotation(wx, wy, wz)
-    dv = VMatrix(wx.reshape(-1), wy.reshape(-1), wz.reshape(-1))
-    return torch.matmul(dr, R), torch.matmul(dv, sol[:, 3:6]) + torch.matmul(dr, T), Wc + sol[:, 6:]
+    Rn, Tn = [], []
+    Rv, Tv = R.reshape(nb, pairs, 3, 3), T.reshape(nb, pairs, 3, 1)
+    for i in range(pairs):
+        o = 6 * i
+        wx, wy, wz = sol[:, o + 0], sol[:, o + 1], sol[:, o + 2]
+        dr = AngleaAxisRotation(wx, wy, wz)
+        dv = VMatrix(wx.reshape(-1), wy.reshape(-1), wz.reshape(-1))
+        Rn.append(torch.matmul(dr, Rv[:, i]))
+        Tn.append(torch.matmul(dv, sol[:, o + 3:o + 6]) + torch.matmul(dr, Tv[:, i]))
+    Rn, Tn = torch.stack(Rn, 1).reshape(R.shape), torch.stack(Tn, 1).reshape(T.shape)
+    return Rn, Tn, Wc + sol[:, 6 * pairs:]
 
 
 def spd_solve(A, b):
@@ -96,14 +109,15 @@ class _SolveNoCheck(torch.autograd.Function):
         return -torch.matmul(lam, x.transpose(-1, -2)), lam
 
 
-def _small_grads(AtA, Atb, absres, R, T, Wc, gR, gT, gW, flat, N, l2_base):
+def _small_grads(AtA, Atb, absres, R, T, Wc, gR, gT, gW, flat, N, l2_base, pairs=1):
     """dL/d(AtA, Atb, sum|d|, R, T, Wc, lambda weights) of one iteration's small part, given dL/d(R', T', W')."""
     with torch.enable_grad():
         leaves = [t.detach().requires_grad_(True) for t in (AtA, Atb, absres, R, T, Wc)]
         lw = [t.detach().requires_grad_(True) for t in flat]
+        spd_ok = AtA.is_cuda and 32 <= AtA.shape[-1] <= 180 and USE_SPD_SOLVE      # banet_spd_solve_f32 keeps the matrix in LDS
         R2, T2, W2 = solve_update_graph(leaves[0], leaves[1], leaves[2], N, leaves[3], leaves[4], leaves[5],
                                         [(lw[2 * i], lw[2 * i + 1]) for i in range(5)], l2_base,
-                                        solve=_SolveSPD.apply if (AtA.is_cuda and AtA.shape[-1] >= 32 and USE_SPD_SOLVE) else _SolveNoCheck.apply)
+                                        solve=_SolveSPD.apply if spd_ok else _SolveNoCheck.apply, pairs=pairs)
         grads = torch.autograd.grad([R2, T2, W2], leaves + lw, [gR, gT, gW], allow_unused=True)
     return [g if g is not None else torch.zeros_like(t) for g, t in zip(grads, leaves + lw)]
 
@@ -113,9 +127,9 @@ class _SmallStepGraph:
     [B,C] tensors per iteration are launch-bound when issued one by one from Python.  Static input / output buffers; falls
     back to eager execution if capture is not possible (BANET_TRAIN_GRAPH=0 disables it)."""
 
-    def __init__(self, shapes, dev, N, l2_base):
+    def __init__(self, shapes, dev, N, l2_base, pairs=1):
         import os
-        self.N, self.l2 = N, l2_base
+        self.N, self.l2, self.pairs = N, l2_base, pairs
         self.inp = [torch.zeros(s, dtype=torch.float32, device=dev) for s in shapes]
         self.graph, self.out, self.error = None, None, None
         mode = os.environ.get("BANET_TRAIN_GRAPH", "1")
@@ -126,7 +140,7 @@ class _SmallStepGraph:
             self.error = "disabled" if mode == "0" else "batch > 8"
             return
         for t in self.inp[3:4]:
-            t.copy_(torch.eye(3, device=dev).expand_as(t))          # a valid rotation / SPD system for the warm-up
+            t.copy_(torch.eye(3, device=dev).expand_as(t))          # a valid rotation / SPD system for the warm-up (broadcasts over frames)
         self.inp[0].copy_(torch.eye(shapes[0][-1], device=dev).expand_as(self.inp[0]))
         try:
             side = torch.cuda.Stream(device=dev)
@@ -145,11 +159,11 @@ class _SmallStepGraph:
 
     def _run(self):
         i = self.inp
-        return _small_grads(i[0], i[1], i[2], i[3], i[4], i[5], i[6], i[7], i[8], i[9:], self.N, self.l2)
+        return _small_grads(i[0], i[1], i[2], i[3], i[4], i[5], i[6], i[7], i[8], i[9:], self.N, self.l2, self.pairs)
 
     def __call__(self, tensors):
         if self.graph is None:
-            return _small_grads(*tensors[:9], tensors[9:], self.N, self.l2)
+            return _small_grads(*tensors[:9], tensors[9:], self.N, self.l2, self.pairs)
         for dst, src in zip(self.inp, tensors):
             dst.copy_(src.reshape(dst.shape))
         self.graph.replay()
@@ -164,12 +178,12 @@ def small_step_modes():
     return {str(k[0][0]): ("graph" if v.graph is not None else "eager (%s)" % (v.error or "capture failed")) for k, v in _small_cache.items()}
 
 
-def _small_step(tensors, N, l2_base):
+def _small_step(tensors, N, l2_base, pairs=1):
     dev = tensors[0].device
-    key = (tuple(tuple(t.shape) for t in tensors), str(dev), int(N), float(l2_base))
+    key = (tuple(tuple(t.shape) for t in tensors), str(dev), int(N), float(l2_base), int(pairs))
     st = _small_cache.get(key)
     if st is None:
-        st = _small_cache[key] = _SmallStepGraph([tuple(t.shape) for t in tensors], dev, N, l2_base)
+        st = _small_cache[key] = _SmallStepGraph([tuple(t.shape) for t in tensors], dev, N, l2_base, pairs)
     return st(tensors)
 
 
@@ -196,13 +210,28 @@ def target_map_adjoint(dmap3, dimg):
     return dimg
 
 
+def _pair_problems(ba, li):
+    """Two-frame views of a multi-frame level, one per target frame (the adjoint kernels take [B,H,W,C] target maps): contiguous
+    copies of tgt[:, i], rebuilt for every backward pass (the level tensors may have changed since the last one)."""
+    lv, prob = ba.levels[li], ba.problems[li]
+    B, H, W, C = lv.B, lv.H, lv.W, lv.C
+    out = []
+    for i in range(prob.pairs):
+        tgt_i = lv.tgt.detach()[:, i].contiguous()
+        out.append(ops.LevelProblem("bundle", lv.src.detach(), tgt_i, lv.depth.detach().reshape(B, H * W), H, W, C,
+                                    basis=lv.basis.detach().reshape(B, H * W, -1), intr=ba.intr, scale=lv.scale, dense=True,
+                                    tgt_has_grad=False, normalize_rays=True, pairs=1))
+    return out
+
+
 class _LevelSolve(torch.autograd.Function):
     """All fixed-count iterations of one pyramid level."""
 
     @staticmethod
     def forward(ctx, ba, li, n_iter, src, tgt, depth, basis, R, T, Wc, *flat_layers):
         prob, mlp = ba.problems[li], ba.mlps[li]
-        st = ops.LmState(R.detach(), T.detach(), Wc.detach(), P=6 + ba.K)
+        pairs = prob.pairs
+        st = ops.LmState(R.detach(), T.detach(), Wc.detach(), P=6 * pairs + ba.K, pairs=pairs)
         saved = []
         for _ in range(n_iter):
             Ri, Ti, Wi = st.R.clone(), st.T.clone(), st.Wc.clone()
@@ -211,52 +240,73 @@ class _LevelSolve(torch.autograd.Function):
             saved.append((Ri, Ti, Wi, AtA, Atb, absres))
         ctx.ba, ctx.li, ctx.saved = ba, li, saved
         ctx.layers = flat_layers
-        ctx.shapes = (src.shape, tgt.shape, depth.shape, basis.shape)
-        return st.R.clone(), st.T.clone(), st.Wc.clone()
+        ctx.shapes = (src.shape, tgt.shape, depth.shape, basis.shape, R.shape, T.shape)
+        return st.R.clone().reshape(R.shape), st.T.clone().reshape(T.shape), st.Wc.clone()
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, gR, gT, gW):
         ba, li = ctx.ba, ctx.li
         prob = ba.problems[li]
+        pairs = prob.pairs
         dev = prob.device
         B, N, C, K, H, W = prob.B, prob.N, prob.C, prob.K, prob.c.H, prob.c.W
+        pprobs = [prob] if pairs == 1 else _pair_problems(ba, li)
         dsrc = torch.zeros((B, N, C), dtype=torch.float32, device=dev)
-        dmap3 = torch.zeros((B, H, W, 3 * C), dtype=torch.float32, device=dev)
+        dmap3 = [torch.zeros((B, H, W, 3 * C), dtype=torch.float32, device=dev) for _ in range(pairs)]
         ddepth = torch.zeros((B, N), dtype=torch.float32, device=dev)
         dbasis = torch.zeros((B, N, K), dtype=torch.float32, device=dev)
         flat = ctx.layers
-        layers = [(flat[2 * i], flat[2 * i + 1]) for i in range(5)]
         glayers = [torch.zeros_like(t) for t in flat]
-        gR = torch.zeros(B, 3, 3, device=dev) if gR is None else gR.reshape(B, 3, 3)
-        gT = torch.zeros(B, 3, 1, device=dev) if gT is None else gT.reshape(B, 3, 1)
+        gR = torch.zeros(B, pairs, 3, 3, device=dev) if gR is None else gR.reshape(B, pairs, 3, 3)
+        gT = torch.zeros(B, pairs, 3, 1, device=dev) if gT is None else gT.reshape(B, pairs, 3, 1)
         gW = torch.zeros(B, K, 1, device=dev) if gW is None else gW.reshape(B, K, 1)
+        o = 6 * pairs
         ws = None
         for Ri, Ti, Wi, AtA, Atb, absres in reversed(ctx.saved):
-            grads = _small_step([AtA, Atb, absres, Ri, Ti, Wi, gR, gT, gW] + [t.detach() for t in flat], N, ba.l2_base)
-            gAtA, gAtb, gabs_avg, dR, dT, dW = grads[:6]
+            Rv, Tv = Ri.reshape(B, pairs, 3, 3), Ti.reshape(B, pairs, 3, 1)
+            grads = _small_step([AtA, Atb, absres, Rv, Tv, Wi, gR, gT, gW] + [t.detach() for t in flat], N, ba.l2_base, pairs)
+            gAtA, gAtb, gabs, dR, dT, dW = grads[:6]
             for acc, g in zip(glayers, grads[6:]):
                 acc += g
-            dpose, ws = dense_adjoint(prob, Ri, Ti, Wi, gAtA, gAtb, gabs_avg, dsrc, dmap3, ddepth, dbasis, ws)
-            gR = dR + dpose[:, 0:9].reshape(B, 3, 3)
-            gT = dT + dpose[:, 9:12].reshape(B, 3, 1)
-            gW = dW + dpose[:, 12:].reshape(B, K, 1)
-        dtgt = torch.zeros((B, H, W, C), dtype=torch.float32, device=dev)
-        target_map_adjoint(dmap3, dtgt)
-        s_src, s_tgt, s_dep, s_bas = ctx.shapes
+            gR, gT, gW = dR.reshape(B, pairs, 3, 3).clone(), dT.reshape(B, pairs, 3, 1).clone(), dW.reshape(B, K, 1).clone()
+            for i in range(pairs):
+                if pairs == 1:
+                    gA_i, gb_i = gAtA, gAtb
+                else:       # E_i^T (dL/dAtA) E_i: the frame's pose block, its cross blocks with the depth block, the depth block
+                    idx = torch.cat([torch.arange(6 * i, 6 * i + 6, device=dev), torch.arange(o, o + K, device=dev)])
+                    gA_i = gAtA.index_select(1, idx).index_select(2, idx).contiguous()
+                    gb_i = gAtb.index_select(1, idx).contiguous()
+                dpose, ws = dense_adjoint(pprobs[i], Rv[:, i].contiguous(), Tv[:, i].contiguous(), Wi, gA_i, gb_i, gabs, dsrc,
+                                          dmap3[i], ddepth, dbasis, ws)
+                gR[:, i] += dpose[:, 0:9].reshape(B, 3, 3)
+                gT[:, i] += dpose[:, 9:12].reshape(B, 3, 1)
+                gW += dpose[:, 12:].reshape(B, K, 1)
+        dtgt = torch.zeros((B, pairs, H, W, C), dtype=torch.float32, device=dev)
+        for i in range(pairs):
+            di = torch.zeros((B, H, W, C), dtype=torch.float32, device=dev)
+            target_map_adjoint(dmap3[i], di)
+            dtgt[:, i] = di
+        s_src, s_tgt, s_dep, s_bas, s_R, s_T = ctx.shapes
         return (None, None, None, dsrc.reshape(s_src), dtgt.reshape(s_tgt), ddepth.reshape(s_dep), dbasis.reshape(s_bas),
-                gR, gT, gW) + tuple(glayers)
+                gR.reshape(s_R), gT.reshape(s_T), gW) + tuple(glayers)
 
 
 def solve_differentiable(ba, levels, lambda_weights, iters_per_level, R=None, T=None, Wc=None):
     """Differentiable DenseBA.solve with fixed iteration counts: `levels` = the DenseLevel objects `ba` was built from (their
     src / tgt / depth / basis tensors may require grad), `lambda_weights` = per level five (filters, biases) pairs (tensors
-    that may require grad, or arrays).  Returns (R [B,3,3], T [B,3,1], Wc [B,K,1]) attached to the autograd graph."""
-    if ba.variant != "bundle" or ba.pairs != 1:
-        raise capi.BanetError("solve_differentiable: bundle variant with two-frame windows only")
+    that may require grad, or arrays).  Returns (R [B,3,3], T [B,3,1], Wc [B,K,1]) attached to the autograd graph
+    (multi-frame windows: R [B,pairs,3,3], T [B,pairs,3,1])."""
+    if ba.variant != "bundle":
+        raise capi.BanetError("solve_differentiable: bundle variant only")
     dev = ba.intr.device
-    B, K = ba.B, ba.K
-    R = torch.eye(3, device=dev).repeat(B, 1, 1) if R is None else R
-    T = torch.zeros(B, 3, 1, device=dev) if T is None else T
+    B, K, pairs = ba.B, ba.K, ba.pairs
+    if pairs == 1:
+        R = torch.eye(3, device=dev).repeat(B, 1, 1) if R is None else R
+        T = torch.zeros(B, 3, 1, device=dev) if T is None else T
+    else:
+        R = torch.eye(3, device=dev).repeat(B, pairs, 1, 1) if R is None else R.reshape(B, pairs, 3, 3)
+        T = torch.zeros(B, pairs, 3, 1, device=dev) if T is None else T.reshape(B, pairs, 3, 1)
     Wc = torch.zeros(B, K, 1, device=dev) if Wc is None else Wc
     for li, (lv, lw, n_it) in enumerate(zip(levels, lambda_weights, iters_per_level)):
         if int(n_it) <= 0:

@@ -97,3 +97,37 @@ def test_solve_update_graph_equals_the_oracle_iteration_tail():
                                                 tt(Wc), layers, 1000.0)
     for got, want in ((R2, Rn), (T2, Tn), (W2, Wn)):
         np.testing.assert_allclose(got.numpy(), want, rtol=1e-9, atol=1e-12)
+
+
+def test_small_step_graph_of_a_multi_frame_window_matches_the_oracle_update():
+    """dense_train.solve_update_graph(pairs = 3) -- the differentiable small part of the window iteration the fused backward
+    differentiates -- reproduces banet_oracle.bundle_window_iteration's update from the oracle's own AtA / Atb / sum|d|
+    (float64, CPU), including the per-frame SE(3) updates and their order in the solution vector."""
+    import numpy as np
+    import torch
+    from banet_amd import dense_train
+    from oracle import banet_oracle as orc, dense as odense, synth
+    C, K, pairs, H, W = 6, 5, 3, 16, 20
+    sc = synth.make_window_scene(H, W, C, K, [1], 9, pairs, rot_mag=0.012, trans_mag=0.04)
+    intr, levels = odense.batch_window_scene([sc])
+    lv = levels[0]
+    one = dict(lv)
+    one["tgt"] = lv["tgt"][:, 0]
+    a = odense.level_inputs(intr, one, True, np.float64)
+    conv2s = [orc.target_map(lv["tgt"][:, i].astype(np.float64)) for i in range(pairs)]
+    rng = np.random.RandomState(4)
+    Rs = [synth.rodrigues(rng.uniform(-0.004, 0.004, 3))[None] for _ in range(pairs)]
+    Ts = [(np.asarray(sc["T_gt"])[i] * 0.8).reshape(1, 3, 1) for i in range(pairs)]
+    Wc = rng.uniform(-0.01, 0.01, (1, K, 1))
+    mlp = orc.he_normal_mlp_weights(C, 1, np.float64)
+    Rn, Tn, Wn, dbg = orc.bundle_window_iteration(a["conv1"], conv2s, a["fx"], a["fy"], a["ox"], a["oy"], a["p"], a["D"],
+                                                  a["Bs"], Rs, Ts, Wc, mlp, 1000.0)
+    tt = lambda x: torch.from_numpy(np.ascontiguousarray(np.asarray(x, np.float64)))  # noqa: E731
+    N = H * W
+    absres = tt(dbg["avg"][:, 0]) * (N * pairs)
+    layers = [(tt(w), tt(b)) for w, b in mlp]
+    R2, T2, W2 = dense_train.solve_update_graph(tt(dbg["AtA"]), tt(dbg["Atb"][..., 0]), absres, N, tt(np.stack(Rs, 1)),
+                                                tt(np.stack(Ts, 1)), tt(Wc), layers, 1000.0, pairs=pairs)
+    np.testing.assert_allclose(R2.numpy(), np.stack(Rn, 1), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(T2.numpy(), np.stack(Tn, 1), rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(W2.numpy(), Wn, rtol=1e-8, atol=1e-12)

@@ -168,6 +168,101 @@ def test_solve_differentiable_matches_the_fused_forward_and_oracle_finite_differ
         assert abs(num - ana) <= 2e-2 * max(abs(num), abs(ana)) + 1e-4 * scale, (name, num, ana)
 
 
+def test_solve_differentiable_multi_frame_windows_match_oracle_finite_differences():
+    """Round 3: the fused backward on multi-frame windows (cfg-3's shape class: one key frame + 3 target frames sharing depth /
+    basis / W, P = 18 + K): forward values equal the fused window solve and the float64 oracle chain
+    (banet_oracle.bundle_window_iteration), gradients w.r.t. the key-frame features, EVERY target frame, the depth, the basis
+    and the lambda weights against central differences of that oracle chain."""
+    from banet_amd import dense as bdense
+    H, W, C, K, B, pairs = 40, 48, 16, 26, 2, 3            # P = 44: the backward's solves run on banet_spd_solve_f32
+    iters = [2, 1]
+    scenes = [synth.make_window_scene(H, W, C, K, [2, 1], 61 + b, pairs, rot_mag=0.012, trans_mag=0.04) for b in range(B)]
+    intr, levels = odense.batch_window_scene(scenes)
+    rng = np.random.RandomState(5)
+    T0 = (np.stack([s["T_gt"] for s in scenes]) * 0.7).reshape(B, pairs, 3, 1)
+    mlps = [orc.he_normal_mlp_weights(C, 40 + i, np.float64) for i in range(2)]
+    cR, cT, cW = rng.standard_normal((B, pairs, 3, 3)), rng.standard_normal((B, pairs, 3, 1)), rng.standard_normal((B, K, 1))
+
+    def _oracle_chain(levels_, mlps_):
+        Rs = [np.tile(np.eye(3)[None], (B, 1, 1)) for _ in range(pairs)]
+        Ts = [T0[:, i].astype(np.float64).copy() for i in range(pairs)]
+        Wn = np.zeros((B, K, 1))
+        for li, lv in enumerate(levels_):
+            one = dict(lv)
+            one["tgt"] = lv["tgt"][:, 0]
+            a = odense.level_inputs(np.asarray(intr, np.float64), one, True, np.float64)
+            conv2s = [orc.target_map(lv["tgt"][:, i].astype(np.float64)) for i in range(pairs)]
+            for _ in range(iters[li]):
+                Rs, Ts, Wn, _ = orc.bundle_window_iteration(a["conv1"], conv2s, a["fx"], a["fy"], a["ox"], a["oy"], a["p"], a["D"],
+                                                            a["Bs"], Rs, Ts, Wn, mlps_[li], 1000.0)
+        return np.stack(Rs, 1), np.stack(Ts, 1), Wn
+
+    def oracle_loss(levels_, mlps_):
+        R, T, Wn = _oracle_chain(levels_, mlps_)
+        return float((cR * R).sum() + (cT * T).sum() + (cW * Wn).sum())
+
+    lv64 = [{k: (np.asarray(v, np.float32).astype(np.float64) if isinstance(v, np.ndarray) else v) for k, v in lv.items()}
+            for lv in levels]
+    tl = [bdense.DenseLevel(lv["scale"], t(lv["src"]).requires_grad_(True), t(lv["tgt"]).requires_grad_(True),
+                            t(lv["D0"]).requires_grad_(True), t(lv["basis"]).requires_grad_(True)) for lv in levels]
+    tm = [[(t(w).requires_grad_(True), t(b).requires_grad_(True)) for w, b in lw] for lw in mlps]
+    ba = bdense.DenseBA(t(intr), tl, tm, "bundle", 1000.0)
+    assert ba.pairs == pairs
+    R, T, Wn = ba.solve_differentiable(iters, T=t(T0))
+    st = ba.new_state(T=t(T0.reshape(B * pairs, 3, 1)))
+    ba.solve(iters, st)
+    assert torch.allclose(R, st.R, atol=1e-6) and torch.allclose(T, st.T, atol=1e-6) and torch.allclose(Wn, st.Wc, atol=1e-6)
+    Ro, To, Wo = _oracle_chain(lv64, mlps)
+    for got, want in ((R, Ro), (T, To), (Wn, Wo)):
+        assert np.abs(n(got) - want).max() <= 1e-4 * max(np.abs(want).max(), 1e-6)
+    loss = (t(cR) * R).sum() + (t(cT) * T).sum() + (t(cW) * Wn).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+
+    def fd(apply, shape, eps):
+        d = rng.standard_normal(shape)
+        d /= np.linalg.norm(d)
+        vals = sorted((apply(e * d) - apply(-e * d)) / (2 * e) for e in (eps, 3 * eps, 10 * eps))
+        return d, vals[1]
+
+    checks = []
+    for li in range(2):
+        for key, tens in (("src", tl[li].src), ("D0", tl[li].depth), ("basis", tl[li].basis)):
+            def apply(dl, li=li, key=key):
+                l2 = [dict(x) for x in lv64]
+                l2[li][key] = lv64[li][key] + dl
+                return oracle_loss(l2, mlps)
+            d, num = fd(apply, lv64[li][key].shape, 1e-5)
+            checks.append(("%s[%d]" % (key, li), num, float((n(tens.grad) * d).sum())))
+        for i in range(pairs):                                   # every target frame on its own
+            def apply(dl, li=li, i=i):
+                l2 = [dict(x) for x in lv64]
+                tg = lv64[li]["tgt"].copy()
+                tg[:, i] += dl
+                l2[li]["tgt"] = tg
+                return oracle_loss(l2, mlps)
+            d, num = fd(apply, lv64[li]["tgt"][:, i].shape, 1e-5)
+            checks.append(("tgt[%d][frame %d]" % (li, i), num, float((n(tl[li].tgt.grad)[:, i] * d).sum())))
+        for wi in (0, 4):
+            def apply(dl, li=li, wi=wi):
+                m2 = [[(w.copy(), b.copy()) for w, b in lw] for lw in mlps]
+                m2[li][wi] = (m2[li][wi][0] + dl, m2[li][wi][1])
+                return oracle_loss(lv64, m2)
+            d, num = fd(apply, mlps[li][wi][0].shape, 1e-4)
+            checks.append(("mlp[%d][%d]" % (li, wi), num, float((n(tm[li][wi][0].grad) * d).sum())))
+    scale = max(abs(c[1]) for c in checks)
+    for name, num, ana in checks:
+        assert abs(num - ana) <= 2e-2 * max(abs(num), abs(ana)) + 1e-4 * scale, (name, num, ana)
+    # bit-reproducible
+    for x in [tl[0].src, tl[1].tgt, tl[1].basis]:
+        x.grad_first = x.grad.clone()
+        x.grad = None
+    R2, T2, W2 = ba.solve_differentiable(iters, T=t(T0))
+    ((t(cR) * R2).sum() + (t(cT) * T2).sum() + (t(cW) * W2).sum()).backward()
+    for x in [tl[0].src, tl[1].tgt, tl[1].basis]:
+        assert torch.equal(x.grad, x.grad_first)
+
+
 @pytest.mark.parametrize("B,N,C,H,W", [(2, 700, 128, 24, 32), (1, 4096, 70, 48, 64)])
 def test_sample_stats_grad_deterministic_variant_matches_the_atomic_one_and_is_bit_reproducible(B, N, C, H, W):
     """banet_sample_stats_grad_det_f32 (the default of the reference-layout training graph): same gradients as the

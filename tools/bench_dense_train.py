@@ -14,15 +14,16 @@ H = int(sys.argv[2]) if len(sys.argv) > 2 else 480
 W = int(sys.argv[3]) if len(sys.argv) > 3 else 640
 IT = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 C = K = 128
+FRAMES = int(os.environ.get("PFRAMES", "2"))
 SCALES = [16, 8, 4, 2, 1]
-intr, levels, gt = bsynth.make_dense_windows(B, H, W, C, K, SCALES, 7, dev, trans_mag=0.06)
+intr, levels, gt = bsynth.make_dense_windows(B, H, W, C, K, SCALES, 7, dev, trans_mag=0.06, pairs=FRAMES - 1)
 mlps = [[(w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)) for w, b in he_normal_lambda_weights(C, 100 + i)]
         for i in range(len(SCALES))]
 for lv in levels:
     for name in ("src", "tgt", "depth", "basis"):
         setattr(lv, name, getattr(lv, name).requires_grad_(True))
 ba = bdense.DenseBA(intr, levels, mlps, "bundle", 1000.0)
-T0 = (gt["T"] * 0.7).reshape(B, 3, 1).to(dev)
+T0 = (gt["T"] * 0.7).reshape(B * (FRAMES - 1), 3, 1).to(dev)
 iters = [IT] * len(SCALES)
 leaves = [getattr(lv, n) for lv in levels for n in ("src", "tgt", "depth", "basis")] + [x for lw in mlps for wb in lw for x in wb]
 
@@ -52,7 +53,7 @@ def timed(fn, reps):
 f_ms, _ = timed(fwd_only, 3)
 t_ms, mem = timed(fwd_bwd, 3)
 nit = sum(iters) * B
-print("dense BA training step, %d windows %dx%d, 5 levels x %d iterations, C = K = 128:" % (B, W, H, IT))
+print("dense BA training step, %d windows of %d frames %dx%d, 5 levels x %d iterations, C = K = 128:" % (B, FRAMES, W, H, IT))
 print("  forward only (lm_level)                 %8.2f ms   (%.1f LM it/s)" % (f_ms, nit / f_ms * 1e3))
 print("  forward + backward (solve_differentiable) %6.2f ms   (%.1f LM it/s, %.2fx the forward), peak extra memory %.2f GB"
       % (t_ms, nit / t_ms * 1e3, t_ms / f_ms, mem))
