@@ -170,7 +170,14 @@ class _SmallStepGraph:
         return [o.clone() for o in self.out]
 
 
-_small_cache = {}
+_small_cache = {}          # shape key -> _SmallStepGraph (static buffers + a private graph memory pool each): bounded, see _small_step
+_SMALL_CACHE_MAX = 8
+
+
+def clear_small_step_cache():
+    """Drop the captured small-step graphs and their static buffers (multi-resolution / multi-batch training keeps at most
+    _SMALL_CACHE_MAX of them alive anyway)."""
+    _small_cache.clear()
 
 
 def small_step_modes():
@@ -181,9 +188,12 @@ def small_step_modes():
 def _small_step(tensors, N, l2_base, pairs=1):
     dev = tensors[0].device
     key = (tuple(tuple(t.shape) for t in tensors), str(dev), int(N), float(l2_base), int(pairs))
-    st = _small_cache.get(key)
+    st = _small_cache.pop(key, None)
     if st is None:
-        st = _small_cache[key] = _SmallStepGraph([tuple(t.shape) for t in tensors], dev, N, l2_base, pairs)
+        st = _SmallStepGraph([tuple(t.shape) for t in tensors], dev, N, l2_base, pairs)
+        while len(_small_cache) >= _SMALL_CACHE_MAX:          # least recently used first (dicts keep insertion order)
+            _small_cache.pop(next(iter(_small_cache)))
+    _small_cache[key] = st
     return st(tensors)
 
 

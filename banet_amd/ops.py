@@ -172,7 +172,9 @@ class MlpCache:
         key = (level, str(device))
         hit = self._d.get(key)
         if hit is None or sig is None or hit[0] != sig:
-            hit = (sig, MlpWeights(layers, device))
+            # the entry keeps the source tensors alive: their id()s cannot be recycled by new tensors (del + reload from a
+            # checkpoint at the same addresses with _version 0) while the signature still names them
+            hit = (sig, MlpWeights(layers, device), flat)
             self._d[key] = hit
         return hit[1]
 
