@@ -81,6 +81,7 @@ static SolveArgs make_solve_args(const banet_level_t* lv, const banet_mlp_t* mlp
   a.nqueue = 0;
   a.bigA = nullptr;
   a.mlp_y = nullptr;
+  a.flags = lv->reserved_;
   banet_lm_params_default(&a.lm);
   return a;
 }

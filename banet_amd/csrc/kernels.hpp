@@ -140,6 +140,7 @@ struct SolveArgs {
   int nqueue;  // words per window
   const float* mlp_y;   // [B] lambda-MLP outputs precomputed by the SYRK launch's role workgroups, or nullptr
   banet_lm_params_t lm;   // run-time LM configuration (legacy/ba.py:5-9)
+  int flags;              // banet_level_t.reserved_ (development switches: bit 23 = blocked LDL^T only, no conjugate gradients)
 };
 int launch_solve(const SolveArgs& a, hipStream_t s);
 int launch_spd_solve(const float* A, const float* rhs, float* x, int B, int P, hipStream_t s);   // 32 <= P, matrix in LDS

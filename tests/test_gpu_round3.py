@@ -269,3 +269,47 @@ def test_strip_gather_full_size_batch_selection_and_twin():
     ra, ta, wa = a.R.clone(), a.T.clone(), a.Wc.clone()
     b2 = ba.solve([3, 3], ba.new_state(T=T0.clone()))[0]
     assert torch.equal(ra, b2.R) and torch.equal(ta, b2.T) and torch.equal(wa, b2.Wc)
+
+
+# ======================================================================================
+# the conjugate-gradient solve of the damped systems (solve.hip::pcg_schur_solve) and its LDL^T fallback
+# ======================================================================================
+@pytest.mark.parametrize("l2_base,pairs", [(1000.0, 1), (30.0, 1), (1.0, 1), (1e-3, 1), (1000.0, 3), (0.05, 3)])
+def test_cg_solve_and_ldlt_fallback_match_the_oracle_lu(l2_base, pairs):
+    """bundlenet.py:264-267: tf.matrix_solve on the damped normal matrix.  The update kernel runs Jacobi-preconditioned
+    conjugate gradients on the damped block + an exact Schur step for the undamped last coefficient, and falls back to the
+    blocked LDL^T when CG does not converge (weak damping: small l2_regularizer_base).  From strong damping (the layer's
+    own 1000: CG in a handful of products) to practically none (fallback): the update equals the float64 LU solution of the
+    same damped system to 1e-4 per coefficient group, and equals what the LDL^T alone gives (reserved_ bit 23)."""
+    from banet_amd import dense as bdense, ops
+    from oracle import dense as odense, synth
+    B, H, W, C, K = 2, 40, 56, 128, 64
+    scenes = [synth.make_window_scene(H, W, C, K, [1], 410 + b, pairs, rot_mag=0.012, trans_mag=0.05) for b in range(B)]
+    intr, levels = odense.batch_window_scene(scenes)
+    rng = np.random.RandomState(3)
+    R = np.stack([[synth.rodrigues(rng.uniform(-1, 1, 3) * 0.004) for _ in range(pairs)] for _ in range(B)]).astype(np.float32)
+    T = (np.stack([s["T_gt"] for s in scenes]) * 0.8).reshape(B, pairs, 3, 1).astype(np.float32)
+    Wc = (rng.standard_normal((B, K, 1)) * 0.01).astype(np.float32)
+    mlps = [orc.he_normal_mlp_weights(C, 9)]
+    ba = bdense.DenseBA(t(intr), _torch_levels(levels), mlps, "bundle", l2_base)
+    AtA, Atb, absres, nvalid = ops.ba_assemble(ba.problems[0], t(R), t(T), t(Wc))
+    sols = {}
+    for bits in (0, 1 << 23):
+        ba.problems[0].c.reserved_ = bits
+        st = ba.new_state(t(R.reshape(B * pairs, 3, 3)), t(T.reshape(B * pairs, 3, 1)), t(Wc))
+        ops.ba_solve_update(ba.problems[0], ba.mlps[0], l2_base, AtA, Atb, absres, nvalid, st)
+        sols[bits] = (n(st.delta).astype(np.float64), float(n(st.lambda_out)[0]))
+    ba.problems[0].c.reserved_ = 0
+    o = 6 * pairs
+    for b in range(B):
+        lam = float(n(st.lambda_out)[b])
+        A64 = n(AtA)[b].astype(np.float64)
+        damp = (np.diag(A64) + 1e-5) * lam
+        damp[-1] = 0.0
+        truth = np.linalg.solve(A64 + np.diag(damp), n(Atb)[b].astype(np.float64))
+        for name, sl in (("pose", slice(0, o)), ("depth", slice(o, -1)), ("last", slice(-1, None))):
+            scale = np.abs(truth[sl]).max()
+            for bits in sols:
+                err = np.abs(sols[bits][0][b][sl] - truth[sl]).max() / scale
+                assert err < 1e-4, (l2_base, pairs, b, name, bits, err, lam)
+    assert np.abs(sols[0][0] - sols[1 << 23][0]).max() <= 2e-5 * np.abs(sols[1 << 23][0]).max()

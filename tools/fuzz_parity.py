@@ -39,6 +39,18 @@ for c in cases_patch:
         print("patch gather case", c, "FAILED")
         traceback.print_exc(limit=2)
 print("wide SYRK cases %s, patch gather cases %s: %d failures so far" % (cases_wide, cases_patch, bad))
+# round 3: the strip gather forced at random shapes (ragged strips / segments, 0..3 target frames, K up to 256, large motion)
+import test_gpu_round3 as T3  # noqa: E402
+cases_strip = [(int(rng.randint(8, 90)), int(rng.randint(21, 120)), int(rng.choice([0, 4, 16, 32, 64, 128, 256])), bool(rng.randint(2)),
+                int(rng.randint(1, 4))) for _ in range(max(4, count // 3))]
+for c in cases_strip:
+    try:
+        T3.test_strip_gather_kernel_matches_oracle(*c)
+    except Exception:
+        bad += 1
+        print("strip gather case", c, "FAILED")
+        traceback.print_exc(limit=2)
+print("strip gather cases %s: %d failures so far" % (cases_strip, bad))
 cases_eq = [(int(rng.randint(1, 4)), int(rng.randint(1, 700)), int(rng.choice([1, 3, 8, 64, 128, 200])), int(rng.choice([6, 7, 12, 38, 70, 134, 143, 144, 145, 160])))
             for _ in range(max(4, count // 4))]
 for c in cases_eq:
