@@ -313,3 +313,29 @@ def test_cg_solve_and_ldlt_fallback_match_the_oracle_lu(l2_base, pairs):
                 err = np.abs(sols[bits][0][b][sl] - truth[sl]).max() / scale
                 assert err < 1e-4, (l2_base, pairs, b, name, bits, err, lam)
     assert np.abs(sols[0][0] - sols[1 << 23][0]).max() <= 2e-5 * np.abs(sols[1 << 23][0]).max()
+
+
+def test_strip_gather_under_the_legacy_early_terminated_lm():
+    """legacy/ba.py's early-terminated LM (device-side loop control, per-window `active` flags, un-normalised rays, pose only)
+    with the strip gather forced on every level (C = 128): iteration counts identical to the oracle's, pose within 1e-4 --
+    and identical counts to the tile kernels on the same problem."""
+    from banet_amd import dense as bdense
+    from oracle import dense as odense, synth
+    B, H, W, C = 3, 48, 64, 128
+    scenes = [synth.make_pair_scene(H, W, C, 0, [2, 1], 51 + b, normalize_rays=False, w_gt=[0.01 * (1 + b), -0.008, 0.006],
+                                    t_gt=[0.06, -0.04 * (1 + 0.5 * b), 0.03]) for b in range(B)]
+    intr, levels = odense.batch_scene(scenes)
+    mlps = [orc.he_normal_mlp_weights(C, 5 + i) for i in range(2)]
+    iters = [5, 7]
+    R, T, ratio, counts = odense.solve_legacy(intr, levels, mlps, iters, early_termination=True)
+    got = {}
+    for bits in (STRIP, DIRECT):
+        ba = bdense.DenseBA(t(intr), _torch_levels(levels), mlps, "legacy_lm")
+        for p in ba.problems:
+            p.c.reserved_ = bits
+        st, cnt = ba.solve(iters, early_termination=True)
+        got[bits] = ([[int(v) for v in c] for c in cnt], n(st.R), n(st.T))
+    assert got[STRIP][0] == counts, (got[STRIP][0], counts)
+    assert got[DIRECT][0] == counts
+    assert relerr(got[STRIP][1], R) < 1e-4 and relerr(got[STRIP][2], T) < 1e-4
+    assert relerr(got[STRIP][1], got[DIRECT][1]) < 1e-5 and relerr(got[STRIP][2], got[DIRECT][2]) < 1e-5
