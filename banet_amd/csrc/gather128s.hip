@@ -131,11 +131,19 @@ struct StripLaneEnv {
   __device__ __forceinline__ void ring_set(int i, int v) { ringv = write_lane(v, i, ringv); }
 };
 
+#ifndef BANET_STRIP_NT     // development: 1 = source features with the nt hint, 2 = window rows too (A/B)
+#define BANET_STRIP_NT 0
+#endif
+#if BANET_STRIP_NT >= 2
+#define BANET_WIN_NT_ " nt"
+#else
+#define BANET_WIN_NT_ ""
+#endif
 // ---- asynchronous loads the compiler does not see (its s_waitcnt bookkeeping would drain them) ----------------------
 // 1 KB from global memory straight into LDS: lane i's 16 bytes go to lds_dst + 16 i (wave-uniform M0 base + lane x 16)
 __device__ __forceinline__ void glds16(const float* gbase, unsigned voff_bytes, unsigned lds_dst) {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" BANET_WIN_NT_ "\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
                : "v"(voff_bytes), "s"(gbase), "s"(lds_dst)
                : "memory");
@@ -171,8 +179,13 @@ static_assert(kMaxWait == 15, "wait_vmcnt implements counts up to 15");
 // it while the data is still in flight (its loop-carried v_mov copies did exactly that to a first version).  Slot j
 // (0..3 = step mod 4), group t: v[224 + 8 j + 4 t .. + 3]; issued by buffer_load, copied out with v_mov after the counted wait.
 constexpr int kStripVgprs = 224;   // the attribute counts in units of (1 VGPR + 1 AGPR) on the unified register file: 112
+#if BANET_STRIP_NT >= 1
+#define BANET_SRC_NT_ " nt"
+#else
+#define BANET_SRC_NT_ ""
+#endif
 #define BANET_SRC_ISSUE_(A0, A1, A2, A3, voff, rs, soff)                                                            \
-  asm volatile("buffer_load_dwordx4 v[" #A0 ":" #A3 "], %0, %1, %2 offen" ::"v"(voff), "s"(rs), "s"(soff)           \
+  asm volatile("buffer_load_dwordx4 v[" #A0 ":" #A3 "], %0, %1, %2 offen" BANET_SRC_NT_ ::"v"(voff), "s"(rs), "s"(soff) \
                : "memory", "v" #A0, "v" #A1, "v" #A2, "v" #A3)
 #define BANET_SRC_READ_(A0, A1, A2, A3, d)                                                                          \
   asm volatile("v_mov_b32 %0, v" #A0 "\n\tv_mov_b32 %1, v" #A1 "\n\tv_mov_b32 %2, v" #A2 "\n\tv_mov_b32 %3, v" #A3 \
