@@ -33,7 +33,7 @@ namespace banet {
 namespace {
 
 constexpr int kAdjMaxCJ = 4;    // C <= 256
-constexpr int kAdjMaxKJ = 2;    // K <= 128 (adj_basis_kernel keeps the K x (K+16) seed block in LDS)
+constexpr int kAdjMaxKJ = 4;    // K <= 256 (K <= 128: adj_basis_kernel keeps the whole K x (K+16) seed block in LDS; above: column chunks)
 constexpr int kAdjHdr = 16;     // partial row: dR (9), dT (3), pad, then dWc (K)
 constexpr int kScanThreads = 1024;
 
@@ -154,6 +154,104 @@ __global__ __launch_bounds__(kBlock, 2) void adj_basis_kernel(const AdjArgs a) {
   }
 }
 
+// K > 128: the seed block [K x (K+16)] no longer fits the LDS (K = 256: 282 KB), so its COLUMN blocks are taken in chunks of NBC
+// (K = 256: 3 chunks of 6 / 6 / 5 blocks, 116 KB each) and the row blocks are walked once per chunk -- the basis is read NCH
+// times (the backward of a K = 256 level is not the hot path; the forward reads it twice per iteration anyway).  A wave meets the
+// same row blocks in every chunk, so zeta = b.S_dd b is accumulated in the pixel's record by the lane that owns it: first chunk
+// writes, later chunks add, in chunk order -- deterministic.
+template <int NK, int NBC>
+__global__ __launch_bounds__(kBlock, 1) void adj_basis_wide_kernel(const AdjArgs a) {
+  extern __shared__ float Wl[];
+  constexpr int KP = 16 * NK, LSC = 16 * NBC + 20, NB = NK + 1, NCH = (NB + NBC - 1) / NBC;   // LSC mod 32 = 20 as in adj_basis_kernel
+  static_assert((NBC & 1) == 0, "bank spreading of the kq groups needs 16 NBC = 0 mod 32");
+  const int b = blockIdx.y, K = a.lv.K, N = a.lv.N, P = 6 + K;
+  const float* __restrict__ S = a.S + (size_t)b * P * P;
+  const float* __restrict__ gb = a.gb + (size_t)b * P;
+  const int lane = threadIdx.x & 63, w = wave_id(), i = lane & 15, kq = lane >> 4;
+  const float* __restrict__ bas = a.lv.basis + (size_t)b * N * K;
+  float* __restrict__ z2 = a.z2 + (size_t)b * N * K;
+  float* __restrict__ arec = a.arec + (size_t)b * N * 8;
+  const int nrb = (N + 15) >> 4;
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    __syncthreads();   // the previous chunk's readers are done
+    for (int idx = threadIdx.x; idx < KP * LSC; idx += kBlock) {
+      const int k = idx / LSC, jj = idx - k * LSC, j = 16 * NBC * ch + jj;
+      float v = 0.f;
+      if (k < K && jj < 16 * NBC) {
+        if (j < K)
+          v = S[(size_t)(6 + k) * P + 6 + j];
+        else if (j >= KP && j < KP + 6)
+          v = S[(size_t)(j - KP) * P + 6 + k];
+        else if (j == KP + 6)
+          v = gb[6 + k];
+      }
+      Wl[idx] = v;
+    }
+    __syncthreads();
+    for (int rb = blockIdx.x * kNumWaves + w; rb < nrb; rb += gridDim.x * kNumWaves) {
+      const int n = rb * 16 + i;
+      const bool okn = n < N;
+      const float* __restrict__ row = bas + (size_t)(okn ? n : 0) * K;
+      float av[NK][4];
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = 16 * kk + 4 * kq + e;
+          const float v = row[k < K ? k : 0];
+          av[kk][e] = (okn && k < K) ? v : 0.f;
+        }
+      f32x4 acc[NBC];
+#pragma unroll
+      for (int jb = 0; jb < NBC; ++jb) acc[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) {
+        asm volatile("" ::: "memory");   // as in adj_basis_kernel: keep the LDS operand reads inside the loop
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float* wl = Wl + (16 * kk + 4 * kq + e) * LSC + i;
+#pragma unroll
+          for (int jb = 0; jb < NBC; ++jb)
+            if (NBC * ch + jb < NB) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk][e], wl[16 * jb], acc[jb], 0, 0, 0);
+        }
+      }
+      float zeta[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int nn = rb * 16 + 4 * kq + v;
+        const bool ok = nn < N;
+#pragma unroll
+        for (int jb = 0; jb < NBC; ++jb) {
+          const int j = 16 * (NBC * ch + jb) + i;
+          if (NBC * ch + jb < NK && ok && j < K) {
+            zeta[v] = fmaf(acc[jb][v], bas[(size_t)nn * K + j], zeta[v]);
+            z2[(size_t)nn * K + j] = 2.f * acc[jb][v];
+          }
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const float zt = row16_sum(zeta[v]);
+        const int nn = rb * 16 + 4 * kq + v;
+        if (nn < N) {
+          if (i == 7) {
+            if (ch == 0)
+              arec[(size_t)nn * 8 + 6] = zt;
+            else
+              arec[(size_t)nn * 8 + 6] += zt;
+          }
+          if (NBC * ch <= NK && NK < NBC * (ch + 1)) {   // the chunk that holds the extra block [S_cd^T | gb]
+            constexpr int je = NK % NBC;
+            if (i < 6) arec[(size_t)nn * 8 + i] = acc[je][v];
+            if (i == 6) arec[(size_t)nn * 8 + 7] = acc[je][v];
+          }
+        }
+      }
+    }
+  }
+}
+
 // ---- per-pixel adjoint ------------------------------------------------------------------------------------------------
 // sum over the wave, every lane gets it: DPP row sums + 4 v_readlane (the ds_bpermute butterfly of wave_sum costs ~6 LDS
 // round trips per value; this kernel needs 8 sums per pixel).  Fixed order -> deterministic.
@@ -166,8 +264,8 @@ __device__ __forceinline__ float wsum(float v) {
   return (a0 + a1) + (a2 + a3);
 }
 
-template <int CJ, int KJ>   // C <= 64 CJ, K <= 64 KJ
-__global__ __launch_bounds__(kBlock, 3) void adj_pixel_kernel(const AdjArgs a) {
+template <int CJ, int KJ>   // C <= 64 CJ, K <= 64 KJ (K > 128: 2 waves per SIMD -- the per-coefficient state would spill at 3)
+__global__ __launch_bounds__(kBlock, (KJ >= 3 ? 2 : 3)) void adj_pixel_kernel(const AdjArgs a) {
   const banet_level_t& lv = a.lv;
   const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x & 63, w = wave_id();
   const int N = lv.N, C = lv.C, K = lv.K, H = lv.H, W = lv.W, P = 6 + K;
@@ -1201,8 +1299,10 @@ struct AdjPlan {
 };
 
 bool adj_supported(const banet_level_t* lv) {
-  return lv->variant == BANET_BUNDLE && lv->dense == 1 && lv->tgt_has_grad == 0 && lv->pairs <= 1 && lv->K >= 1 &&
-         lv->K <= 64 * kAdjMaxKJ && lv->C >= 1 && lv->C <= 64 * kAdjMaxCJ && lv->N == lv->H * lv->W;
+  const bool var_ok = (lv->variant == BANET_BUNDLE && lv->K >= 1 && lv->K <= 64 * kAdjMaxKJ) ||
+                      (lv->variant == BANET_BUNDLE_CAMERA && lv->K == 0);     // pose only: bundlenet.py:122-191, depth fixed
+  return var_ok && lv->dense == 1 && lv->tgt_has_grad == 0 && lv->pairs <= 1 && lv->C >= 1 && lv->C <= 64 * kAdjMaxCJ &&
+         lv->N == lv->H * lv->W;
 }
 
 void adj_plan(const banet_level_t* lv, AdjPlan* pl) {
@@ -1240,6 +1340,15 @@ void launch_adj_basis(const AdjArgs& a, int Ga, hipStream_t s) {
   if (shm > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&adj_basis_kernel<NK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
   hipLaunchKernelGGL((adj_basis_kernel<NK>), dim3(Ga, a.lv.B), dim3(kBlock), shm, s, a);
+}
+
+template <int NK>
+void launch_adj_basis_wide(const AdjArgs& a, int Ga, hipStream_t s) {
+  constexpr int NBC = 6, KP = 16 * NK, LSC = 16 * NBC + 20;
+  const size_t shm = (size_t)KP * LSC * sizeof(float);
+  static_assert((size_t)KP * LSC * sizeof(float) <= 160 * 1024, "seed chunk exceeds the LDS");
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&adj_basis_wide_kernel<NK, NBC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+  hipLaunchKernelGGL((adj_basis_wide_kernel<NK, NBC>), dim3(Ga, a.lv.B), dim3(kBlock), shm, s, a);
 }
 
 }  // namespace
@@ -1295,12 +1404,19 @@ int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T
     case 6: launch_adj_basis<6>(a, pl.Ga, s); break;
     case 7: launch_adj_basis<7>(a, pl.Ga, s); break;
     case 8: launch_adj_basis<8>(a, pl.Ga, s); break;
+    case 9: case 10: case 11: case 12: launch_adj_basis_wide<12>(a, pl.Ga, s); break;
+    case 13: case 14: case 15: case 16: launch_adj_basis_wide<16>(a, pl.Ga, s); break;
+    case 0:   // pose only: no depth block -> q = zeta = e = 0; the pixel kernels read (never use) one basis / z2 element
+      if (hipMemsetAsync(a.arec, 0, (size_t)B * N * 8 * sizeof(float), s) != hipSuccess) return BANET_ERR_LAUNCH;
+      a.lv.basis = a.arec;
+      a.z2 = a.arec;
+      break;
     default: return BANET_ERR_UNSUPPORTED;
   }
   if ((lv->C & 3) == 0 && (K & 3) == 0 && lv->C <= 128 && K <= 128 && !(lv->reserved_ & 262144)) {   // bit 18: one pixel per wave (A/B)
     hipLaunchKernelGGL((adj_pixel2_kernel<1>), dim3(pl.G, B), dim3(kBlock), 0, s, a);   // (C = 256: 264 B of spills -> the one-pixel kernel)
   } else {
-    const int CJ = (lv->C + 63) / 64, KJ = (K + 63) / 64;
+    const int CJ = (lv->C + 63) / 64, KJ = std::max(1, (K + 63) / 64);
     const dim3 grid(pl.G, B), block(kBlock);
 #define BANET_ADJ_PIXEL(cj, kj) \
   if (CJ == cj && KJ == kj) hipLaunchKernelGGL((adj_pixel_kernel<cj, kj>), grid, block, 0, s, a)
@@ -1312,6 +1428,14 @@ int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T
     BANET_ADJ_PIXEL(2, 2);
     BANET_ADJ_PIXEL(3, 2);
     BANET_ADJ_PIXEL(4, 2);
+    BANET_ADJ_PIXEL(1, 3);
+    BANET_ADJ_PIXEL(2, 3);
+    BANET_ADJ_PIXEL(3, 3);
+    BANET_ADJ_PIXEL(4, 3);
+    BANET_ADJ_PIXEL(1, 4);
+    BANET_ADJ_PIXEL(2, 4);
+    BANET_ADJ_PIXEL(3, 4);
+    BANET_ADJ_PIXEL(4, 4);
 #undef BANET_ADJ_PIXEL
   }
   launch_cell_scan(a.cnt, a.start, a.cursor, reinterpret_cast<int*>(base + pl.off_chunks), B, HW, s);

@@ -342,9 +342,9 @@ size_t banet_dense_adjoint_workspace_bytes(const banet_level_t* lv) {
 int banet_dense_adjoint_f32(const banet_level_t* lv, const float* R, const float* T, const float* Wc, const float* gAtA,
                             const float* gAtb, const float* gabs, float* dsrc, float* dmap3, float* ddepth, float* dbasis,
                             float* dpose, void* ws, size_t ws_bytes, banet_stream_t stream) {
-  if (!lv || !R || !T || !Wc || !gAtA || !gAtb || !gabs || !dsrc || !dmap3 || !ddepth || !dbasis || !dpose || !ws)
-    return BANET_ERR_INVALID_ARG;
-  if (lv->B <= 0 || lv->N <= 0 || !lv->src || !lv->tgt || !lv->depth || !lv->basis || !lv->intr) return BANET_ERR_INVALID_ARG;
+  if (!lv || !R || !T || !gAtA || !gAtb || !gabs || !dsrc || !dmap3 || !ddepth || !dpose || !ws) return BANET_ERR_INVALID_ARG;
+  if (lv->K > 0 && (!Wc || !dbasis || !lv->basis)) return BANET_ERR_INVALID_ARG;     // K = 0 (pose only): no coefficient / basis tensors
+  if (lv->B <= 0 || lv->N <= 0 || !lv->src || !lv->tgt || !lv->depth || !lv->intr) return BANET_ERR_INVALID_ARG;
   const size_t need = dense_adjoint_workspace_bytes(lv);
   if (need == 0) return BANET_ERR_UNSUPPORTED;
   if (ws_bytes < need || (reinterpret_cast<uintptr_t>(ws) & 255) != 0) return BANET_ERR_WORKSPACE;

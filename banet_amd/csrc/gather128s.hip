@@ -1,16 +1,18 @@
 // ba_gather128s_kernel -- the strip gather: the gather pass for C = 128 on large dense levels with the target map read
 // (almost) once.  The patch kernel (gather128p.hip) runs at the fabric's practical rate but fetches the target map 2.15 x:
 // a wave's 8x8 tile touches (8 + 3)^2 texels and nothing of that halo survives in the L2 until a neighbouring tile wants it.
-// Here a wave owns a STRIP SEGMENT of 16 x 32 source pixels and shares the halo with itself:
+// Here a wave owns a STRIP SEGMENT of 16 x 16 source pixels (16 x 32 behind a switch: fewer halo rows, but half as many work
+// items per wave and a longer tail -- measured slower, profiles/r03_run11_*) and shares the halo with itself:
 //
 //   * the channel loop is outermost: four passes over the segment, one per 32-channel slice (a texel's slice is one full
 //     128-byte line), each with a ROLLING WINDOW of the last 7 texel rows x 21 texels of the target map in the wave's own LDS
 //     (18.4 KB), filled by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write) as far ahead as the ring allows and
 //     consumed behind COUNTED s_waitcnt vmcnt(n) -- the per-step row counts and wait counts depend only on the segment's
 //     geometry, so they are planned once per segment (strip_plan.hpp, unit-tested on the host) and replayed by the 4 slices;
-//     target fetch = 21/16 x 35/32 = 1.44 texels per pixel instead of 2.15 (launch: 1.15 x its algorithmic bytes, was 1.38);
+//     target fetch = 20/16 x 19/16 = 1.48 texels per pixel instead of 2.15 (counters: the launch moves 1.12-1.19 x its
+//     algorithmic bytes, the patch kernel 1.43-1.47 x: profiles/pmc_traffic.json);
 //   * what has to live across the slices is per-pixel state of the whole segment (tap parameters, depth, the five channel
-//     sums): 9 registers x 8 chunks of 64 pixels, held as lane = pixel in a TRANSPOSED order (lane 4 p + k <-> pixel (row k,
+//     sums): 9 registers x 4 (8) chunks of 64 pixels, held as lane = pixel in a TRANSPOSED order (lane 4 p + k <-> pixel (row k,
 //     column p) of a chunk of 4 rows x 16), so that the tap phase -- one pixel ROW per step, 4 lanes per pixel, 8 channels per
 //     lane -- finds a pixel's parameters inside its own quad (one DPP quad_perm broadcast, no LDS) and leaves the pixel's
 //     sums, after a 2-step DPP reduction over the quad, on exactly the lane that owns the pixel: no staging tables, no

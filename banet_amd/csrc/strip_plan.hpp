@@ -2,7 +2,7 @@
 // host as well: tests/test_strip_plan_cpu.py builds it with g++ and replays the planned instruction stream against a
 // model of the LDS ring and of the in-order VMEM counter.
 //
-// A segment is kStripW x kStripH source pixels.  For one 32-channel slice of the target map the wave keeps the last
+// A segment is kStripW x 16 source pixels (kStripH = 32 at most, behind a switch).  For one 32-channel slice of the target map the wave keeps the last
 // kWinRows texel rows of a kWinTex-texel-wide column band in its own LDS ("window"); texel row Y lives in ring slot
 // Y mod kWinRows.  The wave walks the segment's pixel rows top to bottom ("steps"); before the taps of step r it (1) issues
 // the source-feature loads of step r + kSrcAhead, (2) issues the LDS-DMA loads of the window rows the plan assigns to step r -- as far
@@ -22,7 +22,7 @@
 namespace banet {
 
 constexpr int kStripW = 16;     // source pixels per pixel row of a segment (= 2 instruction groups of 8 pixels)
-constexpr int kStripH = 32;     // pixel rows per segment (= 8 chunks of 4 rows = 64 pixels)
+constexpr int kStripH = 32;     // most pixel rows per segment the plan is sized for (8 chunks of 4 rows); the default is 16
 constexpr int kWinTex = 21;     // texels per window row: kStripW + 3 (stencil) + 2 (slack: local scale up to ~1.12)
 constexpr int kWinRows = 7;     // ring slots
 constexpr int kWinPitchB = kWinTex * 128;        // bytes per window row: 32 channels x 4 B per texel

@@ -86,7 +86,8 @@ class DenseBA:
         """The same fixed-count schedule attached to the autograd graph: gradients flow to the levels' src / tgt / depth /
         basis tensors, to the initial (R, T, Wc) and to the lambda weights through the fused backward kernels
         (banet_amd/dense_train.py, csrc/adjoint.hip; the reference differentiates bundlenet.py:376-397 with tf.gradients +
-        EquationConstructionGrad).  Bundle variant, K <= 128; two-frame and multi-frame windows."""
+        EquationConstructionGrad).  `bundle` (K <= 256) and the pose-only `bundle_camera` variant; two-frame and multi-frame
+        windows."""
         from . import dense_train
         return dense_train.solve_differentiable(self, self.levels, self.lambda_weights, iters_per_level, R, T, Wc)
 

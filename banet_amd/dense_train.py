@@ -12,7 +12,8 @@ One autograd node per pyramid LEVEL (all of its fixed-count iterations, as bundl
             pose, accumulated over the iterations in place; (c) once per level banet_target_map_adjoint_f32 folds the
             [f|gx|gy] map adjoint into the target map's gradient.
 No J / G / d / samp tensors exist in either direction and nothing is scattered with float atomics: gradients are
-bit-reproducible.  Supported: the `bundle` variant, K <= 128, C <= 256, two-frame AND multi-frame windows (round 3): a window's
+bit-reproducible.  Supported: the `bundle` variant with K <= 256 and the pose-only `bundle_camera` variant (bundlenet.py:122-191:
+no depth basis, P = 6, every coefficient damped), C <= 256, two-frame AND multi-frame windows (round 3): a window's
 normal equations are the sum of its target frames' two-frame terms embedded in the block-arrowhead matrix (AtA = sum_i E_i AtA_i
 E_i^T), so its backward is the two-frame adjoint once per target frame on the sub-blocks
 dL/dAtA_i = E_i^T (dL/dAtA) E_i, dL/dAtb_i = E_i^T dL/dAtb -- the source / depth / basis gradients accumulate over the frames, every
@@ -36,11 +37,12 @@ def _to_param(t, dev):
     return t.to(dev) if torch.is_tensor(t) else torch.as_tensor(t, dtype=torch.float32, device=dev)
 
 
-def solve_update_graph(AtA, Atb, absres, N, R, T, Wc, layers, l2_base, solve=torch.linalg.solve, pairs=1):
+def solve_update_graph(AtA, Atb, absres, N, R, T, Wc, layers, l2_base, solve=torch.linalg.solve, pairs=1, camera=False):
     """bundlenet.py:241-276 after the EquationConstruction op, as differentiable torch statements on the small tensors:
     avg -> lambda MLP -> damping (last coefficient undamped) -> matrix_solve -> SE(3) / W update.  pairs > 1: the multi-frame
     window of SURVEY.md 8(d) (banet_oracle.bundle_window_iteration): residual averaged over all frames, parameter order
-    [pose_1 .. pose_pairs, depth], R [B,pairs,3,3], T [B,pairs,3,1]."""
+    [pose_1 .. pose_pairs, depth], R [B,pairs,3,3], T [B,pairs,3,1].  camera: the pose-only CameraIteration,
+    bundlenet.py:165-190 -- no l2_regularizer_base, all six coefficients damped (:181-182), Wc is [B,0,1]."""
     nb = AtA.shape[0]
     avg = (absres / float(N * pairs)).unsqueeze(1)                                   # :243
     h = avg
@@ -48,9 +50,12 @@ def solve_update_graph(AtA, Atb, absres, N, R, T, Wc, layers, l2_base, solve=tor
         z = torch.matmul(h, w) + b
         h = torch.tanh(z) if i == 4 else torch.nn.functional.selu(z)
     lam = torch.linalg.vector_norm(avg, dim=-1, keepdim=True) ** (2.0 + h)           # :249
-    lam = l2_base * lam                                                              # :252-253
     diag = torch.diagonal(AtA, dim1=1, dim2=2)
-    damp = torch.cat([diag[:, :-1] + 1e-5, torch.zeros(nb, 1, device=diag.device, dtype=diag.dtype)], dim=-1)   # :266
+    if camera:
+        damp = diag + 1e-5                                                           # :181-182
+    else:
+        lam = l2_base * lam                                                          # :252-253
+        damp = torch.cat([diag[:, :-1] + 1e-5, torch.zeros(nb, 1, device=diag.device, dtype=diag.dtype)], dim=-1)   # :266
     A = AtA + torch.diag_embed(damp * lam.squeeze(-1))
     sol = solve(A, Atb.unsqueeze(-1))                                                # :267
     Rn, Tn = [], []
@@ -109,7 +114,7 @@ class _SolveNoCheck(torch.autograd.Function):
         return -torch.matmul(lam, x.transpose(-1, -2)), lam
 
 
-def _small_grads(AtA, Atb, absres, R, T, Wc, gR, gT, gW, flat, N, l2_base, pairs=1):
+def _small_grads(AtA, Atb, absres, R, T, Wc, gR, gT, gW, flat, N, l2_base, pairs=1, camera=False):
     """dL/d(AtA, Atb, sum|d|, R, T, Wc, lambda weights) of one iteration's small part, given dL/d(R', T', W')."""
     with torch.enable_grad():
         leaves = [t.detach().requires_grad_(True) for t in (AtA, Atb, absres, R, T, Wc)]
@@ -117,8 +122,9 @@ def _small_grads(AtA, Atb, absres, R, T, Wc, gR, gT, gW, flat, N, l2_base, pairs
         spd_ok = AtA.is_cuda and 32 <= AtA.shape[-1] <= 180 and USE_SPD_SOLVE      # banet_spd_solve_f32 keeps the matrix in LDS
         R2, T2, W2 = solve_update_graph(leaves[0], leaves[1], leaves[2], N, leaves[3], leaves[4], leaves[5],
                                         [(lw[2 * i], lw[2 * i + 1]) for i in range(5)], l2_base,
-                                        solve=_SolveSPD.apply if spd_ok else _SolveNoCheck.apply, pairs=pairs)
-        grads = torch.autograd.grad([R2, T2, W2], leaves + lw, [gR, gT, gW], allow_unused=True)
+                                        solve=_SolveSPD.apply if spd_ok else _SolveNoCheck.apply, pairs=pairs, camera=camera)
+        outs, seeds = ([R2, T2], [gR, gT]) if camera else ([R2, T2, W2], [gR, gT, gW])      # camera: W2 = Wc, an empty tensor
+        grads = torch.autograd.grad(outs, leaves + lw, seeds, allow_unused=True)
     return [g if g is not None else torch.zeros_like(t) for g, t in zip(grads, leaves + lw)]
 
 
@@ -127,9 +133,9 @@ class _SmallStepGraph:
     [B,C] tensors per iteration are launch-bound when issued one by one from Python.  Static input / output buffers; falls
     back to eager execution if capture is not possible (BANET_TRAIN_GRAPH=0 disables it)."""
 
-    def __init__(self, shapes, dev, N, l2_base, pairs=1):
+    def __init__(self, shapes, dev, N, l2_base, pairs=1, camera=False):
         import os
-        self.N, self.l2, self.pairs = N, l2_base, pairs
+        self.N, self.l2, self.pairs, self.camera = N, l2_base, pairs, camera
         self.inp = [torch.zeros(s, dtype=torch.float32, device=dev) for s in shapes]
         self.graph, self.out, self.error = None, None, None
         mode = os.environ.get("BANET_TRAIN_GRAPH", "1")
@@ -159,11 +165,11 @@ class _SmallStepGraph:
 
     def _run(self):
         i = self.inp
-        return _small_grads(i[0], i[1], i[2], i[3], i[4], i[5], i[6], i[7], i[8], i[9:], self.N, self.l2, self.pairs)
+        return _small_grads(i[0], i[1], i[2], i[3], i[4], i[5], i[6], i[7], i[8], i[9:], self.N, self.l2, self.pairs, self.camera)
 
     def __call__(self, tensors):
         if self.graph is None:
-            return _small_grads(*tensors[:9], tensors[9:], self.N, self.l2, self.pairs)
+            return _small_grads(*tensors[:9], tensors[9:], self.N, self.l2, self.pairs, self.camera)
         for dst, src in zip(self.inp, tensors):
             dst.copy_(src.reshape(dst.shape))
         self.graph.replay()
@@ -185,12 +191,12 @@ def small_step_modes():
     return {str(k[0][0]): ("graph" if v.graph is not None else "eager (%s)" % (v.error or "capture failed")) for k, v in _small_cache.items()}
 
 
-def _small_step(tensors, N, l2_base, pairs=1):
+def _small_step(tensors, N, l2_base, pairs=1, camera=False):
     dev = tensors[0].device
-    key = (tuple(tuple(t.shape) for t in tensors), str(dev), int(N), float(l2_base), int(pairs))
+    key = (tuple(tuple(t.shape) for t in tensors), str(dev), int(N), float(l2_base), int(pairs), bool(camera))
     st = _small_cache.pop(key, None)
     if st is None:
-        st = _SmallStepGraph([tuple(t.shape) for t in tensors], dev, N, l2_base, pairs)
+        st = _SmallStepGraph([tuple(t.shape) for t in tensors], dev, N, l2_base, pairs, camera)
         while len(_small_cache) >= _SMALL_CACHE_MAX:          # least recently used first (dicts keep insertion order)
             _small_cache.pop(next(iter(_small_cache)))
     _small_cache[key] = st
@@ -202,11 +208,11 @@ def dense_adjoint(problem, R, T, Wc, gAtA, gAtb, gabs, dsrc, dmap3, ddepth, dbas
     L = capi.lib()
     nb = L.banet_dense_adjoint_workspace_bytes(ctypes.byref(problem.c))
     if nb == 0:
-        raise capi.BanetError("dense_adjoint: unsupported level (bundle variant, dense two-frame windows, K <= 128, C <= 256)")
+        raise capi.BanetError("dense_adjoint: unsupported level (bundle with 1 <= K <= 256 or bundle_camera, dense two-frame windows, C <= 256)")
     if ws is None or ws.numel() < nb:
         ws = capi.workspace(nb, problem.device)
     dpose = torch.empty((problem.B, 12 + problem.K), dtype=torch.float32, device=problem.device)
-    args = [capi.f32c(x) for x in (R, T, Wc, gAtA, gAtb, gabs)]
+    args = [capi.f32c(x) for x in (R, T, Wc, gAtA, gAtb, gabs)]          # (K = 0: Wc / dbasis are empty, never dereferenced)
     capi.check(L.banet_dense_adjoint_f32(ctypes.byref(problem.c), *[capi.ptr(x) for x in args], capi.ptr(dsrc), capi.ptr(dmap3),
                                          capi.ptr(ddepth), capi.ptr(dbasis), capi.ptr(dpose), ctypes.c_void_p(ws.data_ptr()),
                                          ws.numel(), capi.stream()))
@@ -228,8 +234,9 @@ def _pair_problems(ba, li):
     out = []
     for i in range(prob.pairs):
         tgt_i = lv.tgt.detach()[:, i].contiguous()
-        out.append(ops.LevelProblem("bundle", lv.src.detach(), tgt_i, lv.depth.detach().reshape(B, H * W), H, W, C,
-                                    basis=lv.basis.detach().reshape(B, H * W, -1), intr=ba.intr, scale=lv.scale, dense=True,
+        out.append(ops.LevelProblem(ba.variant, lv.src.detach(), tgt_i, lv.depth.detach().reshape(B, H * W), H, W, C,
+                                    basis=None if lv.basis is None else lv.basis.detach().reshape(B, H * W, -1), intr=ba.intr,
+                                    scale=lv.scale, dense=True,
                                     tgt_has_grad=False, normalize_rays=True, pairs=1))
     return out
 
@@ -250,7 +257,7 @@ class _LevelSolve(torch.autograd.Function):
             saved.append((Ri, Ti, Wi, AtA, Atb, absres))
         ctx.ba, ctx.li, ctx.saved = ba, li, saved
         ctx.layers = flat_layers
-        ctx.shapes = (src.shape, tgt.shape, depth.shape, basis.shape, R.shape, T.shape)
+        ctx.shapes = (src.shape, tgt.shape, depth.shape, None if basis is None else basis.shape, R.shape, T.shape)
         return st.R.clone().reshape(R.shape), st.T.clone().reshape(T.shape), st.Wc.clone()
 
     @staticmethod
@@ -260,6 +267,7 @@ class _LevelSolve(torch.autograd.Function):
         prob = ba.problems[li]
         pairs = prob.pairs
         dev = prob.device
+        camera = ba.variant == "bundle_camera"
         B, N, C, K, H, W = prob.B, prob.N, prob.C, prob.K, prob.c.H, prob.c.W
         pprobs = [prob] if pairs == 1 else _pair_problems(ba, li)
         dsrc = torch.zeros((B, N, C), dtype=torch.float32, device=dev)
@@ -275,7 +283,7 @@ class _LevelSolve(torch.autograd.Function):
         ws = None
         for Ri, Ti, Wi, AtA, Atb, absres in reversed(ctx.saved):
             Rv, Tv = Ri.reshape(B, pairs, 3, 3), Ti.reshape(B, pairs, 3, 1)
-            grads = _small_step([AtA, Atb, absres, Rv, Tv, Wi, gR, gT, gW] + [t.detach() for t in flat], N, ba.l2_base, pairs)
+            grads = _small_step([AtA, Atb, absres, Rv, Tv, Wi, gR, gT, gW] + [t.detach() for t in flat], N, ba.l2_base, pairs, camera)
             gAtA, gAtb, gabs, dR, dT, dW = grads[:6]
             for acc, g in zip(glayers, grads[6:]):
                 acc += g
@@ -298,17 +306,17 @@ class _LevelSolve(torch.autograd.Function):
             target_map_adjoint(dmap3[i], di)
             dtgt[:, i] = di
         s_src, s_tgt, s_dep, s_bas, s_R, s_T = ctx.shapes
-        return (None, None, None, dsrc.reshape(s_src), dtgt.reshape(s_tgt), ddepth.reshape(s_dep), dbasis.reshape(s_bas),
-                gR.reshape(s_R), gT.reshape(s_T), gW) + tuple(glayers)
+        return (None, None, None, dsrc.reshape(s_src), dtgt.reshape(s_tgt), ddepth.reshape(s_dep),
+                None if s_bas is None else dbasis.reshape(s_bas), gR.reshape(s_R), gT.reshape(s_T), gW) + tuple(glayers)
 
 
 def solve_differentiable(ba, levels, lambda_weights, iters_per_level, R=None, T=None, Wc=None):
     """Differentiable DenseBA.solve with fixed iteration counts: `levels` = the DenseLevel objects `ba` was built from (their
     src / tgt / depth / basis tensors may require grad), `lambda_weights` = per level five (filters, biases) pairs (tensors
     that may require grad, or arrays).  Returns (R [B,3,3], T [B,3,1], Wc [B,K,1]) attached to the autograd graph
-    (multi-frame windows: R [B,pairs,3,3], T [B,pairs,3,1])."""
-    if ba.variant != "bundle":
-        raise capi.BanetError("solve_differentiable: bundle variant only")
+    (multi-frame windows: R [B,pairs,3,3], T [B,pairs,3,1]; the pose-only `bundle_camera` variant: K = 0, Wc is empty)."""
+    if ba.variant not in ("bundle", "bundle_camera"):
+        raise capi.BanetError("solve_differentiable: bundle / bundle_camera variants only")
     dev = ba.intr.device
     B, K, pairs = ba.B, ba.K, ba.pairs
     if pairs == 1:

@@ -255,8 +255,10 @@ int banet_sample_stats_grad_det_f32(const float* conv1, const float* conv2, cons
  *     direct dependence of the update step on R, T, Wc).  What TF autodiff + EquationConstructionGrad (bundlenet.py:79-82,
  *     utils.cu:465-694) compute for bundlenet.py:206-263, per pixel, without J / G / d in memory.  Bit-reproducible:
  *     the target-map adjoint is gathered per texel in a fixed order (integer atomics only build the cell lists).
- *     Supported: BANET_BUNDLE, dense = 1, tgt_has_grad = 0, pairs <= 1, 1 <= K <= 128, C <= 256 (else workspace_bytes = 0
- *     and BANET_ERR_UNSUPPORTED).
+ *     Supported: dense = 1, tgt_has_grad = 0, pairs <= 1, C <= 256, and BANET_BUNDLE with 1 <= K <= 256 or the pose-only
+ *     BANET_BUNDLE_CAMERA (bundlenet.py:122-191: K = 0, P = 6; basis / Wc / dbasis are not touched and may be NULL); else
+ *     workspace_bytes = 0 and BANET_ERR_UNSUPPORTED.  A multi-frame window (pairs > 1) is the sum of its frames' two-frame
+ *     terms: call once per target frame with the frame's sub-blocks of gAtA / gAtb (banet_amd/dense_train.py does).
  *   banet_target_map_adjoint_f32: dimg [B,H,W,C] += dmap3_f + grad_fixed^T (dmap3_gx, dmap3_gy) -- the adjoint of
  *     banet_target_map_f32 (REFLECT rim: zero gradient on the 1-px border, bundlenet.py:92-100); once per level.      */
 size_t banet_dense_adjoint_workspace_bytes(const banet_level_t* lv);

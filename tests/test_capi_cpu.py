@@ -213,14 +213,18 @@ def test_backward_entry_points_validate_their_arguments_without_gpu(capi):
     lv.variant, lv.dense, lv.scale, lv.pairs = capi.BUNDLE, 1, 1.0, 1
     nb = L.banet_dense_adjoint_workspace_bytes(ctypes.byref(lv))
     assert nb > 0 and nb % 256 == 0
-    for field, bad in (("K", 129), ("K", 0), ("C", 257), ("pairs", 2), ("dense", 0), ("tgt_has_grad", 1), ("N", 100)):
+    for field, bad in (("K", 257), ("K", 0), ("C", 257), ("pairs", 2), ("dense", 0), ("tgt_has_grad", 1), ("N", 100)):
         keep = getattr(lv, field)
         setattr(lv, field, bad)
         assert L.banet_dense_adjoint_workspace_bytes(ctypes.byref(lv)) == 0, field      # outside the supported set
         setattr(lv, field, keep)
-    lv.variant = capi.BUNDLE_CAMERA if hasattr(capi, "BUNDLE_CAMERA") else 2
+    lv.K = 256
+    assert L.banet_dense_adjoint_workspace_bytes(ctypes.byref(lv)) > 0                  # round 3: K <= 256
+    lv.variant = capi.BUNDLE_CAMERA                                                     # pose only: K = 0 exactly
     assert L.banet_dense_adjoint_workspace_bytes(ctypes.byref(lv)) == 0
-    lv.variant = capi.BUNDLE
+    lv.K = 0
+    assert L.banet_dense_adjoint_workspace_bytes(ctypes.byref(lv)) > 0
+    lv.variant, lv.K = capi.BUNDLE, 128
     assert L.banet_dense_adjoint_f32(ctypes.byref(lv), *([None] * 11), None, 0, None) == -1   # null pointers
     assert L.banet_dense_adjoint_f32(None, *([None] * 11), None, 0, None) == -1
     assert L.banet_target_map_adjoint_f32(None, None, 1, 4, 4, 8, None) == -1

@@ -131,3 +131,73 @@ def test_small_step_graph_of_a_multi_frame_window_matches_the_oracle_update():
     np.testing.assert_allclose(R2.numpy(), np.stack(Rn, 1), rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(T2.numpy(), np.stack(Tn, 1), rtol=1e-8, atol=1e-12)
     np.testing.assert_allclose(W2.numpy(), Wn, rtol=1e-8, atol=1e-12)
+
+
+def _camera_inputs(intr, lv):
+    """level inputs of the pose-only CameraIteration: the bundle level with an EMPTY depth basis (K = 0)"""
+    a = odense.level_inputs(intr, lv, True, np.float64)
+    a["Bs"] = np.zeros(a["Bs"].shape[:2] + (0,))
+    return a
+
+
+def test_pose_only_small_step_and_assembly_adjoint():
+    """The pose-only variant (bundlenet.py:122-191) through the same statements with K = 0: forward_lean reproduces
+    oracle.bundle_camera_iteration's normal equations, solve_update_graph(camera=True) its update (all six coefficients damped,
+    no l2 base), and the adjoint matches finite differences for the pose, the depth and the feature maps."""
+    import torch
+    from banet_amd import dense_train
+    intr, lv, R, T, _, rng = _scene(seed=7)
+    lv = {k: (np.asarray(v, np.float64) if isinstance(v, np.ndarray) else v) for k, v in lv.items()}
+    B, H, W, C = lv["src"].shape
+    N = H * W
+    a = _camera_inputs(intr, lv)
+    W0 = np.zeros((B, 0, 1))
+    mlp = orc.he_normal_mlp_weights(C, 5, np.float64)
+    Rn, Tn, dbg = orc.bundle_camera_iteration(a["conv1"], a["conv2"], a["fx"], a["fy"], a["ox"], a["oy"], a["p"], a["D"], R, T, mlp)
+    F = adj.forward_lean(a, lv["tgt"], R, T, W0)
+    for k in ("AtA", "Atb", "avg"):
+        np.testing.assert_allclose(F[k], dbg[k], rtol=1e-10, atol=1e-10 * np.abs(dbg[k]).max())
+    tt = lambda v: torch.from_numpy(np.asarray(v, np.float64))
+    layers = [(tt(w), tt(b)) for w, b in mlp]
+    R2, T2, W2 = dense_train.solve_update_graph(tt(dbg["AtA"]), tt(dbg["Atb"][..., 0]), tt(dbg["avg"][:, 0] * N), N, tt(R), tt(T),
+                                                tt(W0), layers, 1.0, camera=True)
+    np.testing.assert_allclose(R2.numpy(), Rn, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(T2.numpy(), Tn, rtol=1e-9, atol=1e-12)
+    assert W2.shape == (B, 0, 1)
+    # the small step's gradients exist for an empty coefficient vector
+    g = dense_train._small_grads(tt(dbg["AtA"]), tt(dbg["Atb"][..., 0]), tt(dbg["avg"][:, 0] * N), tt(R).reshape(B, 1, 3, 3),
+                                 tt(T).reshape(B, 1, 3, 1), tt(W0), torch.ones(B, 1, 3, 3, dtype=torch.float64),
+                                 torch.ones(B, 1, 3, 1, dtype=torch.float64), torch.zeros(B, 0, 1, dtype=torch.float64),
+                                 [x for wb in layers for x in wb], N, 1.0, camera=True)
+    assert g[0].shape == (B, 6, 6) and g[5].shape == (B, 0, 1) and all(torch.isfinite(x).all() for x in g)
+
+    G = rng.standard_normal((B, 6, 6))
+    gb = rng.standard_normal((B, 6, 1))
+    gavg = rng.standard_normal((B, 1, C))
+    out = adj.assembly_adjoint(a, lv["tgt"], R, T, W0, G, gb, gavg)
+    assert out["dbasis"].shape == (B, N, 0) and out["dW"].shape == (B, 0, 1)
+
+    def phi(lv_, R_, T_):
+        F_ = adj.forward_lean(_camera_inputs(intr, lv_), lv_["tgt"], R_, T_, W0)
+        return float((G * F_["AtA"]).sum() + (gb * F_["Atb"]).sum() + (gavg * F_["avg"]).sum())
+
+    def fd(apply, shape, eps):
+        d = rng.standard_normal(shape)
+        d /= np.linalg.norm(d)
+        vals = sorted((apply(e * d) - apply(-e * d)) / (2 * e) for e in (eps, 3 * eps, 10 * eps))
+        return d, vals[1]
+
+    checks = []
+    for key, gname, shape in (("src", "dsrc", (B, H, W, C)), ("tgt", "dtgt", (B, H, W, C)), ("D0", "dD0", (B, H, W))):
+        def with_level(dl, key=key):
+            l2 = dict(lv)
+            l2[key] = lv[key] + dl
+            return phi(l2, R, T)
+        d, num = fd(with_level, shape, 3e-6)
+        checks.append((key, num, float((out[gname].reshape(shape) * d).sum())))
+    d, num = fd(lambda dl: phi(lv, R + dl, T), (B, 3, 3), 1e-7)
+    checks.append(("R", num, float((out["dR"] * d).sum())))
+    d, num = fd(lambda dl: phi(lv, R, T + dl), (B, 3, 1), 1e-7)
+    checks.append(("T", num, float((out["dT"] * d).sum())))
+    for name, num, ana in checks:
+        assert abs(num - ana) <= 1e-4 * max(abs(num), abs(ana)) + 1e-7, (name, num, ana)
