@@ -68,6 +68,9 @@ EXPORTS = {
     "banet_ba_assemble_f32": (ctypes.c_int, [ctypes.POINTER(Level)] + [_FP] * 7 + [_FP, ctypes.c_size_t, _FP]),
     "banet_ba_solve_update_f32": (ctypes.c_int, [ctypes.POINTER(Level), ctypes.POINTER(Mlp), ctypes.c_float] + [_FP] * 4 +
                                   [ctypes.POINTER(State), _FP]),
+    "banet_ba_solve_update_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Level)]),
+    "banet_ba_solve_update_ws_f32": (ctypes.c_int, [ctypes.POINTER(Level), ctypes.POINTER(Mlp), ctypes.c_float] + [_FP] * 4 +
+                                     [ctypes.POINTER(State), _FP, ctypes.c_size_t, _FP]),
     "banet_lm_level_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Level)]),
     "banet_lm_level_f32": (ctypes.c_int, [ctypes.POINTER(Level), ctypes.POINTER(Mlp), ctypes.c_float, ctypes.c_int,
                                           ctypes.c_int, ctypes.POINTER(State), _FP, ctypes.c_size_t, _FP]),

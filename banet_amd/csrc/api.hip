@@ -181,6 +181,29 @@ int banet_ba_solve_update_f32(const banet_level_t* lv, const banet_mlp_t* mlp, f
   return launch_solve(a, static_cast<hipStream_t>(stream));
 }
 
+size_t banet_ba_solve_update_workspace_bytes(const banet_level_t* lv) {
+  if (!lv || lv->B <= 0 || lv->C <= 0 || lv->K < 0 || lv->pairs < 0) return 0;
+  return align_up(solve_big_bytes(lv->B, 6 * npairs(lv) + lv->K, lv->C), 256);
+}
+
+int banet_ba_solve_update_ws_f32(const banet_level_t* lv, const banet_mlp_t* mlp, float l2_base, const float* AtA,
+                                 const float* Atb, const float* absres, const float* nvalid, banet_state_t* st, void* ws,
+                                 size_t ws_bytes, banet_stream_t stream) {
+  if (!lv || !AtA || !Atb || !absres || !nvalid) return BANET_ERR_INVALID_ARG;
+  if (lv->variant < BANET_LEGACY_LM || lv->variant > BANET_BUNDLE || lv->B <= 0 || lv->N <= 0 || lv->C <= 0 || lv->K < 0 ||
+      lv->pairs < 0)
+    return BANET_ERR_INVALID_ARG;
+  const int rc = check_state(lv, mlp, st);
+  if (rc != BANET_OK) return rc;
+  SolveArgs a = make_solve_args(lv, mlp, l2_base, AtA, Atb, absres, nvalid, st);
+  const size_t need = banet_ba_solve_update_workspace_bytes(lv);
+  if (need > 0) {
+    if (!ws || ws_bytes < need || !aligned256(ws)) return BANET_ERR_WORKSPACE;
+    a.bigA = static_cast<float*>(ws);
+  }
+  return launch_solve(a, static_cast<hipStream_t>(stream));
+}
+
 size_t banet_lm_level_workspace_bytes(const banet_level_t* lv) {
   AsmPlan pl;
   if (plan_assemble(lv, &pl) != BANET_OK) return 0;

@@ -250,10 +250,11 @@ class _LevelSolve(torch.autograd.Function):
         pairs = prob.pairs
         st = ops.LmState(R.detach(), T.detach(), Wc.detach(), P=6 * pairs + ba.K, pairs=pairs)
         saved = []
+        sws = None                                     # P > ~190: the solve's matrix lives in a workspace, shared by the iterations
         for _ in range(n_iter):
             Ri, Ti, Wi = st.R.clone(), st.T.clone(), st.Wc.clone()
             AtA, Atb, absres, nvalid = ops.ba_assemble(prob, st.R, st.T, st.Wc)
-            ops.ba_solve_update(prob, mlp, ba.l2_base, AtA, Atb, absres, nvalid, st)
+            sws = ops.ba_solve_update(prob, mlp, ba.l2_base, AtA, Atb, absres, nvalid, st, sws)
             saved.append((Ri, Ti, Wi, AtA, Atb, absres))
         ctx.ba, ctx.li, ctx.saved = ba, li, saved
         ctx.layers = flat_layers

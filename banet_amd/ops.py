@@ -286,14 +286,25 @@ def ba_assemble(level, R, T, Wc=None):
     return AtA, Atb, absres, nvalid
 
 
-def ba_solve_update(level, mlp, l2_base, AtA, Atb, absres, nvalid, state):
-    """banet_ba_solve_update_f32: lambda, damping, solve, SE(3)/W update (in place on `state`)."""
+def ba_solve_update(level, mlp, l2_base, AtA, Atb, absres, nvalid, state, ws=None):
+    """banet_ba_solve_update_f32: lambda, damping, solve, SE(3)/W update (in place on `state`).  Systems whose matrix does
+    not fit the LDS (P > ~190) go through banet_ba_solve_update_ws_f32 with a workspace (`ws`, or one allocated here)."""
     L = capi.lib()
     if mlp is not None:
         mlp.check(level.C)
-    capi.check(L.banet_ba_solve_update_f32(ctypes.byref(level.c), ctypes.byref(mlp.c) if mlp is not None else None,
-                                           float(l2_base), capi.ptr(AtA), capi.ptr(Atb), capi.ptr(absres),
-                                           capi.ptr(nvalid), ctypes.byref(state.c), capi.stream()))
+    nb = L.banet_ba_solve_update_workspace_bytes(ctypes.byref(level.c))
+    if nb == 0:
+        capi.check(L.banet_ba_solve_update_f32(ctypes.byref(level.c), ctypes.byref(mlp.c) if mlp is not None else None,
+                                               float(l2_base), capi.ptr(AtA), capi.ptr(Atb), capi.ptr(absres),
+                                               capi.ptr(nvalid), ctypes.byref(state.c), capi.stream()))
+        return None
+    if ws is None or ws.numel() < nb:
+        ws = capi.workspace(nb, level.device)
+    capi.check(L.banet_ba_solve_update_ws_f32(ctypes.byref(level.c), ctypes.byref(mlp.c) if mlp is not None else None,
+                                              float(l2_base), capi.ptr(AtA), capi.ptr(Atb), capi.ptr(absres),
+                                              capi.ptr(nvalid), ctypes.byref(state.c), ctypes.c_void_p(ws.data_ptr()),
+                                              ws.numel(), capi.stream()))
+    return ws
 
 
 def lm_level(level, mlp, l2_base, max_iters, early_termination, state, ws=None, params=None):

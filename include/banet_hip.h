@@ -92,9 +92,9 @@ typedef struct banet_level {
   int32_t N;            /* points per window                                              */
   int32_t C;            /* feature channels (C <= 256)                                    */
   int32_t K;            /* depth-basis coefficients; 0 for the pose-only variants; <= 256
-                           (P = 6 pairs + K > ~190: the solve keeps its matrix in the workspace
-                           of banet_lm_level_f32; banet_ba_solve_update_f32 alone then returns
-                           BANET_ERR_UNSUPPORTED)                                          */
+                           (P = 6 pairs + K > ~190: the solve keeps its matrix in a workspace:
+                           banet_lm_level_f32's, or banet_ba_solve_update_ws_f32's;
+                           banet_ba_solve_update_f32 alone then returns BANET_ERR_UNSUPPORTED) */
   int32_t H, W;         /* target map height / width at this level                        */
   int32_t variant;      /* BANET_LEGACY_LM ... BANET_BUNDLE                               */
   int32_t dense;        /* 1: the N = H*W points are this level's own pixel grid          */
@@ -161,6 +161,13 @@ int banet_ba_assemble_f32(const banet_level_t* lv, const float* R, const float* 
 int banet_ba_solve_update_f32(const banet_level_t* lv, const banet_mlp_t* mlp, float l2_base,
                               const float* AtA, const float* Atb, const float* absres,
                               const float* nvalid, banet_state_t* st, banet_stream_t stream);
+/*     The same with a caller workspace for the systems whose matrix does not fit the LDS
+ *     (P > ~190, e.g. K = 256): workspace_bytes = 0 means (4) alone is enough (ws may be NULL). */
+size_t banet_ba_solve_update_workspace_bytes(const banet_level_t* lv);
+int banet_ba_solve_update_ws_f32(const banet_level_t* lv, const banet_mlp_t* mlp, float l2_base,
+                                 const float* AtA, const float* Atb, const float* absres,
+                                 const float* nvalid, banet_state_t* st, void* ws, size_t ws_bytes,
+                                 banet_stream_t stream);
 
 /* (5) the LM loop at one level, entirely enqueued (no host sync): max_iters iterations of
  *     (3)+(4).  For BANET_LEGACY_LM with early_termination != 0 the accept/reject test and

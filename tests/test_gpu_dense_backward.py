@@ -263,13 +263,30 @@ def test_solve_differentiable_multi_frame_windows_match_oracle_finite_difference
         assert torch.equal(x.grad, x.grad_first)
 
 
+def _avoid_abs_kinks(intr, lv, R, T, Wc, camera=False):
+    """|d| is not differentiable at d = 0 and float32 / float64 may land on different sides of it (one such entry moves dsrc by
+    2 |gabs|): nudge the source features of the few entries whose float64 residual is below 1e-5 away from the kink."""
+    f32 = lambda v: np.asarray(v, np.float32).astype(np.float64)
+    lv64 = {k: (f32(v) if isinstance(v, np.ndarray) else v) for k, v in lv.items()}
+    a = odense.level_inputs(intr, lv64, True, np.float64)
+    if camera:
+        a["Bs"] = np.zeros(a["Bs"].shape[:2] + (0,))
+    F = oadj.forward_lean(a, lv64["tgt"], f32(R), f32(T), f32(Wc))
+    near = (np.abs(F["diff"]) < 1e-5) & F["mask"][..., None]
+    lv = dict(lv)
+    src = np.array(lv["src"], np.float32)
+    src.reshape(near.shape)[near] += 1e-3
+    lv["src"] = src
+    return lv
+
+
 @pytest.mark.parametrize("H,W,C,K,seed", [(20, 24, 8, 136, 3), (20, 24, 128, 256, 5), (18, 22, 70, 200, 7), (16, 20, 256, 192, 9),
-                                          (17, 19, 12, 255, 4)])
+                                          (17, 19, 12, 255, 4), (16, 20, 200, 192, 9), (16, 20, 130, 192, 9), (16, 20, 66, 250, 9)])
 def test_dense_adjoint_kernels_with_more_than_128_depth_coefficients(H, W, C, K, seed):
     """Round 3: 128 < K <= 256 (cfg-5's K = 256) -- the seed block of the GEMM-shaped piece no longer fits the LDS and is taken
     in column chunks (adj_basis_wide_kernel), the per-pixel kernel runs with 3-4 coefficients per lane."""
     intr, levels, R, T, Wc, rng = _scene(H, W, C, K, seed)
-    lv = levels[0]
+    lv = _avoid_abs_kinks(intr, levels[0], R, T, Wc)
     B, P = 2, 6 + K
     G = rng.standard_normal((B, P, P))
     gb = rng.standard_normal((B, P, 1))
@@ -301,7 +318,7 @@ def test_pose_only_adjoint_kernels_match_the_float64_statement(H, W, C, seed):
     """Round 3: the pose-only variant (BANET_BUNDLE_CAMERA, bundlenet.py:122-191) through banet_dense_adjoint_f32: K = 0, no
     basis / coefficient pointers, dpose [B,12]."""
     intr, levels, R, T, _, rng = _scene(H, W, C, 4, seed)
-    lv = levels[0]
+    lv = _avoid_abs_kinks(intr, levels[0], R, T, np.zeros((2, 0, 1)), camera=True)
     B = 2
     G = rng.standard_normal((B, 6, 6))
     gb = rng.standard_normal((B, 6, 1))
