@@ -13,6 +13,8 @@
 // 144 < P <= 272 (17 column blocks) runs the same engine as four jobs -- two diagonal groups and two off-diagonal
 // rectangles, four passes over J.  The previous kernel (eq_construction_kernel, eqcon.hip: J tile in LDS, every fp32-MFMA
 // operand fetched from LDS, two barriers per 32 pixels) stays behind BANET_EQ_LDS_KERNEL=1 for A/B.
+#include <cstdlib>
+
 #include "kernels.hpp"
 #include "syrk_split.hpp"
 
@@ -288,6 +290,217 @@ __global__ __launch_bounds__(kBlock, 1) void eq_syrk_kernel(const EqSyrkArgs a) 
   }
 }
 
+// ---- 144 < P <= 272 in ONE pass over J -----------------------------------------------------------------------------------
+// The 17 x 17 block triangle (+ the record block row) does not fit one wave's accumulators, so it is cut into four jobs:
+// sym(0..8), sym(9..16), rect(0..4 x 9..16), rect(5..8 x 9..16).  Run as four launches each job reads J again and splits the
+// columns it needs again (42 column-block splits per step for 17 distinct ones) and the op runs at the fabric's rate on 2.7 x its
+// bytes (0.23 of the roofline: profiles/r02_run9_eqcon_op.txt).  Here the four jobs are the four WAVES of a workgroup (one per
+// SIMD, up to 512 registers each) working on the same 16 pixels per step:
+//   split   every wave takes a few of the 18 operand blocks (17 column blocks + the record row): loads its columns of J one
+//           step ahead into registers, weights (w = L^T J), splits and writes the bf16 triples to LDS (3 KB per block, two
+//           buffers) -- each block is loaded and split ONCE per step, the jobs with fewer tiles take more blocks;
+//   MFMA    every wave reads the operand blocks of its job into registers (42 x 3 KB per step and workgroup: ~1 k LDS cycles
+//           against ~5 k matrix-pipe cycles) and runs its tiles; accumulators stay in registers for the whole range and are
+//           published straight from them (every entry of the partial is owned by exactly one job).
+// One barrier per step: [barrier] operands(st) -> registers, split(st + 1) -> the other buffer, request rows(st + 2), MFMAs(st).
+#ifndef BANET_EQ4_EXP
+#define BANET_EQ4_EXP 0
+#endif
+constexpr int kEq4Blocks = 18;                                      // 17 column blocks of J + the record block row
+constexpr int kEq4OpVecs = kEq4Blocks * 3 * 64;                     // one step's operands: [block][piece][lane] of 16 B
+constexpr int kEq4LdsBytes = 2 * kEq4OpVecs * 16;
+
+// Job = the tiles one wave owns: SYM: the upper triangle of column blocks cb0 .. cb0 + NBC - 1; !SYM: the rectangle of row blocks
+// rb0 .. x column blocks cb0 ..; plus NU tiles of the record block row (Atb): UKIND 1 = over the job's column blocks U0 .. U0 + NU - 1,
+// UKIND 2 = over its ROW blocks (a rectangle holds those as operands too).  The wave also splits operand blocks S0 .. S0 + NS - 1.
+template <int NBR, int NBC, bool SYM, int S0, int NS, int UKIND, int U0, int NU>
+__device__ __forceinline__ void eq_syrk4_job(const EqSyrkArgs& a, int rb0, int cb0, u32x4_t* __restrict__ sOp) {
+  constexpr int NPAIR = SYM ? NBC * (NBC + 1) / 2 : NBR * NBC;
+  constexpr int NR = SYM ? 0 : NBR;
+  constexpr int kRec = 17;
+  static_assert(UKIND == 0 || (UKIND == 1 && U0 + NU <= NBC) || (UKIND == 2 && !SYM && U0 + NU <= NBR), "record tiles out of range");
+  const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x & 63;
+  const int N = a.N, P = a.P;
+  const int m = lane & 15, kq = lane >> 4;
+  const float* __restrict__ J_b = a.J + (size_t)b * N * 2 * P;
+  const float* __restrict__ rec_b = a.rec + (size_t)b * N * 8;
+  // this lane's column of every block it splits; columns >= P take column 0: their operands are finite and only reach entries
+  // of the partial that are never published (a tile entry depends on one column of each of its two blocks)
+  int colc[NS];
+#pragma unroll
+  for (int sb = 0; sb < NS; ++sb) colc[sb] = ((S0 + sb) < kRec && 16 * (S0 + sb) + m < P) ? 16 * (S0 + sb) + m : 0;
+  f32x4 acc[NPAIR];
+  f32x4 acu[NU ? NU : 1];
+#pragma unroll
+  for (int q = 0; q < NPAIR; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < (NU ? NU : 1); ++q) acu[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int ns = (N + 15) >> 4;   // 16-pixel steps; the workgroup's range, the same for its four waves
+  const int s0 = (int)(((long long)ns * g) / a.Gr), s1 = (int)(((long long)ns * (g + 1)) / a.Gr);
+  struct Rec5 {   // the five used floats of a pixel's record
+    f32x4 a;
+    float h1;
+  };
+  float pj[8][NS];
+  Rec5 pr[4];
+  auto issue = [&](int st) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const size_t n = (size_t)min(16 * st + 4 * kq + q, N - 1);   // clamped: the prefetch past the last step reads valid memory
+      pr[q].a = *reinterpret_cast<const f32x4*>(rec_b + n * 8);
+      pr[q].h1 = rec_b[n * 8 + 4];
+      const float* r0 = J_b + n * 2 * P;
+#pragma unroll
+      for (int sb = 0; sb < NS; ++sb) {
+        pj[2 * q][sb] = r0[colc[sb]];
+        pj[2 * q + 1][sb] = r0[P + colc[sb]];
+      }
+    }
+  };
+  auto split = [&](int st) __attribute__((always_inline)) {       // the prefetched rows of step st -> operand buffer (st - s0) & 1
+    u32x4_t* __restrict__ buf = sOp + (size_t)((st - s0) & 1) * kEq4OpVecs;
+    float l11[4], l21[4], l22[4], ut[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool ok = 16 * st + 4 * kq + q < N;       // rows of pixels past N: all-zero
+      l11[q] = ok ? pr[q].a[0] : 0.f;
+      l21[q] = ok ? pr[q].a[1] : 0.f;
+      l22[q] = ok ? pr[q].a[2] : 0.f;
+      ut[2 * q] = (ok && m == 0) ? pr[q].a[3] : 0.f;  // A-operand row 0 of the record block row = h
+      ut[2 * q + 1] = (ok && m == 0) ? pr[q].h1 : 0.f;
+    }
+#pragma unroll
+    for (int sb = 0; sb < NS; ++sb) {
+      float vv[8];
+      if (S0 + sb == kRec) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vv[e] = ut[e];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          vv[2 * q] = fmaf(l11[q], pj[2 * q][sb], l21[q] * pj[2 * q + 1][sb]);
+          vv[2 * q + 1] = l22[q] * pj[2 * q + 1][sb];
+        }
+      }
+      u32x4_t t[3];
+#if BANET_EQ4_EXP == 2
+      t[0] = t[1] = t[2] = u32x4_t{(unsigned)__float_as_uint(vv[0]), 0u, 0u, 0u};
+#else
+      split8_bf16x3(vv, t);
+#endif
+#pragma unroll
+      for (int p = 0; p < 3; ++p) buf[((S0 + sb) * 3 + p) * 64 + lane] = t[p];
+    }
+  };
+  issue(s0);
+  split(s0);
+  issue(s0 + 1);
+  for (int st = s0; st < s1; ++st) {
+    const u32x4_t* __restrict__ buf = sOp + (size_t)((st - s0) & 1) * kEq4OpVecs;
+    // step st's operands are complete; every wave has finished reading the other buffer (step st - 1's)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    u32x4_t op[NBC][3], opr[NR ? NR : 1][3], opu[3];
+#pragma unroll
+    for (int bi = 0; bi < NBC; ++bi)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) op[bi][p] = buf[((cb0 + bi) * 3 + p) * 64 + lane];
+#pragma unroll
+    for (int bi = 0; bi < NR; ++bi)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) opr[bi][p] = buf[((rb0 + bi) * 3 + p) * 64 + lane];
+    if constexpr (NU > 0) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) opu[p] = buf[(kRec * 3 + p) * 64 + lane];
+    }
+    // the split of step st + 1 FIRST (its VALU work covers the latency of the operand reads above), then the request for the rows
+    // of step st + 2: they have the whole MFMA phase to arrive.  (A second register set to request them a block earlier does not
+    // fit beside 54 accumulator tiles; interleaving the split into the MFMA stream by sched_group_barrier: +3 %, spills with it.)
+    split(st + 1);      // past the range: the clamped prefetch, written to the other buffer and never read
+    issue(st + 2);
+    __builtin_amdgcn_sched_barrier(0);
+#if BANET_EQ4_EXP == 1
+#pragma unroll
+    for (int bi = 0; bi < NBC; ++bi) acc[bi][0] += __uint_as_float(op[bi][0][0] ^ op[bi][1][1] ^ op[bi][2][2]);
+    if (false)
+#endif
+    {
+#pragma unroll
+      for (int j = 0; j < NU; ++j) acu[j] = mm6e(opu, UKIND == 2 ? opr[U0 + j] : op[U0 + j], acu[j]);
+      if constexpr (SYM) {
+        int idx = 0;
+#pragma unroll
+        for (int bi = 0; bi < NBC; ++bi)
+#pragma unroll
+          for (int bj = bi; bj < NBC; ++bj) {
+            acc[idx] = mm6e(op[bi], op[bj], acc[idx]);
+            ++idx;
+          }
+      } else {
+#pragma unroll
+        for (int bi = 0; bi < NR; ++bi)
+#pragma unroll
+          for (int bj = 0; bj < NBC; ++bj) acc[bi * NBC + bj] = mm6e(opr[bi], op[bj], acc[bi * NBC + bj]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // ---- publish: accumulator layout = lane (m, kq) holds rows 4 kq + v (v = 0..3) of column m
+  float* __restrict__ part = a.partials + ((size_t)b * a.Gr + g) * a.pstride;
+  if (kq == 0) {
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+      const int cc = 16 * ((UKIND == 2 ? rb0 : cb0) + U0 + j) + m;
+      if (cc < P) part[P * P + cc] = acu[j][0];
+    }
+  }
+  if constexpr (SYM) {
+    int idx = 0;
+#pragma unroll
+    for (int bi = 0; bi < NBC; ++bi)
+#pragma unroll
+      for (int bj = bi; bj < NBC; ++bj) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int rr = 16 * (cb0 + bi) + 4 * kq + v, cc = 16 * (cb0 + bj) + m;
+          if (rr < P && cc < P && (bj > bi || rr <= cc)) {
+            part[rr * P + cc] = acc[idx][v];
+            part[cc * P + rr] = acc[idx][v];
+          }
+        }
+        ++idx;
+      }
+  } else {
+#pragma unroll
+    for (int bi = 0; bi < NR; ++bi)
+#pragma unroll
+      for (int bj = 0; bj < NBC; ++bj)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int rr = 16 * (rb0 + bi) + 4 * kq + v, cc = 16 * (cb0 + bj) + m;
+          if (rr < P && cc < P) {
+            part[rr * P + cc] = acc[bi * NBC + bj][v];
+            part[cc * P + rr] = acc[bi * NBC + bj][v];
+          }
+        }
+  }
+}
+
+__global__ __launch_bounds__(kBlock, 1) void eq_syrk4_kernel(const EqSyrkArgs a) {
+  extern __shared__ u32x4_t sEq4[];
+  const int w = wave_id();
+  // tiles per wave 49 / 36 / 45 / 40 (the 17 record tiles are spread so that no wave has more than 49 of the 170), operand
+  // blocks split per wave 2 / 6 / 4 / 6: a tile costs 6 MFMAs = ~100 cycles, a block ~75 instructions of a single wave = ~300
+  if (w == 0)
+    eq_syrk4_job<9, 9, true, 0, 2, 1, 5, 4>(a, 0, 0, sEq4);        // sym(0..8) + record tiles of blocks 5..8
+  else if (w == 1)
+    eq_syrk4_job<8, 8, true, 2, 6, 0, 0, 0>(a, 9, 9, sEq4);        // sym(9..16)
+  else if (w == 2)
+    eq_syrk4_job<5, 8, false, 8, 4, 2, 0, 5>(a, 0, 9, sEq4);       // rect(0..4 x 9..16) + record tiles of blocks 0..4
+  else
+    eq_syrk4_job<4, 8, false, 12, 6, 1, 0, 8>(a, 5, 9, sEq4);      // rect(5..8 x 9..16) + record tiles of blocks 9..16
+}
+
 void launch_eq_pixel_records(const float* G, const float* d, int B, int N, int C, int raw, float* rec, hipStream_t s) {
   hipLaunchKernelGGL(eq_pixel_records_kernel, dim3((N + 31) / 32, B), dim3(kBlock), 0, s, G, d, N, C, raw, rec);
 }
@@ -305,7 +518,14 @@ int launch_eq_syrk(const float* J, const float* G, const float* d, int B, int N,
     case 3: hipLaunchKernelGGL((eq_syrk_kernel<3, 3, true>), grid, block, 0, s, a); break;
     case 5: hipLaunchKernelGGL((eq_syrk_kernel<5, 5, true>), grid, block, 0, s, a); break;
     case 9: hipLaunchKernelGGL((eq_syrk_kernel<9, 9, true>), grid, block, 0, s, a); break;
-    case 17: {   // 144 < P <= 272: four jobs (see eq_syrk_kernel)
+    case 17: {   // 144 < P <= 272: four jobs, side by side in one launch (BANET_EQ_FOUR_PASS=1: one launch each, for A/B)
+      static const bool four_pass = getenv("BANET_EQ_FOUR_PASS") != nullptr && getenv("BANET_EQ_FOUR_PASS")[0] == '1';
+      if (!four_pass) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&eq_syrk4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  kEq4LdsBytes);
+        hipLaunchKernelGGL(eq_syrk4_kernel, grid, block, kEq4LdsBytes, s, a);
+        break;
+      }
       hipLaunchKernelGGL((eq_syrk_kernel<9, 9, true>), grid, block, 0, s, a);
       a.rb0 = a.cb0 = 9;
       hipLaunchKernelGGL((eq_syrk_kernel<8, 8, true>), grid, block, 0, s, a);
