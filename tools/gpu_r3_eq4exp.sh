@@ -8,5 +8,5 @@ for m in 0 1 2; do
   BANET_HIP_LIB=$lib timeout 300 python tools/bench_eqcon.py 2>&1 | grep "^B=" | tee -a $OUT/exp.log
 done
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -- python $GRAFT_REPO_ROOT/tools/bench_eqcon.py > /dev/null 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/eq4prof -o eq -- python $GRAFT_REPO_ROOT/tools/bench_eqcon.py > /dev/null 2>&1   # (without the timeout this line once ran into the call's limit)
 cd $GRAFT_REPO_ROOT; f=$(ls $OUT/prof/*/*kernel_stats.csv | head -1); head -8 $f | cut -c1-200 | tee -a $OUT/exp.log
