@@ -51,7 +51,7 @@ for c in cases_strip:
         print("strip gather case", c, "FAILED")
         traceback.print_exc(limit=2)
 print("strip gather cases %s: %d failures so far" % (cases_strip, bad))
-cases_eq = [(int(rng.randint(1, 4)), int(rng.randint(1, 700)), int(rng.choice([1, 3, 8, 64, 128, 200])), int(rng.choice([6, 7, 12, 38, 70, 134, 143, 144, 145, 160])))
+cases_eq = [(int(rng.randint(1, 4)), int(rng.randint(1, 700)), int(rng.choice([1, 3, 8, 64, 128, 200])), int(rng.choice([6, 7, 12, 38, 70, 134, 143, 144, 145, 160, 199, 200, 255, 262, 271, 272])))
             for _ in range(max(4, count // 4))]
 for c in cases_eq:
     for fn in (T.test_equation_construction_matches_oracle, T.test_equation_construction_grad_matches_oracle):
