@@ -27,11 +27,13 @@
 #include <algorithm>
 
 #include "kernels.hpp"
+#include "syrk_split.hpp"
 
 namespace banet {
 
 namespace {
 
+typedef __bf16 bf16x8a __attribute__((ext_vector_type(8)));
 constexpr int kAdjMaxCJ = 4;    // C <= 256
 constexpr int kAdjMaxKJ = 4;    // K <= 256 (K <= 128: adj_basis_kernel keeps the whole K x (K+16) seed block in LDS; above: column chunks)
 constexpr int kAdjHdr = 16;     // partial row: dR (9), dT (3), pad, then dWc (K)
@@ -149,6 +151,129 @@ __global__ __launch_bounds__(kBlock, 2) void adj_basis_kernel(const AdjArgs a) {
         if (i < 6) arec[(size_t)nn * 8 + i] = acc[NK][v];
         if (i == 6) arec[(size_t)nn * 8 + 7] = acc[NK][v];
         if (i == 7) arec[(size_t)nn * 8 + 6] = zt;
+      }
+    }
+  }
+}
+
+// The same GEMM on the bf16 matrix pipe at fp32 accuracy (K <= 128): both operands are split exactly into three bf16 pieces and
+// each 16 x 16 x 32 block takes six v_mfma_f32_16x16x32_bf16 (products exact in fp32, fp32 accumulate, the three terms below
+// fp32 rounding dropped -- the scheme of syrk.hip / eqcon_grad.hip): 6 x 17 cycles against 8 x 32 for v_mfma_f32_16x16x4_f32.
+// The seed block is split ONCE per workgroup into LDS as MFMA B operands ([k step][column block][piece][lane], 3 KB per block and
+// k step: 108 KB at K = 128); a wave takes 16 pixels at a time: lane (m, kq) loads the 8 coefficients 32 ks + 8 kq .. + 7 of pixel
+// m (32 contiguous bytes; the four kq lanes of a pixel read 128), splits them (registers) and accumulates.  512 threads: two
+// waves per SIMD.  Epilogue as adj_basis_kernel (same accumulator layout).  reserved_ bit 26 keeps the fp32-MFMA kernel (A/B).
+constexpr int kAdjB6Threads = 512, kAdjB6Waves = kAdjB6Threads / 64;
+template <int NK>   // KP = 16 NK >= K, NK <= 8
+__global__ __launch_bounds__(kAdjB6Threads) void adj_basis6_kernel(const AdjArgs a) {
+  constexpr int KS = (NK + 1) / 2, NB = NK + 1, KP = 16 * NK;
+  extern __shared__ __attribute__((aligned(16))) unsigned sB6[];   // [KS][NB][3][64] quads
+  const int b = blockIdx.y, K = a.lv.K, N = a.lv.N, P = 6 + K;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, kq = lane >> 4;
+  {
+    const float* __restrict__ S = a.S + (size_t)b * P * P;
+    const float* __restrict__ gb = a.gb + (size_t)b * P;
+    for (int task = w; task < KS * NB; task += kAdjB6Waves) {
+      const int ks = task / NB, jb = task - ks * NB;
+      float vv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = 32 * ks + 8 * kq + e, j = 16 * jb + m;     // seed[k][j], the layout of adj_basis_kernel's Wl
+        float v = 0.f;
+        if (k < K) {
+          if (j < K)
+            v = S[(size_t)(6 + k) * P + 6 + j];
+          else if (j >= KP && j < KP + 6)
+            v = S[(size_t)(j - KP) * P + 6 + k];
+          else if (j == KP + 6)
+            v = gb[6 + k];
+        }
+        vv[e] = v;
+      }
+      u32x4_t pc[3];
+      split8_bf16x3(vv, pc);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x4_t*>(&sB6[(((ks * NB + jb) * 3 + t) * 64 + lane) * 4]) = pc[t];
+    }
+  }
+  __syncthreads();
+  const float* __restrict__ bas = a.lv.basis + (size_t)b * N * K;
+  float* __restrict__ z2 = a.z2 + (size_t)b * N * K;
+  float* __restrict__ arec = a.arec + (size_t)b * N * 8;
+  const int nrb = (N + 15) >> 4;
+  const bool k8 = (K & 7) == 0;
+  auto load_a = [&](int rb, int ks, float (&v)[8]) __attribute__((always_inline)) {
+    const int n = min(rb * 16 + m, N - 1), c0 = 32 * ks + 8 * kq;
+    const float* p = bas + (size_t)n * K + c0;
+    if (k8 && c0 + 8 <= K) {
+      const f32x4 t0 = *reinterpret_cast<const f32x4*>(p), t1 = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = t0[e];
+        v[4 + e] = t1[e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (c0 + e < K) ? p[e] : 0.f;
+    }
+    if (rb * 16 + m >= N) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    }
+  };
+  for (int rb = blockIdx.x * kAdjB6Waves + w; rb < nrb; rb += gridDim.x * kAdjB6Waves) {
+    f32x4 acc[NB];
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb) acc[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float av[8], an[8];
+    load_a(rb, 0, av);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      asm volatile("" ::: "memory");   // the B operands are re-read from LDS every row block (hoisting all of them spills)
+      u32x4_t pa[3];
+      split8_bf16x3(av, pa);
+      if (ks + 1 < KS) load_a(rb, ks + 1, an);
+      constexpr int kTa[6] = {2, 0, 1, 1, 0, 0}, kTb[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
+      u32x4_t pb[NB][3];
+#pragma unroll
+      for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) pb[jb][t] = *reinterpret_cast<const u32x4_t*>(&sB6[(((ks * NB + jb) * 3 + t) * 64 + lane) * 4]);
+#pragma unroll
+      for (int t = 0; t < 6; ++t)       // term-major: consecutive MFMAs write different accumulators
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb)
+          acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8a, pa[kTa[t]]), __builtin_bit_cast(bf16x8a, pb[jb][kTb[t]]),
+                                                            acc[jb], 0, 0, 0);
+      if (ks + 1 < KS) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) av[e] = an[e];
+      }
+    }
+    // accumulator layout: lane (j = m, rq = kq) holds rows 4 rq + v, column 16 jb + j  (as adj_basis_kernel)
+    float zeta[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int nn = rb * 16 + 4 * kq + v;
+      const bool ok = nn < N;
+#pragma unroll
+      for (int jb = 0; jb < NK; ++jb) {
+        const int j = 16 * jb + m;
+        if (ok && j < K) {
+          zeta[v] = fmaf(acc[jb][v], bas[(size_t)nn * K + j], zeta[v]);
+          z2[(size_t)nn * K + j] = 2.f * acc[jb][v];
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const float zt = row16_sum(zeta[v]);
+      const int nn = rb * 16 + 4 * kq + v;
+      if (nn < N) {
+        if (m < 6) arec[(size_t)nn * 8 + m] = acc[NK][v];
+        if (m == 6) arec[(size_t)nn * 8 + 7] = acc[NK][v];
+        if (m == 7) arec[(size_t)nn * 8 + 6] = zt;
       }
     }
   }
@@ -1182,6 +1307,38 @@ __global__ void target_map_adjoint_kernel(const float* __restrict__ dmap3, float
   dimg[e] += v;
 }
 
+// C % 4 == 0: four channels per thread, 16-byte accesses; per element the same operations in the same order (identical bits)
+__global__ void target_map_adjoint4_kernel(const float* __restrict__ dmap3, float* __restrict__ dimg, int H, int W, int C4,
+                                           size_t total4) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total4) return;
+  const int c = (int)(e % C4);
+  const size_t tix = e / C4;
+  const int x = (int)(tix % W);
+  const size_t r = tix / W;
+  const int y = (int)(r % H);
+  const size_t Q3 = 3 * (size_t)C4;                      // float4 per texel of the [f|gx|gy] map
+  const float4* m = reinterpret_cast<const float4*>(dmap3) + tix * Q3;
+  float4 v = m[c];
+  auto axpy = [&](float a, const float4 t) {
+    v.x += a * t.x;
+    v.y += a * t.y;
+    v.z += a * t.z;
+    v.w += a * t.w;
+  };
+  if (x - 1 >= 1 && x - 1 <= W - 2) axpy(0.5f, (m - Q3)[C4 + c]);
+  if (x + 1 >= 1 && x + 1 <= W - 2) axpy(-0.5f, (m + Q3)[C4 + c]);
+  if (y - 1 >= 1 && y - 1 <= H - 2) axpy(0.5f, (m - (size_t)W * Q3)[2 * C4 + c]);
+  if (y + 1 >= 1 && y + 1 <= H - 2) axpy(-0.5f, (m + (size_t)W * Q3)[2 * C4 + c]);
+  float4* o = reinterpret_cast<float4*>(dimg) + e;
+  float4 d = *o;
+  d.x += v.x;
+  d.y += v.y;
+  d.z += v.z;
+  d.w += v.w;
+  *o = d;
+}
+
 // ---- the same deterministic gather for the reference-layout adjoint (sparse points, [f|gx|gy] target map) ----------
 // ba_sample_stats_grad_kernel (sstats.hip) scatters its 3C-wide contributions with float atomics; this variant writes them as
 // per-point rows + (cell, fractions) records and lets adj_scan / adj_fill / adj_map_kernel gather them per texel in a fixed
@@ -1343,6 +1500,15 @@ void launch_adj_basis(const AdjArgs& a, int Ga, hipStream_t s) {
 }
 
 template <int NK>
+void launch_adj_basis6(const AdjArgs& a, int Ga, hipStream_t s) {
+  constexpr int KS = (NK + 1) / 2, NB = NK + 1;
+  const size_t shm = (size_t)KS * NB * 3 * 64 * 16;
+  if (shm > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&adj_basis6_kernel<NK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+  hipLaunchKernelGGL((adj_basis6_kernel<NK>), dim3(std::max(1, Ga / 2), a.lv.B), dim3(kAdjB6Threads), shm, s, a);
+}
+
+template <int NK>
 void launch_adj_basis_wide(const AdjArgs& a, int Ga, hipStream_t s) {
   constexpr int NBC = 6, KP = 16 * NK, LSC = 16 * NBC + 20;
   const size_t shm = (size_t)KP * LSC * sizeof(float);
@@ -1395,15 +1561,16 @@ int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T
   const size_t tot = (size_t)B * P * P;
   hipLaunchKernelGGL(adj_sym_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, gAtA, S, P, tot);
   if (hipMemsetAsync(a.cnt, 0, (size_t)B * HW * sizeof(int), s) != hipSuccess) return BANET_ERR_LAUNCH;
+  const bool b6 = !(lv->reserved_ & (1 << 26));   // the bf16x6 form of the GEMM-shaped piece (bit 26: fp32 MFMA, A/B)
   switch ((K + 15) / 16) {
     case 1: launch_adj_basis<1>(a, pl.Ga, s); break;
-    case 2: launch_adj_basis<2>(a, pl.Ga, s); break;
-    case 3: launch_adj_basis<3>(a, pl.Ga, s); break;
-    case 4: launch_adj_basis<4>(a, pl.Ga, s); break;
-    case 5: launch_adj_basis<5>(a, pl.Ga, s); break;
-    case 6: launch_adj_basis<6>(a, pl.Ga, s); break;
-    case 7: launch_adj_basis<7>(a, pl.Ga, s); break;
-    case 8: launch_adj_basis<8>(a, pl.Ga, s); break;
+    case 2: b6 ? launch_adj_basis6<2>(a, pl.Ga, s) : launch_adj_basis<2>(a, pl.Ga, s); break;
+    case 3: b6 ? launch_adj_basis6<3>(a, pl.Ga, s) : launch_adj_basis<3>(a, pl.Ga, s); break;
+    case 4: b6 ? launch_adj_basis6<4>(a, pl.Ga, s) : launch_adj_basis<4>(a, pl.Ga, s); break;
+    case 5: b6 ? launch_adj_basis6<5>(a, pl.Ga, s) : launch_adj_basis<5>(a, pl.Ga, s); break;
+    case 6: b6 ? launch_adj_basis6<6>(a, pl.Ga, s) : launch_adj_basis<6>(a, pl.Ga, s); break;
+    case 7: b6 ? launch_adj_basis6<7>(a, pl.Ga, s) : launch_adj_basis<7>(a, pl.Ga, s); break;
+    case 8: b6 ? launch_adj_basis6<8>(a, pl.Ga, s) : launch_adj_basis<8>(a, pl.Ga, s); break;
     case 9: case 10: case 11: case 12: launch_adj_basis_wide<12>(a, pl.Ga, s); break;
     case 13: case 14: case 15: case 16: launch_adj_basis_wide<16>(a, pl.Ga, s); break;
     case 0:   // pose only: no depth block -> q = zeta = e = 0; the pixel kernels read (never use) one basis / z2 element
@@ -1516,6 +1683,12 @@ int launch_sample_stats_grad_det(const float* conv1, const float* conv2, const f
 int launch_target_map_adjoint(const float* dmap3, float* dimg, int B, int H, int W, int C, hipStream_t s) {
   const size_t total = (size_t)B * H * W * C;
   if (total == 0) return BANET_OK;
+  if ((C & 3) == 0 && ((reinterpret_cast<uintptr_t>(dmap3) | reinterpret_cast<uintptr_t>(dimg)) & 15) == 0) {
+    const size_t total4 = total / 4;
+    hipLaunchKernelGGL(target_map_adjoint4_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, dmap3, dimg, H, W, C / 4,
+                       total4);
+    return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;
+  }
   hipLaunchKernelGGL(target_map_adjoint_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dmap3, dimg, H, W, C, total);
   return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;
 }
