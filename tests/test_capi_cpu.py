@@ -236,6 +236,23 @@ def test_backward_entry_points_validate_their_arguments_without_gpu(capi):
     assert L.banet_spd_solve_f32(buf, buf, buf, 1, 8, None) == -3 and L.banet_spd_solve_f32(buf, buf, buf, 1, 400, None) == -3
 
 
+def test_solve_update_workspace_query_without_gpu(capi):
+    """banet_ba_solve_update_workspace_bytes: 0 while the damped system fits the LDS (banet_ba_solve_update_f32 alone is enough),
+    the matrix's size beyond that (K = 256 levels: banet_ba_solve_update_ws_f32); argument validation on the host."""
+    L = capi.lib()
+    lv = capi.Level()
+    lv.B, lv.N, lv.C, lv.K, lv.H, lv.W = 8, 1280 * 960, 128, 128, 960, 1280
+    lv.variant, lv.dense, lv.scale, lv.pairs = capi.BUNDLE, 1, 1.0, 1
+    assert L.banet_ba_solve_update_workspace_bytes(ctypes.byref(lv)) == 0             # P = 134
+    lv.K = 256
+    nb = L.banet_ba_solve_update_workspace_bytes(ctypes.byref(lv))                        # P = 262
+    assert nb >= 8 * 262 * 262 * 4 and nb % 256 == 0
+    lv.pairs = 7                                                                         # cfg-5: P = 298
+    assert L.banet_ba_solve_update_workspace_bytes(ctypes.byref(lv)) > nb
+    assert L.banet_ba_solve_update_workspace_bytes(None) == 0
+    assert L.banet_ba_solve_update_ws_f32(ctypes.byref(lv), None, 1000.0, None, None, None, None, None, None, 0, None) == -1
+
+
 def test_bench_roofline_record_arithmetic():
     """bench.py's roofline object: the HBM side (algorithmic bytes / gather time) and the matrix-core side of the SYRK
     (algorithmic fp32 flops and executed bf16 MFMA flops / SYRK time) from a synthetic launch profile."""
