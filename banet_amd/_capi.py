@@ -83,6 +83,7 @@ EXPORTS = {
     "banet_spd_solve_f32": (ctypes.c_int, [_FP] * 3 + [ctypes.c_int] * 2 + [_FP]),
     "banet_dense_adjoint_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Level)]),
     "banet_dense_adjoint_f32": (ctypes.c_int, [ctypes.POINTER(Level)] + [_FP] * 11 + [_FP, ctypes.c_size_t, _FP]),
+    "banet_dense_adjoint_ex_f32": (ctypes.c_int, [ctypes.POINTER(Level)] + [_FP] * 11 + [ctypes.c_int, _FP, ctypes.c_size_t, _FP]),
     "banet_target_map_adjoint_f32": (ctypes.c_int, [_FP] * 2 + [ctypes.c_int] * 4 + [_FP]),
     "banet_build_id": (ctypes.c_char_p, []),
     "banet_gather_selection": (ctypes.c_int, [_FP]),

@@ -62,6 +62,7 @@ struct AdjArgs {
   float* dbasis;
   float* dmap3;
   float* dpose;
+  int overwrite;      // 1: dsrc / dmap3 / ddepth / dbasis are WRITTEN (every entry, zeros where nothing contributes) instead of accumulated
 };
 
 __global__ void adj_sym_kernel(const float* __restrict__ g, float* __restrict__ S, int P, size_t total) {
@@ -476,6 +477,15 @@ __global__ __launch_bounds__(kBlock, (KJ >= 3 ? 2 : 3)) void adj_pixel_kernel(co
     float* __restrict__ fr = a.frac + ((size_t)b * N + n) * 4;
     if (!m) {   // wave-uniform: no contribution to anything (M = g = 0)
       if (lane == 0) fr[0] = __int_as_float(-1);
+      if (a.overwrite) {   // nothing was zero-filled: this pixel's rows are written here
+#pragma unroll
+        for (int j = 0; j < CJ; ++j)
+          if (cok[j]) a.dsrc[((size_t)b * N + n) * C + lane + 64 * j] = 0.f;
+#pragma unroll
+        for (int j = 0; j < KJ; ++j)
+          if (kok[j]) a.dbasis[((size_t)b * N + n) * K + lane + 64 * j] = 0.f;
+        if (lane == 0) a.ddepth[(size_t)b * N + n] = 0.f;
+      }
       continue;
     }
     const float xf = floorf(px), yf = floorf(py);
@@ -607,7 +617,7 @@ __global__ __launch_bounds__(kBlock, (KJ >= 3 ? 2 : 3)) void adj_pixel_kernel(co
         const float dd = dg1 * gx + dg2 * gy + sgn * ga[j];
         const float dgx = 2.f * (dM11 * gx + dM12 * gy) + dg1 * d;
         const float dgy = 2.f * (dM12 * gx + dM22 * gy) + dg2 * d;
-        dsrc_n[c] += dd;
+        dsrc_n[c] = a.overwrite ? dd : dsrc_n[c] + dd;
         arow_n[c] = -dd;
         arow_n[C + c] = dgx;
         arow_n[2 * C + c] = dgy;
@@ -653,12 +663,12 @@ __global__ __launch_bounds__(kBlock, (KJ >= 3 ? 2 : 3)) void adj_pixel_kernel(co
 #pragma unroll
         for (int i = 0; i < 6; ++i) su = fmaf(u[i], scd[j][i], su);
         v = fmaf(2.f, su, v);
-        dbas_n[k] += v;
+        dbas_n[k] = a.overwrite ? v : dbas_n[k] + v;
         dwc[j] = fmaf(dD, bv[j], dwc[j]);
       }
     }
     if (lane == 0) {
-      a.ddepth[(size_t)b * N + n] += dD;
+      a.ddepth[(size_t)b * N + n] = a.overwrite ? dD : a.ddepth[(size_t)b * N + n] + dD;
       const int key = y0 * W + x0;
       fr[0] = __int_as_float(key);
       fr[1] = ax;
@@ -925,9 +935,10 @@ __global__ __launch_bounds__(kBlock, 2) void adj_pixel2_kernel(const AdjArgs a) 
           dpx += -dd[e] * Ax[j][0][e] + dgx[e] * Ax[j][1][e] + dgy[e] * Ax[j][2][e];
           dpy += -dd[e] * Ay[j][0][e] + dgx[e] * Ay[j][1][e] + dgy[e] * Ay[j][2][e];
         }
+        if (a.overwrite && live && !m) *reinterpret_cast<f32x4*>(dsrc_n + 128 * j) = f32x4{0.f, 0.f, 0.f, 0.f};
         if (m) {
           f32x4* ds = reinterpret_cast<f32x4*>(dsrc_n + 128 * j);
-          *ds = *ds + dd;
+          *ds = a.overwrite ? dd : *ds + dd;
           *reinterpret_cast<f32x4*>(arow_n + 128 * j) = -dd;
           *reinterpret_cast<f32x4*>(arow_n + C + 128 * j) = dgx;
           *reinterpret_cast<f32x4*>(arow_n + 2 * C + 128 * j) = dgy;
@@ -974,12 +985,15 @@ __global__ __launch_bounds__(kBlock, 2) void adj_pixel2_kernel(const AdjArgs a) 
         dwc[e] = fmaf(dD, bv[e], dwc[e]);
       }
       f32x4* db = reinterpret_cast<f32x4*>(a.dbasis + q * K + k0);
-      *db = *db + v;
+      *db = a.overwrite ? v : *db + v;
+    } else if (a.overwrite && live && kok) {
+      *reinterpret_cast<f32x4*>(a.dbasis + q * K + k0) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (hl == 0 && live) {
       float* __restrict__ fr = a.frac + q * 4;
+      if (a.overwrite && !m) a.ddepth[q] = 0.f;
       if (m) {
-        a.ddepth[q] += dD;
+        a.ddepth[q] = a.overwrite ? dD : a.ddepth[q] + dD;
         const int key = y0 * W + x0;
         fr[0] = __int_as_float(key);
         fr[1] = ax;
@@ -1150,7 +1164,15 @@ __device__ __forceinline__ void adj_map_texel(const AdjArgs& a, int b, int t, in
       s0[cell] = v.x;
     }
     const int Lmax = max(max(L[0], L[1]), max(L[2], L[3]));
-    if (Lmax == 0) return;   // wave-uniform
+    if (Lmax == 0) {         // wave-uniform: nothing lands on this texel
+      if (a.overwrite) {
+        float* __restrict__ o = a.dmap3 + ((size_t)b * HW + t) * C3;
+#pragma unroll
+        for (int j = 0; j < J3; ++j)
+          if (cok[j]) o[lane + 64 * j] = 0.f;
+      }
+      return;
+    }
     float acc[J3];
 #pragma unroll
     for (int j = 0; j < J3; ++j) acc[j] = 0.f;
@@ -1198,11 +1220,11 @@ __device__ __forceinline__ void adj_map_texel(const AdjArgs& a, int b, int t, in
         }
       }
     }
-    if (any) {
+    if (any || a.overwrite) {   // (acc is all zeros when nothing contributed)
       float* __restrict__ o = a.dmap3 + ((size_t)b * HW + t) * C3;
 #pragma unroll
       for (int j = 0; j < J3; ++j)
-        if (cok[j]) o[lane + 64 * j] += acc[j];
+        if (cok[j]) o[lane + 64 * j] = a.overwrite ? acc[j] : o[lane + 64 * j] + acc[j];
     }
   }
 }
@@ -1248,7 +1270,15 @@ __global__ __launch_bounds__(kBlock) void adj_map2_kernel(const AdjArgs a) {
       if (t2 + 1 < HW) adj_map_texel<J3>(a, b, t2 + 1, lane);
       continue;
     }
-    if (!__any(Lmax == 1)) continue;
+    if (!__any(Lmax == 1)) {                     // nothing lands on either texel
+      if (a.overwrite && live) {
+        float* __restrict__ o = a.dmap3 + ((size_t)b * HW + t) * C3 + 4 * hl;
+#pragma unroll
+        for (int j = 0; j < J4; ++j)
+          if (cok[j]) *reinterpret_cast<f32x4*>(o + 128 * j) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      continue;
+    }
     int n1[4];
 #pragma unroll
     for (int cell = 0; cell < 4; ++cell) n1[cell] = list[L[cell] ? s0[cell] : 0];
@@ -1275,13 +1305,13 @@ __global__ __launch_bounds__(kBlock) void adj_map2_kernel(const AdjArgs a) {
       for (int j = 0; j < J4; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(wt[cell], wt[cell] != 0.f ? val[cell][j][e] : 0.f, acc[j][e]);
-    if (any) {
+    if (any || (a.overwrite && live)) {           // (acc is all zeros when nothing contributed)
       float* __restrict__ o = a.dmap3 + ((size_t)b * HW + t) * C3 + 4 * hl;
 #pragma unroll
       for (int j = 0; j < J4; ++j)
         if (cok[j]) {
           f32x4* op = reinterpret_cast<f32x4*>(o + 128 * j);
-          *op = *op + acc[j];
+          *op = a.overwrite ? acc[j] : *op + acc[j];
         }
     }
   }
@@ -1528,7 +1558,7 @@ size_t dense_adjoint_workspace_bytes(const banet_level_t* lv) {
 
 int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T, const float* Wc, const float* gAtA,
                          const float* gAtb, const float* gabs, float* dsrc, float* dmap3, float* ddepth, float* dbasis,
-                         float* dpose, void* ws, hipStream_t s) {
+                         float* dpose, int flags, void* ws, hipStream_t s) {
   if (!adj_supported(lv)) return BANET_ERR_UNSUPPORTED;
   AdjPlan pl;
   adj_plan(lv, &pl);
@@ -1558,6 +1588,7 @@ int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T
   a.dbasis = dbasis;
   a.dmap3 = dmap3;
   a.dpose = dpose;
+  a.overwrite = (flags & BANET_ADJOINT_OVERWRITE) ? 1 : 0;
   const size_t tot = (size_t)B * P * P;
   hipLaunchKernelGGL(adj_sym_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, gAtA, S, P, tot);
   if (hipMemsetAsync(a.cnt, 0, (size_t)B * HW * sizeof(int), s) != hipSuccess) return BANET_ERR_LAUNCH;

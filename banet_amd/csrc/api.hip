@@ -362,17 +362,24 @@ size_t banet_dense_adjoint_workspace_bytes(const banet_level_t* lv) {
   return dense_adjoint_workspace_bytes(lv);
 }
 
-int banet_dense_adjoint_f32(const banet_level_t* lv, const float* R, const float* T, const float* Wc, const float* gAtA,
-                            const float* gAtb, const float* gabs, float* dsrc, float* dmap3, float* ddepth, float* dbasis,
-                            float* dpose, void* ws, size_t ws_bytes, banet_stream_t stream) {
+int banet_dense_adjoint_ex_f32(const banet_level_t* lv, const float* R, const float* T, const float* Wc, const float* gAtA,
+                               const float* gAtb, const float* gabs, float* dsrc, float* dmap3, float* ddepth, float* dbasis,
+                               float* dpose, int flags, void* ws, size_t ws_bytes, banet_stream_t stream) {
   if (!lv || !R || !T || !gAtA || !gAtb || !gabs || !dsrc || !dmap3 || !ddepth || !dpose || !ws) return BANET_ERR_INVALID_ARG;
   if (lv->K > 0 && (!Wc || !dbasis || !lv->basis)) return BANET_ERR_INVALID_ARG;     // K = 0 (pose only): no coefficient / basis tensors
   if (lv->B <= 0 || lv->N <= 0 || !lv->src || !lv->tgt || !lv->depth || !lv->intr) return BANET_ERR_INVALID_ARG;
+  if (flags & ~BANET_ADJOINT_OVERWRITE) return BANET_ERR_INVALID_ARG;
   const size_t need = dense_adjoint_workspace_bytes(lv);
   if (need == 0) return BANET_ERR_UNSUPPORTED;
   if (ws_bytes < need || (reinterpret_cast<uintptr_t>(ws) & 255) != 0) return BANET_ERR_WORKSPACE;
-  return launch_dense_adjoint(lv, R, T, Wc, gAtA, gAtb, gabs, dsrc, dmap3, ddepth, dbasis, dpose, ws,
+  return launch_dense_adjoint(lv, R, T, Wc, gAtA, gAtb, gabs, dsrc, dmap3, ddepth, dbasis, dpose, flags, ws,
                               static_cast<hipStream_t>(stream));
+}
+
+int banet_dense_adjoint_f32(const banet_level_t* lv, const float* R, const float* T, const float* Wc, const float* gAtA,
+                            const float* gAtb, const float* gabs, float* dsrc, float* dmap3, float* ddepth, float* dbasis,
+                            float* dpose, void* ws, size_t ws_bytes, banet_stream_t stream) {
+  return banet_dense_adjoint_ex_f32(lv, R, T, Wc, gAtA, gAtb, gabs, dsrc, dmap3, ddepth, dbasis, dpose, 0, ws, ws_bytes, stream);
 }
 
 int banet_target_map_adjoint_f32(const float* dmap3, float* dimg, int B, int H, int W, int C, banet_stream_t stream) {

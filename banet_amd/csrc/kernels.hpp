@@ -160,7 +160,7 @@ int launch_sample_stats_grad(const float* conv1, const float* conv2, const float
 size_t dense_adjoint_workspace_bytes(const banet_level_t* lv);
 int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T, const float* Wc, const float* gAtA,
                          const float* gAtb, const float* gabs, float* dsrc, float* dmap3, float* ddepth, float* dbasis,
-                         float* dpose, void* ws, hipStream_t s);
+                         float* dpose, int flags, void* ws, hipStream_t s);
 size_t sample_stats_grad_det_workspace_bytes(int B, int N, int C, int H, int W);
 int launch_sample_stats_grad_det(const float* conv1, const float* conv2, const float* px, const float* py, int B, int N, int C,
                                  int H, int W, const float* dstats, const float* dabs, float* dconv1, float* dconv2, float* dpos,

@@ -203,8 +203,12 @@ def _small_step(tensors, N, l2_base, pairs=1, camera=False):
     return st(tensors)
 
 
-def dense_adjoint(problem, R, T, Wc, gAtA, gAtb, gabs, dsrc, dmap3, ddepth, dbasis, ws=None):
-    """banet_dense_adjoint_f32 -> dpose [B, 12 + K]; dsrc / dmap3 / ddepth / dbasis are accumulated in place."""
+ADJOINT_OVERWRITE = 1      # banet_hip.h: BANET_ADJOINT_OVERWRITE
+
+
+def dense_adjoint(problem, R, T, Wc, gAtA, gAtb, gabs, dsrc, dmap3, ddepth, dbasis, ws=None, overwrite=False):
+    """banet_dense_adjoint_ex_f32 -> dpose [B, 12 + K]; dsrc / dmap3 / ddepth / dbasis are accumulated in place, or -- overwrite:
+    the first call on fresh (uninitialised) buffers -- written, every entry."""
     L = capi.lib()
     nb = L.banet_dense_adjoint_workspace_bytes(ctypes.byref(problem.c))
     if nb == 0:
@@ -213,9 +217,9 @@ def dense_adjoint(problem, R, T, Wc, gAtA, gAtb, gabs, dsrc, dmap3, ddepth, dbas
         ws = capi.workspace(nb, problem.device)
     dpose = torch.empty((problem.B, 12 + problem.K), dtype=torch.float32, device=problem.device)
     args = [capi.f32c(x) for x in (R, T, Wc, gAtA, gAtb, gabs)]          # (K = 0: Wc / dbasis are empty, never dereferenced)
-    capi.check(L.banet_dense_adjoint_f32(ctypes.byref(problem.c), *[capi.ptr(x) for x in args], capi.ptr(dsrc), capi.ptr(dmap3),
-                                         capi.ptr(ddepth), capi.ptr(dbasis), capi.ptr(dpose), ctypes.c_void_p(ws.data_ptr()),
-                                         ws.numel(), capi.stream()))
+    capi.check(L.banet_dense_adjoint_ex_f32(ctypes.byref(problem.c), *[capi.ptr(x) for x in args], capi.ptr(dsrc), capi.ptr(dmap3),
+                                            capi.ptr(ddepth), capi.ptr(dbasis), capi.ptr(dpose), ADJOINT_OVERWRITE if overwrite else 0,
+                                            ctypes.c_void_p(ws.data_ptr()), ws.numel(), capi.stream()))
     return dpose, ws
 
 
@@ -271,10 +275,12 @@ class _LevelSolve(torch.autograd.Function):
         camera = ba.variant == "bundle_camera"
         B, N, C, K, H, W = prob.B, prob.N, prob.C, prob.K, prob.c.H, prob.c.W
         pprobs = [prob] if pairs == 1 else _pair_problems(ba, li)
-        dsrc = torch.zeros((B, N, C), dtype=torch.float32, device=dev)
-        dmap3 = [torch.zeros((B, H, W, 3 * C), dtype=torch.float32, device=dev) for _ in range(pairs)]
-        ddepth = torch.zeros((B, N), dtype=torch.float32, device=dev)
-        dbasis = torch.zeros((B, N, K), dtype=torch.float32, device=dev)
+        # no zero-fills: the first adjoint call that touches a buffer writes it (BANET_ADJOINT_OVERWRITE), the later ones accumulate --
+        # 25 GB of fills and as many bytes of reads per 32-window 640x480 level
+        dsrc = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+        dmap3 = [torch.empty((B, H, W, 3 * C), dtype=torch.float32, device=dev) for _ in range(pairs)]
+        ddepth = torch.empty((B, N), dtype=torch.float32, device=dev)
+        dbasis = torch.empty((B, N, K), dtype=torch.float32, device=dev)
         flat = ctx.layers
         glayers = [torch.zeros_like(t) for t in flat]
         gR = torch.zeros(B, pairs, 3, 3, device=dev) if gR is None else gR.reshape(B, pairs, 3, 3)
@@ -282,6 +288,10 @@ class _LevelSolve(torch.autograd.Function):
         gW = torch.zeros(B, K, 1, device=dev) if gW is None else gW.reshape(B, K, 1)
         o = 6 * pairs
         ws = None
+        first = True
+        if not ctx.saved:                                  # (no iteration ran: nothing writes the buffers)
+            for t in [dsrc, ddepth, dbasis] + dmap3:
+                t.zero_()
         for Ri, Ti, Wi, AtA, Atb, absres in reversed(ctx.saved):
             Rv, Tv = Ri.reshape(B, pairs, 3, 3), Ti.reshape(B, pairs, 3, 1)
             grads = _small_step([AtA, Atb, absres, Rv, Tv, Wi, gR, gT, gW] + [t.detach() for t in flat], N, ba.l2_base, pairs, camera)
@@ -296,11 +306,16 @@ class _LevelSolve(torch.autograd.Function):
                     idx = torch.cat([torch.arange(6 * i, 6 * i + 6, device=dev), torch.arange(o, o + K, device=dev)])
                     gA_i = gAtA.index_select(1, idx).index_select(2, idx).contiguous()
                     gb_i = gAtb.index_select(1, idx).contiguous()
+                # The flag covers the four buffers of a call together, and dmap3[i] is fresh for every frame of the first iteration while
+                # dsrc / ddepth / dbasis are shared by the frames: frames i > 0 of the first iteration get a zeroed map instead.
+                if first and i > 0:
+                    dmap3[i].zero_()
                 dpose, ws = dense_adjoint(pprobs[i], Rv[:, i].contiguous(), Tv[:, i].contiguous(), Wi, gA_i, gb_i, gabs, dsrc,
-                                          dmap3[i], ddepth, dbasis, ws)
+                                          dmap3[i], ddepth, dbasis, ws, overwrite=first and i == 0)
                 gR[:, i] += dpose[:, 0:9].reshape(B, 3, 3)
                 gT[:, i] += dpose[:, 9:12].reshape(B, 3, 1)
                 gW += dpose[:, 12:].reshape(B, K, 1)
+            first = False
         dtgt = torch.zeros((B, pairs, H, W, C), dtype=torch.float32, device=dev)
         for i in range(pairs):
             di = torch.zeros((B, H, W, C), dtype=torch.float32, device=dev)

@@ -38,17 +38,18 @@ def _scene(H, W, C, K, seed, B=2, scales=(1,)):
     return intr, levels, R, T, Wc, rng
 
 
-def _run_adjoint(intr, lv, R, T, Wc, G, gb, gabs, variant="bundle"):
+def _run_adjoint(intr, lv, R, T, Wc, G, gb, gabs, variant="bundle", overwrite=False):
     from banet_amd import dense as bdense, dense_train
     B, H, W, C = lv["src"].shape
     K = lv["basis"].shape[-1] if variant == "bundle" else 0
     level = bdense.DenseLevel(lv["scale"], t(lv["src"]), t(lv["tgt"]), t(lv["D0"]), t(lv["basis"]) if K else None)
     ba = bdense.DenseBA(t(intr), [level], [orc.he_normal_mlp_weights(C, 5)], variant, 1000.0)
     prob = ba.problems[0]
-    out = dict(dsrc=torch.zeros(B, H * W, C, device=DEV), dmap3=torch.zeros(B, H, W, 3 * C, device=DEV),
-               ddepth=torch.zeros(B, H * W, device=DEV), dbasis=torch.zeros(B, H * W, K, device=DEV))
+    fill = float("nan") if overwrite else 0.0         # BANET_ADJOINT_OVERWRITE: every entry is written, nothing is read
+    out = dict(dsrc=torch.full((B, H * W, C), fill, device=DEV), dmap3=torch.full((B, H, W, 3 * C), fill, device=DEV),
+               ddepth=torch.full((B, H * W), fill, device=DEV), dbasis=torch.full((B, H * W, K), fill, device=DEV))
     dpose, _ = dense_train.dense_adjoint(prob, t(R), t(T), t(Wc), t(G), t(gb).reshape(B, -1), t(gabs).reshape(B, -1),
-                                        out["dsrc"], out["dmap3"], out["ddepth"], out["dbasis"])
+                                        out["dsrc"], out["dmap3"], out["ddepth"], out["dbasis"], overwrite=overwrite)
     dtgt = torch.zeros(B, H, W, C, device=DEV)
     dense_train.target_map_adjoint(out["dmap3"], dtgt)
     torch.cuda.synchronize()
@@ -455,6 +456,33 @@ def test_solve_differentiable_with_200_depth_coefficients_matches_oracle_finite_
     scale = max(abs(c[1]) for c in checks)
     for name, num, ana in checks:
         assert abs(num - ana) <= 2e-2 * max(abs(num), abs(ana)) + 1e-4 * scale, (name, num, ana)
+
+
+@pytest.mark.parametrize("H,W,C,K,variant", [(24, 32, 128, 128, "bundle"), (17, 33, 130, 40, "bundle"), (20, 24, 256, 64, "bundle"),
+                                             (16, 20, 128, 256, "bundle"), (9, 11, 3, 1, "bundle"), (24, 32, 128, 0, "bundle_camera"),
+                                             (21, 27, 6, 0, "bundle_camera")])
+def test_dense_adjoint_overwrite_mode_equals_accumulation_into_zeros(H, W, C, K, variant):
+    """BANET_ADJOINT_OVERWRITE (banet_dense_adjoint_ex_f32): on NaN-filled buffers the call writes every entry of dsrc / dmap3 /
+    ddepth / dbasis -- zeros where nothing contributes -- with the bits the accumulating call leaves in zero-filled buffers.  One
+    window is rotated so that most of its pixels are masked, one is translated out of view (every pixel masked, no texel hit)."""
+    intr, levels, R, T, Wc, rng = _scene(H, W, C, max(K, 1), 17, B=3)
+    lv = levels[0]
+    R, T = R.copy(), T.copy()
+    R[1] = synth.rodrigues(np.array([0.0, 0.35, 0.05]))
+    T[2] = np.array([[60.0], [0.0], [0.0]])
+    B = 3
+    if variant == "bundle_camera":
+        Wc = np.zeros((B, 0, 1))
+    P = 6 + K
+    G = rng.standard_normal((B, P, P))
+    gb = rng.standard_normal((B, P, 1))
+    gabs = rng.standard_normal((B, 1, C)) * 0.1
+    acc = _run_adjoint(intr, lv, R, T, Wc, G, gb, gabs, variant=variant)
+    ow = _run_adjoint(intr, lv, R, T, Wc, G, gb, gabs, variant=variant, overwrite=True)
+    for k in acc:
+        assert torch.isfinite(ow[k]).all(), k
+        assert torch.equal(acc[k], ow[k]), k
+    assert float(acc["dsrc"][2].abs().max()) == 0.0 and float(acc["dmap3"][2].abs().max()) == 0.0   # the empty window
 
 
 @pytest.mark.parametrize("B,N,C,H,W", [(2, 700, 128, 24, 32), (1, 4096, 70, 48, 64)])
