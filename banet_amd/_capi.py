@@ -85,6 +85,7 @@ EXPORTS = {
     "banet_dense_adjoint_f32": (ctypes.c_int, [ctypes.POINTER(Level)] + [_FP] * 11 + [_FP, ctypes.c_size_t, _FP]),
     "banet_dense_adjoint_ex_f32": (ctypes.c_int, [ctypes.POINTER(Level)] + [_FP] * 11 + [ctypes.c_int, _FP, ctypes.c_size_t, _FP]),
     "banet_target_map_adjoint_f32": (ctypes.c_int, [_FP] * 2 + [ctypes.c_int] * 4 + [_FP]),
+    "banet_target_map_adjoint_ex_f32": (ctypes.c_int, [_FP] * 2 + [ctypes.c_int] * 5 + [_FP]),
     "banet_build_id": (ctypes.c_char_p, []),
     "banet_gather_selection": (ctypes.c_int, [_FP]),
     "banet_profile_ranges": (ctypes.c_int, [ctypes.c_int]),

@@ -62,7 +62,8 @@ struct AdjArgs {
   float* dbasis;
   float* dmap3;
   float* dpose;
-  int overwrite;      // 1: dsrc / dmap3 / ddepth / dbasis are WRITTEN (every entry, zeros where nothing contributes) instead of accumulated
+  int overwrite;      // 1: dsrc / ddepth / dbasis are WRITTEN (every entry, zeros where nothing contributes) instead of accumulated
+  int overwrite_map;  // 1: the same for dmap3
 };
 
 __global__ void adj_sym_kernel(const float* __restrict__ g, float* __restrict__ S, int P, size_t total) {
@@ -1165,7 +1166,7 @@ __device__ __forceinline__ void adj_map_texel(const AdjArgs& a, int b, int t, in
     }
     const int Lmax = max(max(L[0], L[1]), max(L[2], L[3]));
     if (Lmax == 0) {         // wave-uniform: nothing lands on this texel
-      if (a.overwrite) {
+      if (a.overwrite_map) {
         float* __restrict__ o = a.dmap3 + ((size_t)b * HW + t) * C3;
 #pragma unroll
         for (int j = 0; j < J3; ++j)
@@ -1220,11 +1221,11 @@ __device__ __forceinline__ void adj_map_texel(const AdjArgs& a, int b, int t, in
         }
       }
     }
-    if (any || a.overwrite) {   // (acc is all zeros when nothing contributed)
+    if (any || a.overwrite_map) {   // (acc is all zeros when nothing contributed)
       float* __restrict__ o = a.dmap3 + ((size_t)b * HW + t) * C3;
 #pragma unroll
       for (int j = 0; j < J3; ++j)
-        if (cok[j]) o[lane + 64 * j] = a.overwrite ? acc[j] : o[lane + 64 * j] + acc[j];
+        if (cok[j]) o[lane + 64 * j] = a.overwrite_map ? acc[j] : o[lane + 64 * j] + acc[j];
     }
   }
 }
@@ -1271,7 +1272,7 @@ __global__ __launch_bounds__(kBlock) void adj_map2_kernel(const AdjArgs a) {
       continue;
     }
     if (!__any(Lmax == 1)) {                     // nothing lands on either texel
-      if (a.overwrite && live) {
+      if (a.overwrite_map && live) {
         float* __restrict__ o = a.dmap3 + ((size_t)b * HW + t) * C3 + 4 * hl;
 #pragma unroll
         for (int j = 0; j < J4; ++j)
@@ -1305,13 +1306,13 @@ __global__ __launch_bounds__(kBlock) void adj_map2_kernel(const AdjArgs a) {
       for (int j = 0; j < J4; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(wt[cell], wt[cell] != 0.f ? val[cell][j][e] : 0.f, acc[j][e]);
-    if (any || (a.overwrite && live)) {           // (acc is all zeros when nothing contributed)
+    if (any || (a.overwrite_map && live)) {           // (acc is all zeros when nothing contributed)
       float* __restrict__ o = a.dmap3 + ((size_t)b * HW + t) * C3 + 4 * hl;
 #pragma unroll
       for (int j = 0; j < J4; ++j)
         if (cok[j]) {
           f32x4* op = reinterpret_cast<f32x4*>(o + 128 * j);
-          *op = a.overwrite ? acc[j] : *op + acc[j];
+          *op = a.overwrite_map ? acc[j] : *op + acc[j];
         }
     }
   }
@@ -1319,7 +1320,7 @@ __global__ __launch_bounds__(kBlock) void adj_map2_kernel(const AdjArgs a) {
 
 // d img += dmap_f + grad_fixed^T (dmap_gx, dmap_gy): gx[x] = 0.5 (img[x+1] - img[x-1]) for 1 <= x <= W-2, 0 on the rim
 __global__ void target_map_adjoint_kernel(const float* __restrict__ dmap3, float* __restrict__ dimg, int H, int W, int C,
-                                          size_t total) {
+                                          size_t total, int overwrite) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= total) return;
   const int c = (int)(e % C);
@@ -1334,12 +1335,12 @@ __global__ void target_map_adjoint_kernel(const float* __restrict__ dmap3, float
   if (x + 1 >= 1 && x + 1 <= W - 2) v -= 0.5f * (m + C3)[C + c];
   if (y - 1 >= 1 && y - 1 <= H - 2) v += 0.5f * (m - (size_t)W * C3)[2 * C + c];
   if (y + 1 >= 1 && y + 1 <= H - 2) v -= 0.5f * (m + (size_t)W * C3)[2 * C + c];
-  dimg[e] += v;
+  dimg[e] = overwrite ? v : dimg[e] + v;
 }
 
 // C % 4 == 0: four channels per thread, 16-byte accesses; per element the same operations in the same order (identical bits)
 __global__ void target_map_adjoint4_kernel(const float* __restrict__ dmap3, float* __restrict__ dimg, int H, int W, int C4,
-                                           size_t total4) {
+                                           size_t total4, int overwrite) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= total4) return;
   const int c = (int)(e % C4);
@@ -1361,6 +1362,10 @@ __global__ void target_map_adjoint4_kernel(const float* __restrict__ dmap3, floa
   if (y - 1 >= 1 && y - 1 <= H - 2) axpy(0.5f, (m - (size_t)W * Q3)[2 * C4 + c]);
   if (y + 1 >= 1 && y + 1 <= H - 2) axpy(-0.5f, (m + (size_t)W * Q3)[2 * C4 + c]);
   float4* o = reinterpret_cast<float4*>(dimg) + e;
+  if (overwrite) {
+    *o = v;
+    return;
+  }
   float4 d = *o;
   d.x += v.x;
   d.y += v.y;
@@ -1589,6 +1594,7 @@ int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T
   a.dmap3 = dmap3;
   a.dpose = dpose;
   a.overwrite = (flags & BANET_ADJOINT_OVERWRITE) ? 1 : 0;
+  a.overwrite_map = (flags & BANET_ADJOINT_OVERWRITE_MAP) ? 1 : 0;
   const size_t tot = (size_t)B * P * P;
   hipLaunchKernelGGL(adj_sym_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, gAtA, S, P, tot);
   if (hipMemsetAsync(a.cnt, 0, (size_t)B * HW * sizeof(int), s) != hipSuccess) return BANET_ERR_LAUNCH;
@@ -1711,16 +1717,16 @@ int launch_sample_stats_grad_det(const float* conv1, const float* conv2, const f
   return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;
 }
 
-int launch_target_map_adjoint(const float* dmap3, float* dimg, int B, int H, int W, int C, hipStream_t s) {
+int launch_target_map_adjoint(const float* dmap3, float* dimg, int B, int H, int W, int C, int overwrite, hipStream_t s) {
   const size_t total = (size_t)B * H * W * C;
   if (total == 0) return BANET_OK;
   if ((C & 3) == 0 && ((reinterpret_cast<uintptr_t>(dmap3) | reinterpret_cast<uintptr_t>(dimg)) & 15) == 0) {
     const size_t total4 = total / 4;
     hipLaunchKernelGGL(target_map_adjoint4_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, dmap3, dimg, H, W, C / 4,
-                       total4);
+                       total4, overwrite);
     return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL(target_map_adjoint_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dmap3, dimg, H, W, C, total);
+  hipLaunchKernelGGL(target_map_adjoint_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dmap3, dimg, H, W, C, total, overwrite);
   return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;
 }
 

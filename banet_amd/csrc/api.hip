@@ -368,7 +368,7 @@ int banet_dense_adjoint_ex_f32(const banet_level_t* lv, const float* R, const fl
   if (!lv || !R || !T || !gAtA || !gAtb || !gabs || !dsrc || !dmap3 || !ddepth || !dpose || !ws) return BANET_ERR_INVALID_ARG;
   if (lv->K > 0 && (!Wc || !dbasis || !lv->basis)) return BANET_ERR_INVALID_ARG;     // K = 0 (pose only): no coefficient / basis tensors
   if (lv->B <= 0 || lv->N <= 0 || !lv->src || !lv->tgt || !lv->depth || !lv->intr) return BANET_ERR_INVALID_ARG;
-  if (flags & ~BANET_ADJOINT_OVERWRITE) return BANET_ERR_INVALID_ARG;
+  if (flags & ~(BANET_ADJOINT_OVERWRITE | BANET_ADJOINT_OVERWRITE_MAP)) return BANET_ERR_INVALID_ARG;
   const size_t need = dense_adjoint_workspace_bytes(lv);
   if (need == 0) return BANET_ERR_UNSUPPORTED;
   if (ws_bytes < need || (reinterpret_cast<uintptr_t>(ws) & 255) != 0) return BANET_ERR_WORKSPACE;
@@ -382,9 +382,13 @@ int banet_dense_adjoint_f32(const banet_level_t* lv, const float* R, const float
   return banet_dense_adjoint_ex_f32(lv, R, T, Wc, gAtA, gAtb, gabs, dsrc, dmap3, ddepth, dbasis, dpose, 0, ws, ws_bytes, stream);
 }
 
+int banet_target_map_adjoint_ex_f32(const float* dmap3, float* dimg, int B, int H, int W, int C, int flags, banet_stream_t stream) {
+  if (!dmap3 || !dimg || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (flags & ~BANET_ADJOINT_OVERWRITE)) return BANET_ERR_INVALID_ARG;
+  return launch_target_map_adjoint(dmap3, dimg, B, H, W, C, flags & BANET_ADJOINT_OVERWRITE, static_cast<hipStream_t>(stream));
+}
+
 int banet_target_map_adjoint_f32(const float* dmap3, float* dimg, int B, int H, int W, int C, banet_stream_t stream) {
-  if (!dmap3 || !dimg || B <= 0 || H <= 0 || W <= 0 || C <= 0) return BANET_ERR_INVALID_ARG;
-  return launch_target_map_adjoint(dmap3, dimg, B, H, W, C, static_cast<hipStream_t>(stream));
+  return banet_target_map_adjoint_ex_f32(dmap3, dimg, B, H, W, C, 0, stream);
 }
 
 #include "build_id.h"   // generated by build.sh: BANET_BUILD_ID

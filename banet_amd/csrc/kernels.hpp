@@ -165,6 +165,6 @@ size_t sample_stats_grad_det_workspace_bytes(int B, int N, int C, int H, int W);
 int launch_sample_stats_grad_det(const float* conv1, const float* conv2, const float* px, const float* py, int B, int N, int C,
                                  int H, int W, const float* dstats, const float* dabs, float* dconv1, float* dconv2, float* dpos,
                                  void* ws, hipStream_t s);
-int launch_target_map_adjoint(const float* dmap3, float* dimg, int B, int H, int W, int C, hipStream_t s);
+int launch_target_map_adjoint(const float* dmap3, float* dimg, int B, int H, int W, int C, int overwrite, hipStream_t s);
 
 }  // namespace banet

@@ -203,12 +203,13 @@ def _small_step(tensors, N, l2_base, pairs=1, camera=False):
     return st(tensors)
 
 
-ADJOINT_OVERWRITE = 1      # banet_hip.h: BANET_ADJOINT_OVERWRITE
+ADJOINT_OVERWRITE, ADJOINT_OVERWRITE_MAP = 1, 2      # banet_hip.h: BANET_ADJOINT_OVERWRITE, BANET_ADJOINT_OVERWRITE_MAP
 
 
-def dense_adjoint(problem, R, T, Wc, gAtA, gAtb, gabs, dsrc, dmap3, ddepth, dbasis, ws=None, overwrite=False):
+def dense_adjoint(problem, R, T, Wc, gAtA, gAtb, gabs, dsrc, dmap3, ddepth, dbasis, ws=None, overwrite=False, overwrite_map=None):
     """banet_dense_adjoint_ex_f32 -> dpose [B, 12 + K]; dsrc / dmap3 / ddepth / dbasis are accumulated in place, or -- overwrite:
-    the first call on fresh (uninitialised) buffers -- written, every entry."""
+    the first call on fresh (uninitialised) buffers -- written, every entry (overwrite_map: dmap3 on its own; default = overwrite)."""
+    overwrite_map = overwrite if overwrite_map is None else overwrite_map
     L = capi.lib()
     nb = L.banet_dense_adjoint_workspace_bytes(ctypes.byref(problem.c))
     if nb == 0:
@@ -218,15 +219,17 @@ def dense_adjoint(problem, R, T, Wc, gAtA, gAtb, gabs, dsrc, dmap3, ddepth, dbas
     dpose = torch.empty((problem.B, 12 + problem.K), dtype=torch.float32, device=problem.device)
     args = [capi.f32c(x) for x in (R, T, Wc, gAtA, gAtb, gabs)]          # (K = 0: Wc / dbasis are empty, never dereferenced)
     capi.check(L.banet_dense_adjoint_ex_f32(ctypes.byref(problem.c), *[capi.ptr(x) for x in args], capi.ptr(dsrc), capi.ptr(dmap3),
-                                            capi.ptr(ddepth), capi.ptr(dbasis), capi.ptr(dpose), ADJOINT_OVERWRITE if overwrite else 0,
+                                            capi.ptr(ddepth), capi.ptr(dbasis), capi.ptr(dpose),
+                                            (ADJOINT_OVERWRITE if overwrite else 0) | (ADJOINT_OVERWRITE_MAP if overwrite_map else 0),
                                             ctypes.c_void_p(ws.data_ptr()), ws.numel(), capi.stream()))
     return dpose, ws
 
 
-def target_map_adjoint(dmap3, dimg):
-    """banet_target_map_adjoint_f32: dimg [B,H,W,C] += the adjoint of banet_target_map_f32 applied to dmap3 [B,H,W,3C]."""
+def target_map_adjoint(dmap3, dimg, overwrite=False):
+    """banet_target_map_adjoint_ex_f32: dimg [B,H,W,C] += (overwrite: =) the adjoint of banet_target_map_f32 applied to dmap3 [B,H,W,3C]."""
     B, H, W, C = dimg.shape
-    capi.check(capi.lib().banet_target_map_adjoint_f32(capi.ptr(dmap3), capi.ptr(dimg), B, H, W, C, capi.stream()))
+    capi.check(capi.lib().banet_target_map_adjoint_ex_f32(capi.ptr(dmap3), capi.ptr(dimg), B, H, W, C, ADJOINT_OVERWRITE if overwrite else 0,
+                                                          capi.stream()))
     return dimg
 
 
@@ -306,21 +309,22 @@ class _LevelSolve(torch.autograd.Function):
                     idx = torch.cat([torch.arange(6 * i, 6 * i + 6, device=dev), torch.arange(o, o + K, device=dev)])
                     gA_i = gAtA.index_select(1, idx).index_select(2, idx).contiguous()
                     gb_i = gAtb.index_select(1, idx).contiguous()
-                # The flag covers the four buffers of a call together, and dmap3[i] is fresh for every frame of the first iteration while
-                # dsrc / ddepth / dbasis are shared by the frames: frames i > 0 of the first iteration get a zeroed map instead.
-                if first and i > 0:
-                    dmap3[i].zero_()
+                # dmap3[i] is fresh for every frame of the first iteration; dsrc / ddepth / dbasis are shared by the frames
                 dpose, ws = dense_adjoint(pprobs[i], Rv[:, i].contiguous(), Tv[:, i].contiguous(), Wi, gA_i, gb_i, gabs, dsrc,
-                                          dmap3[i], ddepth, dbasis, ws, overwrite=first and i == 0)
+                                          dmap3[i], ddepth, dbasis, ws, overwrite=first and i == 0, overwrite_map=first)
                 gR[:, i] += dpose[:, 0:9].reshape(B, 3, 3)
                 gT[:, i] += dpose[:, 9:12].reshape(B, 3, 1)
                 gW += dpose[:, 12:].reshape(B, K, 1)
             first = False
-        dtgt = torch.zeros((B, pairs, H, W, C), dtype=torch.float32, device=dev)
-        for i in range(pairs):
-            di = torch.zeros((B, H, W, C), dtype=torch.float32, device=dev)
-            target_map_adjoint(dmap3[i], di)
-            dtgt[:, i] = di
+        if pairs == 1:                                     # written in place: no fill, no copy
+            dtgt = torch.empty((B, 1, H, W, C), dtype=torch.float32, device=dev)
+            target_map_adjoint(dmap3[0], dtgt.view(B, H, W, C), overwrite=True)
+        else:
+            dtgt = torch.empty((B, pairs, H, W, C), dtype=torch.float32, device=dev)
+            for i in range(pairs):
+                di = torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
+                target_map_adjoint(dmap3[i], di, overwrite=True)
+                dtgt[:, i] = di
         s_src, s_tgt, s_dep, s_bas, s_R, s_T = ctx.shapes
         return (None, None, None, dsrc.reshape(s_src), dtgt.reshape(s_tgt), ddepth.reshape(s_dep),
                 None if s_bas is None else dbasis.reshape(s_bas), gR.reshape(s_R), gT.reshape(s_T), gW) + tuple(glayers)

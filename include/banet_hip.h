@@ -277,15 +277,18 @@ int banet_spd_solve_f32(const float* A, const float* rhs, float* x, int B, int P
 int banet_dense_adjoint_f32(const banet_level_t* lv, const float* R, const float* T, const float* Wc, const float* gAtA,
                             const float* gAtb, const float* gabs, float* dsrc, float* dmap3, float* ddepth,
                             float* dbasis, float* dpose, void* ws, size_t ws_bytes, banet_stream_t stream);
-/*   banet_dense_adjoint_ex_f32: the same with flags.  BANET_ADJOINT_OVERWRITE: dsrc / dmap3 / ddepth / dbasis are WRITTEN -- every
- *     entry, zeros where nothing contributes -- instead of accumulated: the first call of a level (its last iteration, and the
- *     first target frame of a multi-frame window for dsrc / ddepth / dbasis) needs no zero-filled buffers and reads none
- *     (25 GB of fills + 25 GB of reads per 32-window 640x480 level).  Same bits as accumulating into zeros.              */
-enum { BANET_ADJOINT_OVERWRITE = 1 };
+/*   banet_dense_adjoint_ex_f32: the same with flags.  BANET_ADJOINT_OVERWRITE: dsrc / ddepth / dbasis are WRITTEN -- every
+ *     entry, zeros where nothing contributes -- instead of accumulated; BANET_ADJOINT_OVERWRITE_MAP: the same for dmap3.  The first
+ *     call of a level (its last iteration; per target frame for dmap3, the first frame only for the buffers the frames share)
+ *     then needs no zero-filled buffers and reads none (25 GB of fills + 25 GB of reads per 32-window 640x480 level).  Same bits
+ *     as accumulating into zeros.  banet_target_map_adjoint_ex_f32 with BANET_ADJOINT_OVERWRITE: dimg is written, not added to. */
+enum { BANET_ADJOINT_OVERWRITE = 1, BANET_ADJOINT_OVERWRITE_MAP = 2 };
 int banet_dense_adjoint_ex_f32(const banet_level_t* lv, const float* R, const float* T, const float* Wc, const float* gAtA,
                                const float* gAtb, const float* gabs, float* dsrc, float* dmap3, float* ddepth,
                                float* dbasis, float* dpose, int flags, void* ws, size_t ws_bytes, banet_stream_t stream);
 int banet_target_map_adjoint_f32(const float* dmap3, float* dimg, int B, int H, int W, int C, banet_stream_t stream);
+int banet_target_map_adjoint_ex_f32(const float* dmap3, float* dimg, int B, int H, int W, int C, int flags,
+                                    banet_stream_t stream);
 
 /* (8) optional kernel timing, used by bench.py for the roofline figure.  Between
  *     banet_profile_begin and banet_profile_end every launch of the fused assembly kernel

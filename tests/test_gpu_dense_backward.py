@@ -50,8 +50,8 @@ def _run_adjoint(intr, lv, R, T, Wc, G, gb, gabs, variant="bundle", overwrite=Fa
                ddepth=torch.full((B, H * W), fill, device=DEV), dbasis=torch.full((B, H * W, K), fill, device=DEV))
     dpose, _ = dense_train.dense_adjoint(prob, t(R), t(T), t(Wc), t(G), t(gb).reshape(B, -1), t(gabs).reshape(B, -1),
                                         out["dsrc"], out["dmap3"], out["ddepth"], out["dbasis"], overwrite=overwrite)
-    dtgt = torch.zeros(B, H, W, C, device=DEV)
-    dense_train.target_map_adjoint(out["dmap3"], dtgt)
+    dtgt = torch.full((B, H, W, C), fill, device=DEV)
+    dense_train.target_map_adjoint(out["dmap3"], dtgt, overwrite=overwrite)
     torch.cuda.synchronize()
     return dict(dsrc=out["dsrc"], dmap3=out["dmap3"], ddepth=out["ddepth"], dbasis=out["dbasis"], dpose=dpose, dtgt=dtgt)
 
