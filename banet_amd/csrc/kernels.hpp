@@ -45,6 +45,7 @@ struct MlpRole {        // one extra workgroup per window of the SYRK launch eva
 };
 struct SyrkPlan {
   int Gs, tiles, pstride, nb;
+  int x3;       // ba_syrk_bf16x6_kernel, opt-in: three products instead of six (reserved_ bit 29)
   int direct;   // 0: the LDS-tiled kernel, 1: ba_syrk_direct_kernel (fp32 MFMA, A/B), 2: ba_syrk_bf16x6_kernel (K = 64 / 128, <= 4 frames),
                 // 3: syrk_wide.hip jobs (K = 256, or K = 128 with more than 4 target frames)
   size_t off_aux;        // direct == 3: per-pixel (s, r) sums over the frames, inside the partial buffer

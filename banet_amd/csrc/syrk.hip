@@ -450,7 +450,7 @@ __global__ __launch_bounds__(kBlock, 1) void ba_syrk_direct_kernel(const SyrkArg
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int KH, int PAIRS>
+template <int KH, int PAIRS, int T0>   // T0 = 0: six products (fp32-exact, the product path); 3: the three largest only (opt-in, see plan_syrk)
 __global__ __launch_bounds__(kBlock, 1) void ba_syrk_bf16x6_kernel(const SyrkArgs a) {
   constexpr int NBV = 4 * KH, NPAIR = NBV * (NBV + 1) / 2, K = 64 * KH;
   constexpr int NU = (PAIRS + 1) / 2;
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(kBlock, 1) void ba_syrk_bf16x6_kernel(const SyrkArg
 #if defined(BANET_SYRK_ABL) && BANET_SYRK_ABL >= 1   // development ablation (tools/time_syrk.py): one product instead of six
     constexpr int kT0 = 5;
 #else
-    constexpr int kT0 = 0;
+    constexpr int kT0 = T0;   // 3: mid hi' + hi mid' + hi hi' -- the third piece of the split is then dead code
 #endif
 #pragma unroll
     for (int t6 = kT0; t6 < 6; ++t6) {
@@ -762,6 +762,10 @@ int plan_syrk(int B, int N, int K, int pairs, int dbg, SyrkPlan* pl) {
   // K = 64 / 128: barrier-free kernels, one wave per SIMD, 256 workgroups in all: 2 = ba_syrk_bf16x6_kernel
   // (default), 1 = ba_syrk_direct_kernel (fp32 MFMA; reserved_ bit 8, A/B only)
   pl->direct = ((K == 64 || K == 128) && pairs <= 4) ? ((dbg & 256) ? 1 : 2) : 0;
+  // OPT-IN (reserved_ bit 29, K = 128): the three largest of the six products only -- a two-piece split, 16 significand bits per
+  // operand, ~2^-16 relative error per product instead of 2^-24.  Not the product path and not what bench.py's `value` is measured
+  // with (its dtype is "f32": fp32-exact products); measured beside it: profiles/r03_run31_*, DESIGN.md section 7.
+  pl->x3 = (pl->direct == 2 && K == 128 && (dbg & (1 << 29))) ? 1 : 0;
   // K = 256, or K = 128 with more than 4 target frames: the job kernels of syrk_wide.hip (reserved_ bit 8: the LDS-tiled kernel, A/B)
   if (!(dbg & 256) && (K == 256 || (K == 128 && pairs > 4))) pl->direct = 3;
   int target = (((pl->direct || pl->nb > 8) ? 256 : 512) + B - 1) / B;   // LDS kernel: 2 resident workgroups per CU (1 at K > 128)
@@ -788,14 +792,14 @@ static void launch_syrk_nb(const SyrkArgs& a, int B, hipStream_t s) {
   hipLaunchKernelGGL(k, dim3(a.Gs, B), dim3(kBlock), lds, s, a);
 }
 
-template <int KH>
+template <int KH, int T0>
 static void launch_bf16x6(const SyrkArgs& a, int B, hipStream_t s) {
   const dim3 grid(a.Gs + (a.mr.y != nullptr ? 1 : 0), B), block(kBlock);
   switch (a.pairs) {
-    case 1: hipLaunchKernelGGL((ba_syrk_bf16x6_kernel<KH, 1>), grid, block, 0, s, a); break;
-    case 2: hipLaunchKernelGGL((ba_syrk_bf16x6_kernel<KH, 2>), grid, block, 0, s, a); break;
-    case 3: hipLaunchKernelGGL((ba_syrk_bf16x6_kernel<KH, 3>), grid, block, 0, s, a); break;
-    default: hipLaunchKernelGGL((ba_syrk_bf16x6_kernel<KH, 4>), grid, block, 0, s, a); break;
+    case 1: hipLaunchKernelGGL((ba_syrk_bf16x6_kernel<KH, 1, T0>), grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((ba_syrk_bf16x6_kernel<KH, 2, T0>), grid, block, 0, s, a); break;
+    case 3: hipLaunchKernelGGL((ba_syrk_bf16x6_kernel<KH, 3, T0>), grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL((ba_syrk_bf16x6_kernel<KH, 4, T0>), grid, block, 0, s, a); break;
   }
 }
 
@@ -818,10 +822,14 @@ int launch_syrk(const float* basis, const float* rec, int B, int N, int K, int p
   SyrkArgs a{basis, rec, active, active_stride, partials, N, K, pl.Gs, pl.tiles, pl.pstride, pairs, 0, MlpRole{}};
   if (pl.direct == 2) {
     if (mr != nullptr) a.mr = *mr;
-    if (K == 128)
-      launch_bf16x6<2>(a, B, s);
-    else
-      launch_bf16x6<1>(a, B, s);
+    if (K == 128) {
+      if (pl.x3)
+        launch_bf16x6<2, 3>(a, B, s);
+      else
+        launch_bf16x6<2, 0>(a, B, s);
+    } else {
+      launch_bf16x6<1, 0>(a, B, s);
+    }
     return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;
   }
   if (pl.direct) {

@@ -255,6 +255,7 @@ class LevelProblem:
 
 GATHER_KERNELS = {0: "ba_gather_kernel", 1: "ba_gather128_kernel", 2: "ba_gather128p_kernel", 3: "ba_gather128s_kernel"}
 FORCE_PATCH_GATHER, FORCE_STRIP_GATHER = 512, 262144     # banet_level_t.reserved_ bits (parity checks at small batch sizes)
+SYRK_THREE_PRODUCTS = 1 << 29   # opt-in: the K = 128 SYRK with the three largest bf16 products only (~2^-16 per product instead of fp32-exact)
 
 
 def gather_selection(level):

@@ -130,6 +130,37 @@ def test_syrk_bf16x6_with_basis_columns_spanning_4096x(K, H, W):
         assert dg[6:].max() / dg[6:].min() > 1000.0           # the dynamic range really is in the matrix
 
 
+def test_opt_in_three_product_syrk_is_a_separate_less_exact_path():
+    """reserved_ bit 29 (ops.SYRK_THREE_PRODUCTS): the K = 128 SYRK with the three largest of the six bf16 products.  It is NOT the
+    product path: the default leaves the bits of AtA untouched, the opt-in differs from it -- by no more than the two-piece split
+    allows (each entry within 1e-4 of sqrt(A_ii A_jj), against 3e-5 vs float64 for the exact form) -- and one LM step from it stays
+    within the headline tolerance of the float64 twin."""
+    from banet_amd import dense as bdense, ops, synth as bsynth
+    B, C, K, H, W = 2, 128, 128, 120, 160
+    intr, levels, gt = bsynth.make_dense_windows(B, H, W, C, K, [1], 23, DEV, trans_mag=0.06)
+    ba = bdense.DenseBA(intr, levels, [orc.he_normal_mlp_weights(C, 5)], "bundle", 1000.0)
+    p = ba.problems[0]
+    R = torch.eye(3, device=DEV).repeat(B, 1, 1)
+    T = (gt["T"] * 0.7).reshape(B, 3, 1).to(DEV)
+    Wc = torch.zeros(B, K, 1, device=DEV)
+    base = [x.clone() for x in ops.ba_assemble(p, R, T, Wc)]
+    again = [x.clone() for x in ops.ba_assemble(p, R, T, Wc)]
+    p.c.reserved_ = ops.SYRK_THREE_PRODUCTS
+    fast = [x.clone() for x in ops.ba_assemble(p, R, T, Wc)]
+    st_fast = ba.step_from(0, R, T, Wc)
+    p.c.reserved_ = 0
+    st_base = ba.step_from(0, R, T, Wc)
+    assert all(torch.equal(a, b) for a, b in zip(base, again))
+    assert not torch.equal(base[0], fast[0])                         # a different kernel ran
+    assert torch.equal(base[0][:, :6, :6], fast[0][:, :6, :6])       # the pose block comes from the gather: untouched
+    for b in range(B):
+        A, F = n(base[0][b]).astype(np.float64), n(fast[0][b]).astype(np.float64)
+        dg = np.sqrt(np.maximum(np.diag(A), 1e-300))
+        assert (np.abs(F - A) / np.outer(dg, dg)).max() < 1e-4
+    d = (st_fast.delta - st_base.delta).abs().max() / st_base.delta.abs().max()
+    assert float(d) < 1e-4, float(d)
+
+
 def test_losses_and_quaternion_on_the_gpu_match_the_reference(golden_dir):
     """SURVEY 8(f) rank 4 (bundlenet.py:6-15,401-463) on cuda:0 against the reference's own output
     (tests/golden/golden_losses.npz, golden_bundle_fns.npz), and their gradients against the CPU result."""
