@@ -129,6 +129,8 @@ def roofline_record(prob, prof, elapsed_s, traffic=None):
     alg_bytes, kern_ms, nlaunch, per_level, syrk_ms, syrk_n = 0.0, 0.0, 0, {}, 0.0, 0
     syrk_flops, syrk_exec = 0.0, 0.0
     pairs = max(int(prob.pairs), 1)
+    three = bool(int(getattr(ba.problems[0].c, "reserved_", 0)) & (1 << 29)) and int(ba.problems[0].c.K) == 128   # ops.SYRK_THREE_PRODUCTS (opt-in)
+    nprod = 3 if three else 6
     for li, p in enumerate(ba.problems):
         cnt, ms = prof.get(p.N, (0, 0.0))
         scnt, sms = prof.get(-p.N, (0, 0.0))
@@ -145,7 +147,7 @@ def roofline_record(prob, prof, elapsed_s, traffic=None):
         syrk_flops += float(p.N) * (Kk * (Kk + 1) + 14 * Kk * pairs) * B * scnt
         if Kk in (64, 128):
             nbv = Kk // 16
-            syrk_exec += float(p.N) / 32.0 * 6 * 16384 * (nbv * (nbv + 1) // 2 + ((pairs + 1) // 2) * nbv) * B * scnt
+            syrk_exec += float(p.N) / 32.0 * nprod * 16384 * (nbv * (nbv + 1) // 2 + ((pairs + 1) // 2) * nbv) * B * scnt
         per_level["%dx%d" % (p.c.W, p.c.H)] = {"launches": cnt, "gather_avg_us": round(1e3 * ms / max(cnt, 1), 2),
                                                 "syrk_avg_us": round(1e3 * sms / max(scnt, 1), 2),
                                                 "gather_GBps": round(by / max(ms, 1e-9) / 1e6, 1)}
@@ -167,7 +169,9 @@ def roofline_record(prob, prof, elapsed_s, traffic=None):
             "syrk_kernel": {"launches": syrk_n, "avg_launch_us": round(1e3 * syrk_ms / max(syrk_n, 1), 2),
                             "time_share": round(syrk_ms / (1e3 * elapsed_s), 4),
                             # the matrix-core side of the path (north_star: "MFMA utilisation against gfx950 peak")
-                            "mfma": {"bound": "mfma", "kernel": "ba_syrk_bf16x6_kernel (fp32 operands split exactly into 3 bf16 pieces, 6 products)",
+                            "mfma": {"bound": "mfma", "kernel": ("ba_syrk_bf16x6_kernel, OPT-IN form (--reserved bit 29): 2 bf16 pieces, the 3 largest products, "
+                                                                       "~2^-16 per product -- reduced precision, not the headline path") if three else
+                                               "ba_syrk_bf16x6_kernel (fp32 operands split exactly into 3 bf16 pieces, 6 products)",
                                      "algorithmic_fp32_TFLOPs": round(syrk_flops / max(syrk_ms, 1e-9) / 1e9, 1),
                                      "peak_fp32_matrix_TFLOPs": MFMA_F32_PEAK_TF,
                                      "frac_of_fp32_matrix_peak": round(syrk_flops / max(syrk_ms, 1e-9) / 1e9 / MFMA_F32_PEAK_TF, 4),
@@ -571,7 +575,9 @@ def main():
             "value": round(value, 2), "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "ms_per_solve": round(1e3 * elapsed / args.steps / B, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if not (args.reserved & (1 << 29)) else "f32 with bf16x3 products in the SYRK (opt-in, reduced precision)",
+            "data": "synthetic",
             "config": {"workload": workload_name(args.frames, B, Hh, Ww, Kk, args.iters),
                        "windows_per_gpu": B, "windows_total": total_windows, "iters_per_level": iters, "scales": SCALES,
                        "shape": {"H": Hh, "W": Ww, "C": C, "K": Kk, "frames": args.frames},
