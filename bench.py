@@ -25,7 +25,9 @@ HBM.  value = windows * 50 * steps / time over all ranks.  The JSON line also ca
                  (oracle/torch_port.py, all intra-op threads); cfg-1 (160x120, K = 32, 3 iterations) timed the same way.
 
 `python bench.py --gpus N` without a torch.distributed environment launches its own N ranks (torch.distributed.run,
-127.0.0.1); under torchrun it is one rank of the job.  Rank 0 prints the one JSON line.
+127.0.0.1); under torchrun it is one rank of the job.  Rank 0 prints the one JSON line -- COMPACT (< 4 KB: the contract's
+fields, roofline, cpu_baseline, one number per parity / sweep record) as the LAST line of stdout; the full record (per-level
+tables, per-sweep parity detail) goes to bench_detail.json and to earlier '#detail ...' stdout lines.
 """
 import argparse
 import gc
@@ -464,6 +466,80 @@ def parity_and_cpu_baseline(prob, dev, want_baseline, scenes=(0, 1)):
     return parity, base
 
 
+COMPACT_LINE_LIMIT = 4000     # bytes; the driver keeps only a few KB of stdout (BENCH_r03: a 38 KB line was not parseable)
+
+
+def compact_record(out):
+    """The ONE JSON line rank 0 prints last: the contract's fields + roofline + cpu_baseline + one number per parity / sweep
+    record, < COMPACT_LINE_LIMIT bytes.  The full record (per-level tables, per-sweep parity detail) goes to
+    bench_detail.json next to this file and to earlier '#detail' stdout lines."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_solve", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "build_id", "end_to_end_hbm_frac")
+    c = {k: out[k] for k in keep if k in out}
+    cfg = out.get("config", {})
+    c["config"] = {k: cfg[k] for k in ("workload", "windows_per_gpu", "windows_total", "iters_per_level", "shape", "parallelism",
+                                       "world_size", "backend") if k in cfg}
+    rl = out.get("roofline")
+    if rl:
+        r = {k: rl.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_GBps", "kernel", "launches",
+                                    "avg_launch_us", "algorithmic_bytes_per_launch", "kernel_time_share")}
+        sk = rl.get("syrk_kernel") or {}
+        mf = sk.get("mfma") or {}
+        r["syrk_kernel"] = {"avg_launch_us": sk.get("avg_launch_us"), "time_share": sk.get("time_share"),
+                            "mfma": {"bound": "mfma", "achieved": mf.get("achieved"), "peak": mf.get("peak"), "unit": "TFLOP/s",
+                                     "frac": mf.get("frac"), "frac_of_fp32_matrix_peak": mf.get("frac_of_fp32_matrix_peak")}}
+        r["per_level_gather_us"] = {k: v.get("gather_avg_us") for k, v in (rl.get("per_level") or {}).items()}
+        c["roofline"] = r
+    cb = out.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "engine", "host_cpus", "median_s", "p10_s",
+                                                    "p90_s", "repeats", "warmups")}
+        c["cpu_baseline"]["sample"] = ("oracle port, 640x480 C=K=128 level-0..4 chain of window 0, 1 LM iteration per level "
+                                       "(5 per repeat), value = 5 / median")
+        c1 = (cb.get("cfg1_160x120_K32_3iters") or {})
+        if c1:
+            c["cpu_baseline"]["cfg1_ms_per_solve"] = {k: v.get("ms_per_solve") for k, v in c1.items() if isinstance(v, dict)}
+    pr = out.get("parity")
+    if pr:
+        c["parity"] = {"max_rel_err": pr.get("max_rel_err"), "ok": pr.get("ok"), "tolerance": pr.get("tolerance"),
+                       "scenes": len(pr.get("scenes", [])), "iters": pr.get("iters")}
+    sw = out.get("sweep")
+    if sw:
+        c["sweep"] = {}
+        for name, rec in sw.items():
+            e = {"value": rec.get("value"), "ms_per_step": rec.get("ms_per_step"), "steps": rec.get("steps"),
+                 "frac": (rec.get("roofline") or {}).get("frac"), "e2e_frac": rec.get("end_to_end_hbm_frac")}
+            if "parity" in rec:
+                e["parity_max"] = rec["parity"].get("max_rel_err")
+                e["parity_ok"] = rec["parity"].get("ok")
+            c["sweep"][name] = e
+    c["detail"] = "bench_detail.json"
+    line = json.dumps(c, separators=(",", ":"))
+    if len(line) >= COMPACT_LINE_LIMIT:          # never again an unparseable line: drop the optional parts, largest first
+        for k in ("sweep", "parity"):
+            if k in c and len(line) >= COMPACT_LINE_LIMIT:
+                c[k] = {"see": "bench_detail.json"}
+                line = json.dumps(c, separators=(",", ":"))
+    assert len(line) < COMPACT_LINE_LIMIT, len(line)
+    return line
+
+
+def emit(out):
+    """Detail to bench_detail.json (+ '#detail <section> <json>' stdout lines, so a log of the run still holds everything), then
+    the compact line as the LAST line of stdout."""
+    try:
+        with open(os.path.join(os.environ.get("BANET_BENCH_DETAIL_DIR", ROOT), "bench_detail.json"), "w") as f:
+            json.dump(out, f, indent=1)
+    except OSError as e:
+        print("#detail-file not written: %s" % e, flush=True)
+    for k in ("roofline", "check", "parity", "cpu_baseline"):
+        if k in out:
+            print("#detail %s %s" % (k, json.dumps(out[k])), flush=True)
+    for name, rec in (out.get("sweep") or {}).items():
+        print("#detail sweep.%s %s" % (name, json.dumps(rec)), flush=True)
+    print(compact_record(out), flush=True)
+
+
 def self_launch(args, argv):
     """`python bench.py --gpus N` outside a torch.distributed environment: become the launcher of N ranks on this node."""
     import socket
@@ -610,15 +686,15 @@ def main():
                            ("B8_2frame",           2,   8,  H,   W,    K,   10,  5,    1,   None),
                            ("cfg3_5frame_B32",     5,   32, H,   W,    K,   10,  5,    1,   None)]
                 if not args.no_sweep_large:      # 161 GB / 67 GB of inputs in the 288 GB of HBM
-                    entries += [("B256_2frame",    2,   256, H,  W,    K,   10,  2,    1,   None),
-                                ("cfg5_8frame_1280x960_K256_B8", 8, 8, 960, 1280, 256, 15, 2, 1, None)]
+                    entries += [("B256_2frame",    2,   256, H,  W,    K,   10,  3,    1,   None),
+                                ("cfg5_8frame_1280x960_K256_B8", 8, 8, 960, 1280, 256, 15, 3, 1, None)]
                 for name, fr, bb, hh, ww, kk, it, stp, wu, sc in entries:
                     sweep[name] = sub_record(fr, bb, hh, ww, kk, it, stp, wu, 4321, dev, fence, args.reserved, sc, par)
                 out["sweep"] = sweep
                 out["co_headline"] = {"cfg3_5frame_B32": {k: sweep["cfg3_5frame_B32"][k] for k in ("value", "unit", "ms_per_step", "steps")},
                                       "note": "configs[2] is the only configuration BASELINE.json quotes literally at batch 32 on one "
                                               "MI355X; reported beside the 2-frame headline"}
-        print(json.dumps(out), flush=True)
+        emit(out)
         bad = []
         if "parity" in out and not out["parity"]["ok"]:
             bad.append(("headline", out["parity"]))

@@ -276,3 +276,35 @@ def test_bench_roofline_record_arithmetic():
     assert m["bound"] == "mfma" and m["peak"] == 2500.0 and m["peak_fp32_matrix_TFLOPs"] == 157.3
     assert abs(m["algorithmic_fp32_TFLOPs"] - flops / 1.0 / 1e9) < 0.06
     assert abs(m["achieved"] - executed / 1.0 / 1e9) < 0.06 and abs(m["frac"] - m["achieved"] / 2500.0) < 1e-3
+
+
+def test_bench_compact_line_stays_under_4_kb(tmp_path, capsys, monkeypatch):
+    """bench.py's LAST stdout line is the driver's record: one JSON object < 4 KB with the contract's fields, `roofline` and
+    `cpu_baseline` (BENCH_r03's 38 KB line was not parseable); the full record goes to bench_detail.json and '#detail' lines.
+    Stubbed run: the full record of a real run (profiles/r03_run28_bench.json), bloated further."""
+    import json
+    sys.path.insert(0, ROOT) if ROOT not in sys.path else None
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r03_run28_bench.json")))
+    for i in range(12):         # a sweep twice as long as today's
+        full["sweep"]["extra_%d" % i] = dict(full["sweep"]["B8_2frame"])
+    monkeypatch.setenv("BANET_BENCH_DETAIL_DIR", str(tmp_path))
+    bench.emit(full)
+    lines = capsys.readouterr().out.strip().split("\n")
+    last = lines[-1]
+    assert len(last) < 4096 and all(l.startswith("#detail") for l in lines[:-1])
+    rec = json.loads(last)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "parity", "sweep"):
+        assert k in rec, k
+    assert "workload" in rec["config"] and "model" not in rec["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rec["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in rec["cpu_baseline"], k
+    assert rec["value"] == full["value"] and rec["roofline"]["frac"] == full["roofline"]["frac"]
+    assert json.load(open(tmp_path / "bench_detail.json"))["sweep"].keys() == full["sweep"].keys()
+    # a record too large even in compact form degrades to pointers instead of growing
+    for i in range(200):
+        full["sweep"]["more_%d" % i] = dict(full["sweep"]["B8_2frame"])
+    assert len(bench.compact_record(full)) < 4096
