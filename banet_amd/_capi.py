@@ -66,6 +66,7 @@ EXPORTS = {
     "banet_sample_stats_grad_f32": (ctypes.c_int, [_FP] * 4 + [ctypes.c_int] * 5 + [_FP] * 6),
     "banet_ba_assemble_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Level)]),
     "banet_ba_assemble_f32": (ctypes.c_int, [ctypes.POINTER(Level)] + [_FP] * 7 + [_FP, ctypes.c_size_t, _FP]),
+    "banet_ba_assemble_mask_f32": (ctypes.c_int, [ctypes.POINTER(Level)] + [_FP] * 8 + [_FP, ctypes.c_size_t, _FP]),
     "banet_ba_solve_update_f32": (ctypes.c_int, [ctypes.POINTER(Level), ctypes.POINTER(Mlp), ctypes.c_float] + [_FP] * 4 +
                                   [ctypes.POINTER(State), _FP]),
     "banet_ba_solve_update_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Level)]),

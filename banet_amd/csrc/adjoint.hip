@@ -1466,7 +1466,7 @@ __global__ __launch_bounds__(kBlock) void sstats_rows_kernel(const float* __rest
 
 static void launch_adj_map(const AdjArgs& a, int C, dim3 grid, dim3 block, hipStream_t s) {
   const int C3 = 3 * C, J3 = (C3 + 63) / 64;
-  const bool half = (C3 & 3) == 0 && !(a.lv.reserved_ & 524288);   // bit 19: one texel per wave (A/B)
+  const bool half = (C3 & 3) == 0 && !(a.lv.reserved_ & (1 << 28));   // bit 28: one texel per wave (A/B; bits 18 / 19 belong to the forward's gather selection)
   if (J3 <= 3) {
     if (half)
       hipLaunchKernelGGL((adj_map2_kernel<2, 3>), grid, block, 0, s, a);
@@ -1617,7 +1617,7 @@ int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T
       break;
     default: return BANET_ERR_UNSUPPORTED;
   }
-  if ((lv->C & 3) == 0 && (K & 3) == 0 && lv->C <= 128 && K <= 128 && !(lv->reserved_ & 262144)) {   // bit 18: one pixel per wave (A/B)
+  if ((lv->C & 3) == 0 && (K & 3) == 0 && lv->C <= 128 && K <= 128 && !(lv->reserved_ & (1 << 27))) {   // bit 27: one pixel per wave (A/B)
     hipLaunchKernelGGL((adj_pixel2_kernel<1>), dim3(pl.G, B), dim3(kBlock), 0, s, a);   // (C = 256: 264 B of spills -> the one-pixel kernel)
   } else {
     const int CJ = (lv->C + 63) / 64, KJ = std::max(1, (K + 63) / 64);

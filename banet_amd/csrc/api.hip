@@ -168,6 +168,20 @@ int banet_ba_assemble_f32(const banet_level_t* lv, const float* R, const float* 
                          static_cast<hipStream_t>(stream));
 }
 
+int banet_ba_assemble_mask_f32(const banet_level_t* lv, const float* R, const float* T, const float* Wc, float* AtA,
+                               float* Atb, float* absres, float* nvalid, unsigned char* mask_out, void* ws, size_t ws_bytes,
+                               banet_stream_t stream) {
+  int rc = check_level(lv);
+  if (rc != BANET_OK) return rc;
+  if (!R || !T || !AtA || !Atb || !absres || !nvalid || !mask_out || (lv->K > 0 && !Wc)) return BANET_ERR_INVALID_ARG;
+  AsmPlan pl;
+  rc = plan_assemble(lv, &pl);
+  if (rc != BANET_OK) return rc;
+  if (!ws || ws_bytes < pl.ws_bytes || !aligned256(ws)) return BANET_ERR_WORKSPACE;
+  return launch_assemble(lv, pl, R, T, Wc, nullptr, 0, ws, AtA, Atb, absres, nvalid, static_cast<hipStream_t>(stream), true,
+                         nullptr, nullptr, mask_out);
+}
+
 int banet_ba_solve_update_f32(const banet_level_t* lv, const banet_mlp_t* mlp, float l2_base, const float* AtA,
                               const float* Atb, const float* absres, const float* nvalid, banet_state_t* st,
                               banet_stream_t stream) {
@@ -276,11 +290,11 @@ int banet_lm_level_ex_f32(const banet_level_t* lv, const banet_mlp_t* mlp, float
     // need CUs of their own -- at B = 32 (8 + 1 workgroups per window = 288 > 256 CUs) a second round of workgroups doubled
     // the SYRK time (640x480 x 32: 1326 -> 2457 us); with B <= 8 one SYRK workgroup per window is given up where needed.
     const bool role = lv->variant == BANET_BUNDLE && mlp != nullptr && a.use_mlp && syrk_runs_mlp_role(pl.s) && lv->C <= 256 &&
-                      (lv->C & 3) == 0 && ((long long)lv->B * (pl.s.Gs + 1) <= 256 || (lv->B <= 8 && pl.s.Gs >= 16)) &&
+                      (lv->C & 3) == 0 && ((long long)lv->B * (pl.s.Gs + 1) <= num_cus() || (lv->B <= 8 && pl.s.Gs >= 16)) &&
                       !(lv->reserved_ & 32768);   // reserved_ bit 15: MLP inside the solve kernel (A/B)
     if (role) {
       a.mlp_y = w.mlp_y;
-      if ((long long)lv->B * (pl.s.Gs + 1) > 256) pl.s.Gs -= 1;
+      if ((long long)lv->B * (pl.s.Gs + 1) > num_cus()) pl.s.Gs -= 1;
     }
     for (int it = 0; it < max_iters; ++it) {
       rc = launch_assemble(lv, pl, st->R, st->T, st->Wc, nullptr, 0, w.partials, w.AtA, w.Atb, w.absres, w.nvalid, s,

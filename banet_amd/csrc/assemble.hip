@@ -2,6 +2,7 @@
 // reductions, pose block) + ba_fold_kernel + a SYRK kernel (syrk*.hip; depth-basis blocks on the matrix cores) +
 // ba_reduce2_kernel (fixed-order sum of the per-tile / per-workgroup partials).  Also hosts the optional
 // launch timer behind banet_profile_begin/_end.
+#include <atomic>
 #include <dlfcn.h>
 
 #include <cstdio>
@@ -115,6 +116,25 @@ int profile_end(int max_tags, int32_t* tag_points, int32_t* tag_launches, double
   return BANET_OK;
 }
 
+int num_cus() {
+  constexpr int kMaxDev = 64, kDefault = 256;
+  static std::atomic<int> cached[kMaxDev];        // 0 = not queried yet
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) {
+    (void)hipGetLastError();
+    return kDefault;
+  }
+  int n = cached[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+      (void)hipGetLastError();
+      n = kDefault;
+    }
+    cached[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+
 int plan_assemble(const banet_level_t* lv, AsmPlan* pl) {
   int rc = plan_gather(lv, &pl->g);
   if (rc != BANET_OK) return rc;
@@ -134,7 +154,8 @@ int* assemble_queue(const AsmPlan& pl, void* ws) {
 // tags for the profiler: +N = gather kernel at a level with N points, -N = syrk kernel
 int launch_assemble(const banet_level_t* lv, const AsmPlan& pl, const float* R, const float* T, const float* Wc,
                     const int32_t* active, int active_stride, void* ws, float* AtA, float* Atb, float* absres,
-                    float* nvalid, hipStream_t s, bool reset_queue, const banet_mlp_t* role_mlp, float* role_y) {
+                    float* nvalid, hipStream_t s, bool reset_queue, const banet_mlp_t* role_mlp, float* role_y,
+                    unsigned char* mask_out) {
   char* base = static_cast<char*>(ws);
   float* gpart = reinterpret_cast<float*>(base);
   float* rec = lv->K > 0 ? reinterpret_cast<float*>(base + pl.off_rec) : nullptr;
@@ -144,7 +165,7 @@ int launch_assemble(const banet_level_t* lv, const AsmPlan& pl, const float* R, 
   {
     RangeScope r("gather", lv->N);
     Timed t(s, lv->N);
-    rc = launch_gather(lv, pl.g, R, T, Wc, active, active_stride, rec, gpart, s);
+    rc = launch_gather(lv, pl.g, R, T, Wc, active, active_stride, rec, gpart, s, mask_out);
   }
   if (rc != BANET_OK) return rc;
   const float* gred;

@@ -38,5 +38,5 @@ done
 [ "$fail" = 0 ] || exit 1
 OBJS=""
 for f in $SRCS; do OBJS="$OBJS $OUT/$f.o"; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libbanet_hip.so" $OBJS
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libbanet_hip.so" $OBJS -ldl   # dlopen of the roctx marker library (assemble.hip)
 echo "built $OUT/libbanet_hip.so"

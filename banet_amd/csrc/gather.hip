@@ -25,6 +25,7 @@
 //      flight per wave; the five channel sums per pixel go through the same butterfly so that
 //      pixel j's sums land on lane j;
 //   4. 6x6 algebra with lane = pixel; H_cc in LDS accumulators (ds_add_f32, one owner per address).
+#include <algorithm>
 #include "gather_common.hpp"
 
 #ifndef BANET_GATHER_WAVES
@@ -375,6 +376,7 @@ __global__ __launch_bounds__(kBlock, BANET_GATHER_WAVES) void ba_gather_kernel(c
 #pragma unroll
       for (int i = 0; i < 6; ++i) atomicAdd(&sH[w][21 + i][lane], jc[i] * q.g1 + jc[6 + i] * q.g2);
       atomicAdd(&sH[w][27][lane], (float)(gflags & 1));
+      if (a.mask_out != nullptr && valid) a.mask_out[(size_t)vb * N + pt] = (unsigned char)(gflags & 1);
       if constexpr (KCH > 0) {
         if (valid) {
           const float md0 = q.m11 * jd0 + q.m12 * jd1, md1 = q.m12 * jd0 + q.m22 * jd1;
@@ -430,7 +432,6 @@ __global__ __launch_bounds__(kBlock, BANET_GATHER_WAVES) void ba_gather_kernel(c
 // --------------------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------------------
-constexpr int kCUs = 256;
 constexpr int kStripSegW = 16, kStripSegH = 32, kStripMinW = 21;   // = kStripW, kStripH, kWinTex of strip_plan.hpp (gather128s.hip)
 constexpr int kGenericBlocksPerCU = BANET_GATHER_WAVES;  // ba_gather_kernel: launch bounds
 constexpr int kC128BlocksPerCU = BANET_G128_WAVES;       // ba_gather128_kernel: launch bounds (LDS: 18 KB)
@@ -441,6 +442,7 @@ static bool use_c128(const banet_level_t* lv) {
 }
 
 int plan_gather(const banet_level_t* lv, GatherPlan* pl) {
+  const int kCUs = num_cus();
   if (!lv || lv->B <= 0 || lv->N <= 0 || lv->C <= 0 || lv->K < 0 || lv->H < 4 || lv->W < 4) return BANET_ERR_INVALID_ARG;
   if (lv->C > 256 || lv->K > 256) return BANET_ERR_UNSUPPORTED;
   if (lv->dense && lv->N != lv->H * lv->W) return BANET_ERR_INVALID_ARG;
@@ -458,6 +460,7 @@ int plan_gather(const banet_level_t* lv, GatherPlan* pl) {
   // where a launch has at least 4 segments per resident wave (coarser items than the 8x8 tiles: below that the tail of the
   // last round costs more than the halo saves).  reserved_ bit 18: force it at any size (parity tests); bit 19: off (A/B).
   pl->strip = 0;
+  pl->strip_fp = 0;
   if (pl->c128 && lv->dense && !(lv->reserved_ & 524288) && lv->W >= kStripMinW && lv->W < 4096 && lv->H < 4096 &&
       (size_t)lv->N * lv->C * 4 < ((size_t)1 << 31)) {
     // segment height: 16 rows.  32-row segments fetch less (target rows 35/32 x instead of 19/16 x: launch 1.12 x vs 1.16 x the
@@ -469,17 +472,25 @@ int plan_gather(const banet_level_t* lv, GatherPlan* pl) {
     const int syn = (lv->H + segh - 1) / segh;
     // (A single resident round at tiny batches -- every segment on a wave of its own -- does not pay: one segment is a serial chain
     // of ~200-270 us whatever the load; batch 1: 640x480 270 vs 272 us, 320x240 205 vs 168 us for the tile kernels.)
-    if ((long long)sxn * syn * lv->B >= 4LL * kCUs * 8 || (lv->reserved_ & 262144)) {
+    // multi-frame windows: frame-parallel workgroups (gather128s.hip, FP) -- `pairs` waves per segment, so a launch has
+    // 2048 / pairs resident work-item slots instead of 2048.  reserved_ bit 22: the frames looped over inside one wave (A/B).
+    const int np = npairs(lv);
+    const bool fp = np >= 2 && np <= 7 && segh == kStripSegH / 2 && !(lv->reserved_ & (1 << 22));
+    const int fp_wg_per_cu = fp ? (int)std::min<size_t>(8 / np, (size_t)(160 * 1024) / (((size_t)np * (7 * 21 * 32 + 128) + 4 * 64 + 4) * 4)) : 0;
+    const long long slots = fp ? (long long)kCUs * fp_wg_per_cu : (long long)kCUs * 8;
+    pl->strip_fp = 0;
+    if ((long long)sxn * syn * lv->B >= 4LL * slots || (lv->reserved_ & 262144)) {
       pl->strip = segh;
+      pl->strip_fp = fp ? 1 : 0;
       pl->tiles_x = sxn;
       pl->tiles_y = syn;
       pl->tiles = sxn * syn;
       pl->patch = 0;
       pl->pairloop = 1;
       pl->qshift = 0;
-      const int resident = kCUs * 4;                 // 128-thread workgroups, 4 per CU (2 waves per SIMD)
+      const int resident = fp ? kCUs * fp_wg_per_cu : kCUs * 4;   // 128-thread workgroups, 4 per CU (2 waves per SIMD); FP: by LDS / waves
       int G = (resident + lv->B - 1) / lv->B;
-      const int want = (pl->tiles + 1) / 2;          // one item per wave at least
+      const int want = fp ? pl->tiles : (pl->tiles + 1) / 2;      // one item per wave (FP: per workgroup) at least
       if (G > want) G = want;
       if (G < 1) G = 1;
       pl->G = G;
@@ -613,7 +624,7 @@ static int launch_c(const GatherArgs& a, int C, int K, hipStream_t s) {
 }
 
 int launch_gather(const banet_level_t* lv, const GatherPlan& pl, const float* R, const float* T, const float* Wc,
-                  const int32_t* active, int active_stride, float* rec, float* partials, hipStream_t s) {
+                  const int32_t* active, int active_stride, float* rec, float* partials, hipStream_t s, unsigned char* mask_out) {
   GatherArgs a;
   a.lv = *lv;
   a.R = R;
@@ -634,6 +645,8 @@ int launch_gather(const banet_level_t* lv, const GatherPlan& pl, const float* R,
   a.qshift = pl.qshift;
   a.pairloop = pl.pairloop;
   a.seg_h = pl.strip;
+  a.strip_fp = pl.strip_fp;
+  a.mask_out = mask_out;
   int rc;
   if (pl.c128)
     rc = pl.strip ? launch_gather128s(a, lv->K, s) : pl.patch ? launch_gather128p(a, lv->K, s) : launch_gather128(a, lv->K, s);

@@ -397,6 +397,7 @@ __global__ __launch_bounds__(kBlock, BANET_G128_WAVES) void ba_gather128_kernel(
 #pragma unroll
       for (int i = 0; i < 6; ++i) carry_push_n<5, 32>(pend, jc[i] * q.g1 + jc[6 + i] * q.g2, 21 + i);
       carry_push_n<5, 32>(pend, (float)(gflags & 1), 27);
+      if (a.mask_out != nullptr && valid && mine) a.mask_out[(size_t)vb * N + pt] = (unsigned char)(gflags & 1);
 #pragma unroll
       for (int i = 28; i < 32; ++i) carry_push_n<5, 32>(pend, 0.f, i);
       float tot = pend[5];

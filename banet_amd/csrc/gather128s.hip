@@ -293,17 +293,33 @@ __device__ __forceinline__ void strip_geometry(const banet_level_t& lv, int b, c
 // KV4 = number of 128-coefficient chunks of a basis row (0: pose only; K % 4 == 0, K <= 128 KV4)
 // NCH = chunks per segment: 8 (16 x 32 pixels, target rows fetched 35/32 x) where a launch has enough of them to fill the
 // chip evenly, 4 (16 x 16 pixels, 19/16 x) on launches with fewer, coarser items (gather.hip::plan_gather)
-template <int KV4, int NCH>
-__global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVgprs / 2))) void ba_gather128s_kernel(const GatherArgs a) {
+// FP ("frame-parallel", multi-frame windows): a workgroup is `pairs` waves that process the SAME segment at the same time, wave p
+// against target frame p.  The key frame's data is then fetched from HBM once per window instead of once per target frame: the
+// depth dot (the basis rows) is divided among the waves and shared through LDS, and the source rows, which every wave still
+// loads into its own registers, are requested by all `pairs` waves of a CU within the same few microseconds -- one fabric read,
+// the others hit the L2.  (Looping over the frames inside one wave -- the other mode -- re-reads them ~150 us apart, by which
+// time the chip has moved hundreds of MB: 29 % of a 5-frame window's traffic.)  Two workgroup barriers per segment (item
+// broadcast, depth hand-over), none inside the counted section.
+extern __shared__ __attribute__((aligned(16))) float sDynS[];
+constexpr int kSWaveLdsFloats = kWinFloats + kC128s;     // per wave: the rolling window + row statistics / sum|d|
+inline size_t strip_fp_lds_bytes(int pairs, int nch) { return ((size_t)pairs * kSWaveLdsFloats + (size_t)nch * 64 + 4) * sizeof(float); }
+
+template <int KV4, int NCH, bool FP>
+__global__ __launch_bounds__(FP ? 512 : kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVgprs / 2))) void ba_gather128s_kernel(const GatherArgs a) {
   constexpr int SEGH = 4 * NCH;          // pixel rows per segment
   constexpr int NH = NCH / 4;            // groups of four chunks
-  __shared__ __attribute__((aligned(16))) float sWin[kSWaves][kWinFloats];    // the rolling window: [slot][texel][32 channels]
-  __shared__ __attribute__((aligned(16))) float sScr[kSWaves][kC128s];        // row statistics (plan input), later C x sum|d|
+  __shared__ __attribute__((aligned(16))) float sWinS[FP ? 1 : kSWaves][FP ? 4 : kWinFloats];    // the rolling window: [slot][texel][32 channels]
+  __shared__ __attribute__((aligned(16))) float sScrS[FP ? 1 : kSWaves][FP ? 4 : kC128s];        // row statistics (plan input), later C x sum|d|
   const banet_level_t& lv = a.lv;
   const int b = blockIdx.y;
   if (a.active != nullptr && a.active[(size_t)b * a.active_stride] == 0) return;
   const int lane = threadIdx.x & 63;
   const int w = wave_id();
+  [[maybe_unused]] const int nw = FP ? a.pairs : kSWaves;                           // waves per workgroup
+  float* const sWinW = FP ? sDynS + (size_t)w * kSWaveLdsFloats : &sWinS[FP ? 0 : w][0];
+  float* const sScrW = FP ? sWinW + kWinFloats : &sScrS[FP ? 0 : w][0];
+  [[maybe_unused]] float* const sDep = sDynS + (size_t)nw * kSWaveLdsFloats;        // FP: [NCH][64] depths of the segment
+  [[maybe_unused]] int* const sItem = reinterpret_cast<int*>(sDep + NCH * 64);      // FP: [2] the segment index, ping-pong
   const int N = lv.N, K = lv.K, H = lv.H, W = lv.W;
   constexpr int C = kC128s;
   const float* __restrict__ src_b = lv.src + (size_t)b * N * C;
@@ -318,10 +334,10 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
   const int jA = 4 * hA + oc, jB = 4 * (1 - hA) + oc;
   const int half = lane >> 5, li = lane & 31;     // depth dot: one basis row per half wave
   // lane = pixel phases: this lane owns pixel (row oc, column pc) of a chunk (4 pixel rows x 16)
-  const unsigned win_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&sWin[w][0];
+  const unsigned win_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)sWinW;
   const unsigned dma_off = (unsigned)((lane >> 3) * 512 + (lane & 7) * 16);   // LDS-DMA: (texel lane >> 3 of an 8-texel run, piece lane & 7)
   const unsigned srcA_off = (unsigned)(pc * 512 + jA * 16), srcB_off = (unsigned)(pc * 512 + jB * 16);
-  StripRowStat* sStat = reinterpret_cast<StripRowStat*>(&sScr[w][0]);
+  StripRowStat* sStat = reinterpret_cast<StripRowStat*>(sScrW);
 
   float wreg[KV4 ? KV4 : 1][4];  // this lane's slice of the depth coefficients
   if constexpr (KV4 > 0) {
@@ -341,12 +357,19 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
     if (lane == 0) v = atomicAdd(&queue[0], 1);
     return v;
   };
-  int raw_next = pop_raw();
+  int raw_next = (!FP || w == 0) ? pop_raw() : 0;
 
-  while (true) {
-    const int wi = rfl(raw_next);
+  for (int it = 0;; ++it) {
+    int wi;
+    if constexpr (FP) {     // wave 0 pops for the workgroup
+      if (w == 0 && lane == 0) sItem[it & 1] = raw_next;
+      __syncthreads();
+      wi = rfl(sItem[it & 1]);
+    } else {
+      wi = rfl(raw_next);
+    }
     if (wi >= nitems) return;
-    raw_next = pop_raw();  // issued now, read at the top of the next item
+    if (!FP || w == 0) raw_next = pop_raw();  // issued now, read at the top of the next item
     const int sx = wi / segs_y, sy = wi - sx * segs_y;
     const int px = sx * kStripW + pc;                         // this lane's pixel column (all chunks)
     const int py0 = sy * SEGH + oc;                        // its pixel row in chunk 0 (+ 4 per chunk)
@@ -391,6 +414,36 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
           carry_push_s<5, 16>(pend, acc, RB * hb + i);
         }
       };
+      if constexpr (FP) {
+        // chunk c is computed by wave c mod nw and handed to the others through LDS
+        if (w < NCH) issue_batch(IC<0>{}, w, 0);
+#pragma unroll 1
+        for (int c = w; c < NCH; c += nw) {
+          const int py = py0 + 4 * c;
+          const bool valid = (px < W) && (py < H);
+          float D = valid ? dep_b[py * W + px] : 0.f;
+          float pend[6];
+#pragma unroll
+          for (int hb = 0; hb < NB; ++hb) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (hb + 1 < NB) {
+              if ((hb & 1) == 0) issue_batch(IC<1>{}, c, hb + 1);
+              else issue_batch(IC<0>{}, c, hb + 1);
+            } else if (c + nw < NCH) {
+              issue_batch(IC<0>{}, c + nw, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if ((hb & 1) == 0) reduce_batch(IC<0>{}, pend, hb);
+            else reduce_batch(IC<1>{}, pend, hb);
+          }
+          sDep[c * 64 + lane] = D + pend[5];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh)
+#pragma unroll
+          for (int c4 = 0; c4 < 4; ++c4) Dv[hh][c4] = sDep[(4 * hh + c4) * 64 + lane];
+      } else {
       issue_batch(IC<0>{}, 0, 0);
 #pragma unroll
       for (int hh = 0; hh < NH; ++hh)
@@ -417,6 +470,7 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
         D += pend[5];
         Dv[hh][c4] = D;
       }
+      }
     } else {
 #pragma unroll
       for (int hh = 0; hh < NH; ++hh)
@@ -431,7 +485,7 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
 
     BANET_TICK(ts1);
 #pragma unroll 1
-    for (int pr = 0; pr < a.pairs; ++pr) {   // target frames of the window: same pixels, depth and source features
+    for (int pr = FP ? w : 0; pr < (FP ? w + 1 : a.pairs); ++pr) {   // target frames of the window: same pixels, depth and source features (FP: this wave's frame)
       const int vb = b * a.pairs + pr;
       const float* __restrict__ tgt_b = lv.tgt + (size_t)vb * H * W * C;
       float* __restrict__ rec_b = KV4 ? a.rec + (size_t)vb * N * 8 : nullptr;
@@ -528,6 +582,9 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
           if (lane < ncol3) glds16(gb + 16 * C, dma_off, dst + 2048u);
         };
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the counted section starts with nothing in flight
+        if constexpr (FP) {
+          if (lv.reserved_ & (1 << 24)) __syncthreads();     // A/B: the waves of a segment start every slice in phase
+        }
         {
           const int c0 = __builtin_amdgcn_readlane(plan_ctl, 0), c1 = __builtin_amdgcn_readlane(plan_ctl, 1);
           if (step_src_pre(c0)) {
@@ -590,7 +647,7 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
               const int m1i = m0 + 1 >= kWinRows ? m0 + 1 - kWinRows : m0 + 1;
               const int m2i = m1i + 1 >= kWinRows ? m1i + 1 - kWinRows : m1i + 1;
               const int m3i = m2i + 1 >= kWinRows ? m2i + 1 - kWinRows : m2i + 1;
-              const float* l = &sWin[w][0] + xr * 32;
+              const float* l = sWinW + xr * 32;
               const float* l0 = l + m0 * kWinPitchF;
               const float* l1 = l + m1i * kWinPitchF;
               const float* l2 = l + m2i * kWinPitchF;
@@ -665,8 +722,8 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
             hi += __shfl_xor(hi, sh, 64);
           }
           if (lane < 4) {
-            sScr[w][32 * s + 4 * oc + e] = lo;
-            sScr[w][32 * s + 16 + 4 * oc + e] = hi;
+            sScrW[32 * s + 4 * oc + e] = lo;
+            sScrW[32 * s + 16 + 4 * oc + e] = hi;
           }
         }
       }
@@ -736,6 +793,7 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
 #pragma unroll
           for (int i = 0; i < 6; ++i) accp[21 + i] += jc[i] * qv.g1 + jc[6 + i] * qv.g2;
           accp[27] += (float)(ge.flags & 1);
+          if (a.mask_out != nullptr && valid) a.mask_out[(size_t)vb * N + pt] = (unsigned char)(ge.flags & 1);
         }
 
         if constexpr (KV4 > 0) {
@@ -770,10 +828,10 @@ __global__ __launch_bounds__(kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVg
         if ((lane & 1) == 0 && leaf < 28) part[leaf] = tot;
       }
       // ---- 5. the segment's C x sum|d| ----------------------------------------------------------------------------------------
-      sScr[w][2 * lane] += absd2[0][0];       // same wave: LDS operations retire in program order
-      sScr[w][2 * lane + 1] += absd2[0][1];
-      part[kGHdr + lane] = sScr[w][lane];
-      part[kGHdr + 64 + lane] = sScr[w][64 + lane];
+      sScrW[2 * lane] += absd2[0][0];       // same wave: LDS operations retire in program order
+      sScrW[2 * lane + 1] += absd2[0][1];
+      part[kGHdr + lane] = sScrW[lane];
+      part[kGHdr + 64 + lane] = sScrW[64 + lane];
 #ifdef BANET_TIMING   // tools/time_strip.py: cycles of this segment (the last target frame of the window)
       {
         BANET_TICK(ts9);
@@ -798,10 +856,28 @@ int launch_gather128s(const GatherArgs& a, int K, hipStream_t s) {
   dim3 grid(a.G, a.lv.B), block(kSBlock);
   const bool tall = a.seg_h == 32;
   if (a.seg_h != 32 && a.seg_h != 16) return BANET_ERR_INVALID_ARG;
+  if (a.strip_fp) {    // frame-parallel workgroups: `pairs` waves, dynamic LDS (16-row segments only)
+    if (tall || a.pairs < 2 || a.pairs > 7) return BANET_ERR_INVALID_ARG;
+    const size_t shm = strip_fp_lds_bytes(a.pairs, 4);
+    block = dim3(64 * a.pairs);
+#define BANET_LAUNCH_FP(KV4)                                                                                              \
+  do {                                                                                                                    \
+    if (shm > 64 * 1024)                                                                                                  \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_gather128s_kernel<KV4, 4, true>),                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                                    \
+    hipLaunchKernelGGL((ba_gather128s_kernel<KV4, 4, true>), grid, block, shm, s, a);                                     \
+  } while (0)
+    if (K == 0) BANET_LAUNCH_FP(0);
+    else if ((K & 3) == 0 && K <= 128) BANET_LAUNCH_FP(1);
+    else if ((K & 3) == 0 && K <= 256) BANET_LAUNCH_FP(2);
+    else return BANET_ERR_UNSUPPORTED;
+#undef BANET_LAUNCH_FP
+    return BANET_OK;
+  }
 #define BANET_LAUNCH_S(KV4)                                                                     \
   do {                                                                                          \
-    if (tall) hipLaunchKernelGGL((ba_gather128s_kernel<KV4, 8>), grid, block, 0, s, a);         \
-    else hipLaunchKernelGGL((ba_gather128s_kernel<KV4, 4>), grid, block, 0, s, a);              \
+    if (tall) hipLaunchKernelGGL((ba_gather128s_kernel<KV4, 8, false>), grid, block, 0, s, a);  \
+    else hipLaunchKernelGGL((ba_gather128s_kernel<KV4, 4, false>), grid, block, 0, s, a);       \
   } while (0)
   if (K == 0) BANET_LAUNCH_S(0);
   else if ((K & 3) == 0 && K <= 128) BANET_LAUNCH_S(1);

@@ -21,6 +21,8 @@ struct GatherArgs {
   int pairloop;     // ba_gather128p_kernel: 1 = grid y = window, the window's target frames are looped over inside a tile
   int qshift;       // ba_gather128_kernel: 0 = a work item is a tile, 2 = a quarter tile (small levels)
   int seg_h;        // ba_gather128s_kernel: pixel rows per strip segment (32 or 16)
+  unsigned char* mask_out;   // optional (parity diagnostics): [B * pairs][N] the in-image mask bit of every pixel, or nullptr
+  int strip_fp;     // ba_gather128s_kernel: 1 = frame-parallel workgroups (`pairs` waves per segment, one per target frame)
 };
 
 template <int VEC>

@@ -9,6 +9,10 @@ constexpr int kUStrideS = 8;    // per-pixel record: u0..u5, s, r
 
 inline int npairs(const banet_level_t* lv) { return lv->pairs > 1 ? lv->pairs : 1; }
 
+// compute units of the current device (hipDeviceAttributeMultiprocessorCount, queried once per device; 256 = MI355X when no
+// device is visible, e.g. the host-only plan / workspace arithmetic of the CPU tests).  The launch plans size their grids by it.
+int num_cus();
+
 // ---- gather.hip ------------------------------------------------------------------------
 struct GatherPlan {
   int G, tiles, tiles_x, tiles_y, groups, pstride;
@@ -16,6 +20,7 @@ struct GatherPlan {
   int patch;    // 1: ba_gather128p_kernel (same interface; taps from wave-private LDS patches) for large levels
   int strip;    // ba_gather128s_kernel (work items = 16-pixel-wide strip segments, rolling LDS window): pixel rows per segment
                 //    (32 or 16; 0 = another kernel); tiles_x / tiles_y / tiles then count segments
+  int strip_fp; // strip kernel, multi-frame windows: a workgroup = `pairs` waves on one segment, wave p against target frame p
   int rows;     // partial rows per window written by the gather kernel (tiles or G)
   int frows;    // rows per window handed to ba_reduce2_kernel (after ba_fold_kernel when rows > kFoldRows)
   int nbands;   // tile-queue bands (8 = one per XCD)
@@ -30,7 +35,8 @@ int plan_gather(const banet_level_t* lv, GatherPlan* pl);
 // -> finish (fold the tile partials); `reduced` returns the rows ba_reduce2_kernel should read
 void prepare_gather(const banet_level_t* lv, const GatherPlan& pl, float* partials, hipStream_t s);
 int launch_gather(const banet_level_t* lv, const GatherPlan& pl, const float* R, const float* T, const float* Wc,
-                  const int32_t* active, int active_stride, float* rec, float* partials, hipStream_t s);
+                  const int32_t* active, int active_stride, float* rec, float* partials, hipStream_t s,
+                  unsigned char* mask_out = nullptr);
 const float* finish_gather(const banet_level_t* lv, const GatherPlan& pl, const int32_t* active, int active_stride,
                            float* partials, hipStream_t s);
 
@@ -74,7 +80,7 @@ int plan_assemble(const banet_level_t* lv, AsmPlan* pl);
 int launch_assemble(const banet_level_t* lv, const AsmPlan& pl, const float* R, const float* T, const float* Wc,
                     const int32_t* active, int active_stride, void* ws, float* AtA, float* Atb, float* absres,
                     float* nvalid, hipStream_t s, bool reset_queue = true, const banet_mlp_t* role_mlp = nullptr,
-                    float* role_y = nullptr);
+                    float* role_y = nullptr, unsigned char* mask_out = nullptr);
 int* assemble_queue(const AsmPlan& pl, void* ws);   // the gather's tile-queue heads inside the workspace (or nullptr)
 int profile_ranges(int enable);             // roctx ranges around the launches (banet_profile_ranges)
 struct RangeScope {                         // pushes "banet.<role>[ N=<n>]" when ranges are on

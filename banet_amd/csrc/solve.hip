@@ -773,7 +773,10 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve_update_kernel(const So
       // matrix in LDS: conjugate gradients on the damped block first (reads the matrix only), the LDL^T when they do not
       // converge (flags bit 23: LDL^T only, A/B and parity tests)
       bool cg_ok = false;
-      if (!(a.flags & (1 << 23))) cg_ok = pcg_schur_solve(smem, ld, P, a.variant == BANET_BUNDLE, sX, sCol);
+      // pcg_schur_solve covers 4 threads per row and needs 2 n1p + 8 kSolveWaves floats of scratch: larger systems (none is
+      // LDS-resident today: solve_lds_bytes stops at P ~ 190) go straight to the factorisation instead of dropping rows
+      const bool cg_fits = 4 * P <= kSolveThreads && 2 * ((P + 3) & ~3) + 8 * kSolveWaves <= solve_scratch_floats(P);
+      if (cg_fits && !(a.flags & (1 << 23))) cg_ok = pcg_schur_solve(smem, ld, P, a.variant == BANET_BUNDLE, sX, sCol);
       if (!cg_ok) ldlt_solve_blocked(smem, ld, P, sX, sCol);
     }
   }

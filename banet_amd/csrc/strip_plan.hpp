@@ -13,7 +13,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define BANET_HD __host__ __device__ __forceinline__
 #else
 #define BANET_HD inline

@@ -759,7 +759,7 @@ int plan_syrk(int B, int N, int K, int pairs, int dbg, SyrkPlan* pl) {
     return BANET_OK;
   }
   pl->tiles = (N + kTilePix - 1) / kTilePix;
-  // K = 64 / 128: barrier-free kernels, one wave per SIMD, 256 workgroups in all: 2 = ba_syrk_bf16x6_kernel
+  // K = 64 / 128: barrier-free kernels, one wave per SIMD, one workgroup per CU in all: 2 = ba_syrk_bf16x6_kernel
   // (default), 1 = ba_syrk_direct_kernel (fp32 MFMA; reserved_ bit 8, A/B only)
   pl->direct = ((K == 64 || K == 128) && pairs <= 4) ? ((dbg & 256) ? 1 : 2) : 0;
   // OPT-IN (reserved_ bit 29, K = 128): the three largest of the six products only -- a two-piece split, 16 significand bits per
@@ -768,7 +768,8 @@ int plan_syrk(int B, int N, int K, int pairs, int dbg, SyrkPlan* pl) {
   pl->x3 = (pl->direct == 2 && K == 128 && (dbg & (1 << 29))) ? 1 : 0;
   // K = 256, or K = 128 with more than 4 target frames: the job kernels of syrk_wide.hip (reserved_ bit 8: the LDS-tiled kernel, A/B)
   if (!(dbg & 256) && (K == 256 || (K == 128 && pairs > 4))) pl->direct = 3;
-  int target = (((pl->direct || pl->nb > 8) ? 256 : 512) + B - 1) / B;   // LDS kernel: 2 resident workgroups per CU (1 at K > 128)
+  const int cus = num_cus();
+  int target = (((pl->direct || pl->nb > 8) ? cus : 2 * cus) + B - 1) / B;   // LDS kernel: 2 resident workgroups per CU (1 at K > 128)
   int G = pl->direct ? (N + 4 * 4 * 16 - 1) / (4 * 4 * 16) : pl->tiles / 4;   // direct: >= 16 quads per wave
   if (G > target) G = target;
   if (G < 1) G = 1;

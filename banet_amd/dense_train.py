@@ -20,6 +20,8 @@ dL/dAtA_i = E_i^T (dL/dAtA) E_i, dL/dAtb_i = E_i^T dL/dAtb -- the source / depth
 target frame gets its own map adjoint and pose gradient.
 """
 import ctypes
+import os
+import warnings
 
 import torch
 
@@ -177,7 +179,7 @@ class _SmallStepGraph:
 
 
 _small_cache = {}          # shape key -> _SmallStepGraph (static buffers + a private graph memory pool each): bounded, see _small_step
-_SMALL_CACHE_MAX = 8
+_SMALL_CACHE_MAX = int(os.environ.get("BANET_SMALL_STEP_CACHE", "32"))   # >= levels x configurations in flight (5 levels x 2 configs = 10)
 
 
 def clear_small_step_cache():
@@ -198,7 +200,10 @@ def _small_step(tensors, N, l2_base, pairs=1, camera=False):
     if st is None:
         st = _SmallStepGraph([tuple(t.shape) for t in tensors], dev, N, l2_base, pairs, camera)
         while len(_small_cache) >= _SMALL_CACHE_MAX:          # least recently used first (dicts keep insertion order)
-            _small_cache.pop(next(iter(_small_cache)))
+            old = next(iter(_small_cache))
+            _small_cache.pop(old)
+            warnings.warn("banet_amd.dense_train: small-step graph cache full (%d entries): evicting %s; the next use of that shape "
+                          "re-captures its graph (raise BANET_SMALL_STEP_CACHE)" % (_SMALL_CACHE_MAX, old[0][0]), RuntimeWarning)
     _small_cache[key] = st
     return st(tensors)
 

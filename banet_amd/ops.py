@@ -254,8 +254,8 @@ class LevelProblem:
 
 
 GATHER_KERNELS = {0: "ba_gather_kernel", 1: "ba_gather128_kernel", 2: "ba_gather128p_kernel", 3: "ba_gather128s_kernel"}
-FORCE_PATCH_GATHER, FORCE_STRIP_GATHER = 512, 262144     # banet_level_t.reserved_ bits (parity checks at small batch sizes)
-SYRK_THREE_PRODUCTS = 1 << 29   # opt-in: the K = 128 SYRK with the three largest bf16 products only (~2^-16 per product instead of fp32-exact)
+FORCE_PATCH_GATHER, FORCE_STRIP_GATHER = 512, 262144     # banet_hip.h: BANET_DEV_FORCE_PATCH_GATHER / _STRIP_GATHER (parity checks at small batch sizes)
+SYRK_THREE_PRODUCTS = 1 << 29   # banet_hip.h: BANET_DEV_SYRK_THREE_PRODUCTS -- opt-in: the K = 128 SYRK with the three largest bf16 products only (~2^-16 per product instead of fp32-exact)
 
 
 def gather_selection(level):
@@ -266,8 +266,9 @@ def gather_selection(level):
     return rc
 
 
-def ba_assemble(level, R, T, Wc=None):
-    """banet_ba_assemble_f32 -> (AtA [B,P,P], Atb [B,P], absres [B,C], nvalid [B])."""
+def ba_assemble(level, R, T, Wc=None, return_mask=False):
+    """banet_ba_assemble_f32 -> (AtA [B,P,P], Atb [B,P], absres [B,C], nvalid [B]); return_mask: banet_ba_assemble_mask_f32,
+    additionally the in-image mask bit the kernel decided for every pixel, uint8 [B, pairs, N] (parity diagnostics)."""
     L = capi.lib()
     dev = level.device
     B, P, C = level.B, level.P, level.C
@@ -281,6 +282,13 @@ def ba_assemble(level, R, T, Wc=None):
     ws = capi.workspace(nb, dev)
     R, T = capi.f32c(R), capi.f32c(T)
     Wc = capi.f32c(Wc) if Wc is not None else None
+    if return_mask:
+        pairs = max(int(level.c.pairs), 1)
+        mask = torch.full((B, pairs, int(level.c.N)), 255, dtype=torch.uint8, device=dev)
+        capi.check(L.banet_ba_assemble_mask_f32(ctypes.byref(level.c), capi.ptr(R), capi.ptr(T), capi.ptr(Wc), capi.ptr(AtA),
+                                                capi.ptr(Atb), capi.ptr(absres), capi.ptr(nvalid), ctypes.c_void_p(mask.data_ptr()),
+                                                ctypes.c_void_p(ws.data_ptr()), ws.numel(), capi.stream()))
+        return AtA, Atb, absres, nvalid, mask
     capi.check(L.banet_ba_assemble_f32(ctypes.byref(level.c), capi.ptr(R), capi.ptr(T), capi.ptr(Wc), capi.ptr(AtA),
                                        capi.ptr(Atb), capi.ptr(absres), capi.ptr(nvalid),
                                        ctypes.c_void_p(ws.data_ptr()), ws.numel(), capi.stream()))

@@ -87,6 +87,18 @@ enum { /* banet_level_t.variant: which reference iteration is restated */
   BANET_BUNDLE = 3         /* bundlenet.py:193-278 BundleIteration (pose + depth basis)   */
 };
 
+/* Documented bits of banet_level_t.reserved_ (everything else is internal A/B plumbing and must be 0):
+ *   BANET_DEV_FORCE_PATCH_GATHER / _STRIP_GATHER : run that C = 128 gather kernel at any launch size (parity tests compare
+ *       the kernels at oracle sizes; banet_gather_selection reports what a level runs);
+ *   BANET_DEV_SYRK_THREE_PRODUCTS : OPT-IN, reduced precision -- the K = 128 depth-block contraction with the three largest
+ *       bf16 products only (~2^-16 per product instead of fp32-exact).  Never the default, never what bench.py's `value`
+ *       is measured with.                                                                                              */
+enum {
+  BANET_DEV_FORCE_PATCH_GATHER = 1 << 9,
+  BANET_DEV_FORCE_STRIP_GATHER = 1 << 18,
+  BANET_DEV_SYRK_THREE_PRODUCTS = 1 << 29
+};
+
 typedef struct banet_level {
   int32_t B;            /* windows                                                        */
   int32_t N;            /* points per window                                              */
@@ -108,7 +120,8 @@ typedef struct banet_level {
                            of SURVEY.md 8(d): the key frame carries depth / basis / Wc, every
                            other frame its own pose; P = 6 pairs + K, parameter order
                            [pose_1 .. pose_pairs, depth]                                     */
-  int32_t reserved_;    /* must be 0 (development switches)                               */
+  int32_t reserved_;    /* 0 in production; development switches (A/B kernel selection), of which
+                           the BANET_DEV_* bits below are the documented ones                  */
   int32_t pad_;         /* must be 0                                                      */
   const float* src;     /* dense: source map [B,H,W,C];  sparse: conv1 [B,N,C]            */
   const float* tgt;     /* target maps [B,pairs,H,W,C] or [B,pairs,H,W,3C]                */
@@ -154,6 +167,13 @@ size_t banet_ba_assemble_workspace_bytes(const banet_level_t* lv);
 int banet_ba_assemble_f32(const banet_level_t* lv, const float* R, const float* T,
                           const float* Wc, float* AtA, float* Atb, float* absres,
                           float* nvalid, void* ws, size_t ws_bytes, banet_stream_t stream);
+/* The same pass, additionally writing the in-image mask bit (bundlenet.py:155,231 / utils_python.py:61-117) the kernel decided
+ * for every pixel: mask_out [B * pairs][N] bytes, 1 = in the image.  A parity diagnostic (bench.py's sweep gate compares it
+ * bit by bit with the float64 oracle's mask, so that a float32-vs-float64 disagreement on a pixel sitting on the image border is
+ * demonstrated, not assumed); same kernels, same sums.                                                                        */
+int banet_ba_assemble_mask_f32(const banet_level_t* lv, const float* R, const float* T,
+                               const float* Wc, float* AtA, float* Atb, float* absres, float* nvalid,
+                               unsigned char* mask_out, void* ws, size_t ws_bytes, banet_stream_t stream);
 
 /* (4) lambda prediction + damping + solve + SE(3)/W update for all B windows
  *     (bundlenet.py:165-190,241-276; legacy/ba.py:187-213,266-302).  Consumes the outputs

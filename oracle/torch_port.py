@@ -45,11 +45,15 @@ def prepare_level(intr, scale, src, tgt, depth, basis, normalize_rays=True, dtyp
                 tmap=tmap, src=src.reshape(B, N, C), depth=depth, basis=f(basis).reshape(B, N, K) if K > 0 else None)
 
 
-def assemble_prepared(L, R, T, Wc, bundle, stats=None):
+def assemble_prepared(L, R, T, Wc, bundle, stats=None, mask_override=None):
     """-> AtA [B,P,P], Atb [B,P], absres [B,C], nvalid [B] at the pose (R, T, Wc); L = prepare_level(...).
     stats: optional dict; receives "borderline" [B] = pixels whose projection lies within 4e-6 x max(W, H) pixels of the
     in-image mask's boundary (bundlenet.py:155,231): at such a state float32 and float64 arithmetic can legitimately disagree
-    on the pixel's mask bit, which changes every sum by one pixel's worth (the parity gates account for it)."""
+    on the pixel's mask bit, which changes every sum by one pixel's worth (the parity gates account for it); "mask" (appended per
+    call) = this evaluation's own mask [B,N] as bool.
+    mask_override [B,N] (0/1): use THIS mask instead of the one the projection decides -- the parity gate evaluates the float64
+    statements with the mask bits the GPU kernel decided, so that both sides solve the same system even where a pixel sits on
+    the image border (taps of a pixel forced in are clamped like any other: utils_python.py:96-99)."""
     B, H, W, C, N, K = L["B"], L["H"], L["W"], L["C"], L["N"], L["K"]
     dtype = L["tmap"].dtype
     p, fx, fy, ox, oy = L["p"], L["fx"], L["fy"], L["ox"], L["oy"]
@@ -64,10 +68,18 @@ def assemble_prepared(L, R, T, Wc, bundle, stats=None):
     px, py = fx * x + ox, fy * y + oy
     mask = ((px >= 0) & (px <= W - 1) & (py >= 0) & (py <= H - 1)).to(dtype)
     if stats is not None:
+        stats.setdefault("mask", []).append(mask > 0)
+        stats.setdefault("pxy", []).append((px, py))
         e = 4e-6 * max(W, H)
         inx, iny = (px >= -e) & (px <= W - 1 + e), (py >= -e) & (py <= H - 1 + e)
         near = (((px.abs() < e) | ((px - (W - 1)).abs() < e)) & iny) | (((py.abs() < e) | ((py - (H - 1)).abs() < e)) & inx)
         stats["borderline"] = stats.get("borderline", 0) + near.sum(1)
+    if mask_override is not None:
+        forced = mask_override.to(device=px.device).reshape(B, N) > 0
+        # a pixel forced in samples at the border it sits on (its float32 projection is inside by definition)
+        px = torch.where(forced & (mask == 0), torch.minimum(torch.clamp(px, min=0.0), torch.full_like(px, W - 1)), px)
+        py = torch.where(forced & (mask == 0), torch.minimum(torch.clamp(py, min=0.0), torch.full_like(py, H - 1)), py)
+        mask = forced.to(dtype)
     pxs = torch.where(mask > 0, px, torch.zeros_like(px))
     pys = torch.where(mask > 0, py, torch.zeros_like(py))
     x0f, y0f = torch.floor(pxs), torch.floor(pys)
@@ -173,7 +185,8 @@ def bundle_iteration(intr, scale, src, tgt, depth, basis, R, T, Wc, mlp, l2_base
 # --------------------------------------------------------------------------------------
 # multi-frame windows (restated in banet_oracle.bundle_window_iteration)
 # --------------------------------------------------------------------------------------
-def window_assemble(intr, scale, src, tgts, depth, basis, Rs, Ts, Wc, normalize_rays=True, dtype=torch.float64, stats=None):
+def window_assemble(intr, scale, src, tgts, depth, basis, Rs, Ts, Wc, normalize_rays=True, dtype=torch.float64, stats=None,
+                    mask_override=None):
     """Normal equations of one multi-frame window at the poses (Rs, Ts) and depth coefficients Wc, composed from the
     per-pair assemblies exactly as banet_oracle.bundle_window_iteration stacks its rows: parameter order
     [pose_1 .. pose_pairs, depth]; pose blocks on the diagonal, each pair's pose/depth cross block, the depth block and
@@ -192,7 +205,8 @@ def window_assemble(intr, scale, src, tgts, depth, basis, Rs, Ts, Wc, normalize_
     o = 6 * pairs
     for i in range(pairs):
         L = prepare_level(intr, scale, src, tgts[:, i], depth, basis, normalize_rays, dtype)
-        A, b, ab, nv = assemble_prepared(L, Rs[:, i], Ts[:, i], Wc, True, stats)
+        A, b, ab, nv = assemble_prepared(L, Rs[:, i], Ts[:, i], Wc, True, stats,
+                                         None if mask_override is None else mask_override[:, i])
         del L
         AtA[:, 6 * i:6 * i + 6, 6 * i:6 * i + 6] = A[:, :6, :6]
         AtA[:, 6 * i:6 * i + 6, o:] = A[:, :6, 6:]
@@ -205,13 +219,13 @@ def window_assemble(intr, scale, src, tgts, depth, basis, Rs, Ts, Wc, normalize_
     return AtA, Atb, absres, nvalid
 
 
-def window_iteration(intr, scale, src, tgts, depth, basis, Rs, Ts, Wc, mlp, l2_base=1000.0, dtype=torch.float64):
+def window_iteration(intr, scale, src, tgts, depth, basis, Rs, Ts, Wc, mlp, l2_base=1000.0, dtype=torch.float64, mask_override=None):
     """One multi-frame BundleIteration (banet_oracle.bundle_window_iteration: lambda from the residual averaged over all
     pairs, last coefficient undamped, LU solve, per-frame SE(3) update) -> (Rs', Ts', W', dict(lam, solution, AtA, Atb))."""
     B, pairs = tgts.shape[0], tgts.shape[1]
     N = src.shape[1] * src.shape[2]
     stats = {}
-    AtA, Atb, absres, nv = window_assemble(intr, scale, src, tgts, depth, basis, Rs, Ts, Wc, True, dtype, stats)
+    AtA, Atb, absres, nv = window_assemble(intr, scale, src, tgts, depth, basis, Rs, Ts, Wc, True, dtype, stats, mask_override)
     avg = (absres / (N * pairs)).unsqueeze(1)
     mlp = [(torch.as_tensor(w).cpu().numpy() if not hasattr(w, "numpy") else w.cpu().numpy(),
             torch.as_tensor(b).cpu().numpy() if not hasattr(b, "numpy") else b.cpu().numpy()) for w, b in mlp]
@@ -228,4 +242,7 @@ def window_iteration(intr, scale, src, tgts, depth, basis, Rs, Ts, Wc, mlp, l2_b
         Tn.append(torch.matmul(V, sol[:, 6 * i + 3:6 * i + 6]) + torch.matmul(Rw, Ts[:, i].to(dtype).reshape(B, 3, 1)))
     Wn = Wc.to(dtype).reshape(B, -1, 1) + sol[:, 6 * pairs:]
     return torch.stack(Rn, 1), torch.stack(Tn, 1), Wn, dict(lam=lam.reshape(-1), solution=sol[..., 0], AtA=AtA, Atb=Atb,
-                                                             nvalid=nv.sum(1), borderline=stats["borderline"])
+                                                             nvalid=nv.sum(1), borderline=stats["borderline"],
+                                                             mask=torch.stack(stats["mask"], 1),
+                                                             px=torch.stack([q[0] for q in stats["pxy"]], 1),
+                                                             py=torch.stack([q[1] for q in stats["pxy"]], 1))

@@ -205,12 +205,15 @@ def _torch_levels(levels):
 
 
 STRIP, DIRECT, STRIP_ALL_DIRECT, SEG32 = 262144, 64 | 524288, 262144 | (1 << 20), 1 << 21
+PAIR_LOOP, SLICE_BARRIERS = 1 << 22, 1 << 24      # multi-frame strip gather: frames looped over inside one wave (A/B) / FP with slice barriers
 
 
 @pytest.mark.parametrize("H,W,K,big,pairs", [(48, 64, 128, False, 1),      # whole segments, unit-scale footprints: all from the window
                                              (40, 56, 16, True, 1),        # large motion: fallback rows, rim, masked pixels
                                              (37, 53, 0, True, 2),         # ragged strips and segments, pose only, 2 target frames
                                              (64, 96, 64, False, 3),       # 3 target frames share the depth dot
+                                             (50, 70, 128, True, 4),       # cfg-3's window: 4 waves per segment, large motion
+                                             (36, 48, 256, False, 7),      # cfg-5's window: 7 waves per segment, K = 256
                                              (70, 45, 256, False, 1),      # K = 256 (two basis chunks per row)
                                              (33, 21, 32, False, 1)])      # the narrowest map the window fits (21 texels)
 def test_strip_gather_kernel_matches_oracle(H, W, K, big, pairs):
@@ -231,7 +234,8 @@ def test_strip_gather_kernel_matches_oracle(H, W, K, big, pairs):
     mlps = [orc.he_normal_mlp_weights(C, 9)]
     ba = bdense.DenseBA(t(intr), _torch_levels(levels), mlps, "bundle" if K else "bundle_camera", 1000.0)
     outs = {}
-    for bits in (STRIP, DIRECT, STRIP_ALL_DIRECT, STRIP | SEG32):
+    variants = (STRIP, DIRECT, STRIP_ALL_DIRECT, STRIP | SEG32) + ((STRIP | PAIR_LOOP, STRIP | SLICE_BARRIERS) if pairs > 1 else ())
+    for bits in variants:
         ba.problems[0].c.reserved_ = bits
         assert ops.gather_selection(ba.problems[0]) == (1 if bits == DIRECT else 3)
         outs[bits] = [n(x) for x in ops.ba_assemble(ba.problems[0], t(R), t(T), t(Wc) if K else None)]
@@ -246,6 +250,10 @@ def test_strip_gather_kernel_matches_oracle(H, W, K, big, pairs):
     for name, x, y in zip(("AtA", "Atb", "absres", "nvalid"), outs[STRIP | SEG32], outs[STRIP]):
         assert relerr(x, y) < 3e-6, (name, relerr(x, y))          # 32-row segments: the same sums, other partial rows
     np.testing.assert_array_equal(outs[STRIP][3], outs[DIRECT][3])
+    if pairs > 1:     # frame-parallel workgroups (the default) == the frames looped over inside one wave, bit for bit
+        for x, y, z in zip(outs[STRIP], outs[STRIP | PAIR_LOOP], outs[STRIP | SLICE_BARRIERS]):
+            np.testing.assert_array_equal(x, y)
+            np.testing.assert_array_equal(x, z)
     one = dict(lv)
     one["tgt"] = lv["tgt"][:, 0]
     a = odense.level_inputs(intr, one, True, np.float64)

@@ -28,7 +28,7 @@ static void run(const f32x4* p, size_t n, float* out, int wgs, const char* name)
   hipEventCreate(&e1);
   for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((read_kernel<U, NT>), dim3(wgs), dim3(256), 0, 0, p, n, out);
   hipEventRecord(e0, 0);
-  const int reps = 5;
+  const int reps = n * 16 < ((size_t)1 << 30) ? 200 : 5;
   for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((read_kernel<U, NT>), dim3(wgs), dim3(256), 0, 0, p, n, out);
   hipEventRecord(e1, 0);
   hipEventSynchronize(e1);
@@ -37,8 +37,11 @@ static void run(const f32x4* p, size_t n, float* out, int wgs, const char* name)
   printf("%-40s %d workgroups: %.1f GB/s\n", name, wgs, (double)n * 16 * reps / (ms * 1e-3) / 1e9);
 }
 
-int main() {
-  const size_t bytes = (size_t)8 << 30, n = bytes / 16;
+int main(int argc, char** argv) {
+  // stream_read [MiB]: the buffer size (default 8 GiB, far beyond the 256 MiB infinity cache; 64 .. 192 = resident in it:
+  // does a re-read that hits the infinity cache go faster than one from HBM?)
+  const size_t bytes = argc > 1 ? (size_t)atol(argv[1]) << 20 : (size_t)8 << 30, n = bytes / 16;
+  printf("buffer %zu MiB\n", bytes >> 20);
   f32x4* p;
   float* out;
   if (hipMalloc(&p, bytes) != hipSuccess || hipMalloc(&out, 64) != hipSuccess) return 1;
