@@ -89,6 +89,7 @@ EXPORTS = {
     "banet_target_map_adjoint_ex_f32": (ctypes.c_int, [_FP] * 2 + [ctypes.c_int] * 5 + [_FP]),
     "banet_build_id": (ctypes.c_char_p, []),
     "banet_gather_selection": (ctypes.c_int, [_FP]),
+    "banet_syrk_selection": (ctypes.c_int, [_FP]),
     "banet_profile_ranges": (ctypes.c_int, [ctypes.c_int]),
     "banet_profile_begin": (ctypes.c_int, [ctypes.c_int]),
     "banet_profile_end": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),

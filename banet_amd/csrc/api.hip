@@ -165,7 +165,7 @@ int banet_ba_assemble_f32(const banet_level_t* lv, const float* R, const float* 
   if (rc != BANET_OK) return rc;
   if (!ws || ws_bytes < pl.ws_bytes || !aligned256(ws)) return BANET_ERR_WORKSPACE;
   return launch_assemble(lv, pl, R, T, Wc, nullptr, 0, ws, AtA, Atb, absres, nvalid,
-                         static_cast<hipStream_t>(stream));
+                         static_cast<hipStream_t>(stream), true, nullptr, nullptr, nullptr, pl.s.f16_standalone ? 0 : -1);
 }
 
 int banet_ba_assemble_mask_f32(const banet_level_t* lv, const float* R, const float* T, const float* Wc, float* AtA,
@@ -179,7 +179,7 @@ int banet_ba_assemble_mask_f32(const banet_level_t* lv, const float* R, const fl
   if (rc != BANET_OK) return rc;
   if (!ws || ws_bytes < pl.ws_bytes || !aligned256(ws)) return BANET_ERR_WORKSPACE;
   return launch_assemble(lv, pl, R, T, Wc, nullptr, 0, ws, AtA, Atb, absres, nvalid, static_cast<hipStream_t>(stream), true,
-                         nullptr, nullptr, mask_out);
+                         nullptr, nullptr, mask_out, pl.s.f16_standalone ? 0 : -1);
 }
 
 int banet_ba_solve_update_f32(const banet_level_t* lv, const banet_mlp_t* mlp, float l2_base, const float* AtA,
@@ -231,6 +231,8 @@ void banet_lm_params_default(banet_lm_params_t* p) {
   p->residual_ratio = 1.0f;                             // legacy/ba.py:8
   p->solver = BANET_SOLVER_QR;                          // legacy/ba.py:9
 }
+
+constexpr int kRoleSmallLevel = 19200;   // pixels: levels whose SYRK launch is latency-bound (see the role condition below)
 
 int banet_lm_level_f32(const banet_level_t* lv, const banet_mlp_t* mlp, float l2_base, int max_iters,
                        int early_termination, banet_state_t* st, void* ws, size_t ws_bytes, banet_stream_t stream) {
@@ -286,11 +288,14 @@ int banet_lm_level_ex_f32(const banet_level_t* lv, const banet_mlp_t* mlp, float
     if (a.queue) launch_zero_iters(a.queue, lv->B * a.nqueue, s);   // a kernel, not hipMemsetAsync: see prepare_gather
     // bundle levels whose SYRK is ba_syrk_bf16x6_kernel: the lambda MLP runs as a role workgroup of the SYRK launch, off the
     // solve kernel's critical path (C <= 256: the role's LDS scratch)
-    // Small batches only (B <= 8): the SYRK kernel runs one workgroup per CU (512 registers per wave), so the role workgroups
+    // ... and coarse levels at any batch (N <= kRoleSmallLevel pixels: their SYRK is a latency chain of 1-3 steps per wave, so a
+    // window's 7 workgroups take what 8 take, and the solve kernel loses the 19 us MLP: 40x30 .. 160x120 x 32 windows).
+    // Small batches only (B <= 8) otherwise: the SYRK kernel runs one workgroup per CU (512 registers per wave), so the role workgroups
     // need CUs of their own -- at B = 32 (8 + 1 workgroups per window = 288 > 256 CUs) a second round of workgroups doubled
     // the SYRK time (640x480 x 32: 1326 -> 2457 us); with B <= 8 one SYRK workgroup per window is given up where needed.
     const bool role = lv->variant == BANET_BUNDLE && mlp != nullptr && a.use_mlp && syrk_runs_mlp_role(pl.s) && lv->C <= 256 &&
-                      (lv->C & 3) == 0 && ((long long)lv->B * (pl.s.Gs + 1) <= num_cus() || (lv->B <= 8 && pl.s.Gs >= 16)) &&
+                      (lv->C & 3) == 0 && ((long long)lv->B * (pl.s.Gs + 1) <= num_cus() || (lv->B <= 8 && pl.s.Gs >= 16) ||
+                       (lv->N <= kRoleSmallLevel && pl.s.Gs >= 4)) &&
                       !(lv->reserved_ & 32768);   // reserved_ bit 15: MLP inside the solve kernel (A/B)
     if (role) {
       a.mlp_y = w.mlp_y;
@@ -298,7 +303,8 @@ int banet_lm_level_ex_f32(const banet_level_t* lv, const banet_mlp_t* mlp, float
     }
     for (int it = 0; it < max_iters; ++it) {
       rc = launch_assemble(lv, pl, st->R, st->T, st->Wc, nullptr, 0, w.partials, w.AtA, w.Atb, w.absres, w.nvalid, s,
-                           a.queue == nullptr, role ? mlp : nullptr, role ? w.mlp_y : nullptr);
+                           a.queue == nullptr, role ? mlp : nullptr, role ? w.mlp_y : nullptr, nullptr,
+                           pl.s.f16 ? (it == 0 ? 0 : 1) : -1);   // basis column maxima: once per level
       if (rc != BANET_OK) return rc;
       {
         RangeScope r("solve", lv->N);
@@ -414,7 +420,15 @@ int banet_gather_selection(const banet_level_t* lv) {
   GatherPlan pl;
   const int rc = plan_gather(lv, &pl);
   if (rc != BANET_OK) return rc;
-  return pl.strip ? 3 : pl.patch ? 2 : pl.c128 ? 1 : 0;
+  return pl.quad ? 4 : pl.strip ? 3 : pl.patch ? 2 : pl.c128 ? 1 : 0;
+}
+
+int banet_syrk_selection(const banet_level_t* lv) {
+  AsmPlan pl;
+  const int rc = plan_assemble(lv, &pl);
+  if (rc != BANET_OK) return rc;
+  if (lv->K == 0) return -1000;
+  return pl.s.f16 ? 4 : pl.s.direct;
 }
 
 int banet_profile_begin(int max_launches) { return profile_begin(max_launches); }

@@ -155,7 +155,7 @@ int* assemble_queue(const AsmPlan& pl, void* ws) {
 int launch_assemble(const banet_level_t* lv, const AsmPlan& pl, const float* R, const float* T, const float* Wc,
                     const int32_t* active, int active_stride, void* ws, float* AtA, float* Atb, float* absres,
                     float* nvalid, hipStream_t s, bool reset_queue, const banet_mlp_t* role_mlp, float* role_y,
-                    unsigned char* mask_out) {
+                    unsigned char* mask_out, int f16_stats) {
   char* base = static_cast<char*>(ws);
   float* gpart = reinterpret_cast<float*>(base);
   float* rec = lv->K > 0 ? reinterpret_cast<float*>(base + pl.off_rec) : nullptr;
@@ -188,7 +188,7 @@ int launch_assemble(const banet_level_t* lv, const AsmPlan& pl, const float* R, 
       mr.y = role_y;
     }
     rc = launch_syrk(lv->basis, rec, lv->B, lv->N, lv->K, npairs(lv), pl.s, active, active_stride, spart, s,
-                     mr.y != nullptr ? &mr : nullptr);
+                     mr.y != nullptr ? &mr : nullptr, f16_stats);
     if (rc != BANET_OK) return rc;
   }
   RangeScope r("reduce", lv->N);

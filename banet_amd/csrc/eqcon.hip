@@ -328,6 +328,7 @@ static int eq_nb(int P) {
   if (nb <= 5) return 5;
   if (nb <= 9) return 9;
   if (nb <= 17) return 17;
+  if (nb <= 19) return 19;   // 272 < P <= 304 (cfg-5's 8-frame windows: P = 298): the LDS-tiled kernel below, no SYRK-engine job set
   return -1;
 }
 
@@ -383,6 +384,7 @@ int launch_eq(const float* J, const float* G, const float* d, float* AtA, float*
     case 5: launch_eq_nb<5>(a, s); break;
     case 9: launch_eq_nb<9>(a, s); break;
     case 17: launch_eq_nb<17>(a, s); break;
+    case 19: launch_eq_nb<19>(a, s); break;
     default: return BANET_ERR_UNSUPPORTED;
   }
   launch_reduce(partials, B, pl.Gr, pl.pstride, P, AtA, Atb, s);

@@ -432,6 +432,7 @@ __global__ __launch_bounds__(kBlock, BANET_GATHER_WAVES) void ba_gather_kernel(c
 // --------------------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------------------
+constexpr int kQuadRounds = 6;       // ba_gather128q_kernel: most items per resident wave (measured: tools/gpu_r4_quad.sh)
 constexpr int kStripSegW = 16, kStripSegH = 32, kStripMinW = 21;   // = kStripW, kStripH, kWinTex of strip_plan.hpp (gather128s.hip)
 constexpr int kGenericBlocksPerCU = BANET_GATHER_WAVES;  // ba_gather_kernel: launch bounds
 constexpr int kC128BlocksPerCU = BANET_G128_WAVES;       // ba_gather128_kernel: launch bounds (LDS: 18 KB)
@@ -482,6 +483,7 @@ int plan_gather(const banet_level_t* lv, GatherPlan* pl) {
     if ((long long)sxn * syn * lv->B >= 4LL * slots || (lv->reserved_ & 262144)) {
       pl->strip = segh;
       pl->strip_fp = fp ? 1 : 0;
+      pl->quad = 0;
       pl->tiles_x = sxn;
       pl->tiles_y = syn;
       pl->tiles = sxn * syn;
@@ -504,6 +506,40 @@ int plan_gather(const banet_level_t* lv, GatherPlan* pl) {
       pl->off_queue = pl->off_fold + (pl->frows != pl->rows ? align_up(row_bytes_s * pl->frows, 256) : 0);
       pl->partial_bytes = pl->off_queue + align_up((size_t)VBs * 8 * sizeof(int), 256);
       pl->rec_bytes = lv->K > 0 ? align_up((size_t)VBs * lv->N * 8 * sizeof(float), 256) : 0;
+      return BANET_OK;
+    }
+  }
+  // Latency-bound launches (coarse levels, small batches): ba_gather128q_kernel -- 4x4-pixel items, the whole item one step,
+  // ~4x shorter serial chain per item than a tile's 16 steps (gather128q.hip) -- while the launch has at most kQuadRounds items
+  // per resident wave (2 workgroups x 4 waves per CU); beyond that the tile kernels' shared stencils win.
+  // reserved_ bit 25: force it at any size (parity tests, A/B); bit 30: off.
+  pl->quad = 0;
+  if (pl->c128 && lv->dense && !(lv->reserved_ & (1 << 30))) {
+    const int qxn = (lv->W + 3) / 4, qyn = (lv->H + 3) / 4;
+    const long long qitems = (long long)qxn * qyn * lv->B * npairs(lv);
+    if (qitems <= (long long)kQuadRounds * kCUs * 8 || (lv->reserved_ & (1 << 25))) {
+      const int VBq = lv->B * npairs(lv);
+      pl->quad = 1;
+      pl->patch = 0;
+      pl->pairloop = 0;
+      pl->qshift = 0;
+      pl->tiles_x = qxn;
+      pl->tiles_y = qyn;
+      pl->tiles = qxn * qyn;
+      int G = (kCUs * 2 + VBq - 1) / VBq;            // one resident round of 256-thread workgroups, 2 per CU
+      const int want = (pl->tiles + kNumWaves - 1) / kNumWaves;
+      if (G > want) G = want;
+      if (G < 1) G = 1;
+      pl->G = G;
+      pl->nbands = 1;
+      pl->pstride = kGHdr + lv->C;
+      pl->rows = pl->tiles;
+      pl->frows = pl->rows > kFoldRows ? (pl->rows + kFoldRows - 1) / kFoldRows : pl->rows;
+      const size_t row_bytes_q = (size_t)VBq * pl->pstride * sizeof(float);
+      pl->off_fold = align_up(row_bytes_q * pl->rows, 256);
+      pl->off_queue = pl->off_fold + (pl->frows != pl->rows ? align_up(row_bytes_q * pl->frows, 256) : 0);
+      pl->partial_bytes = pl->off_queue + align_up((size_t)VBq * 8 * sizeof(int), 256);
+      pl->rec_bytes = lv->K > 0 ? align_up((size_t)VBq * lv->N * 8 * sizeof(float), 256) : 0;
       return BANET_OK;
     }
   }
@@ -649,7 +685,7 @@ int launch_gather(const banet_level_t* lv, const GatherPlan& pl, const float* R,
   a.mask_out = mask_out;
   int rc;
   if (pl.c128)
-    rc = pl.strip ? launch_gather128s(a, lv->K, s) : pl.patch ? launch_gather128p(a, lv->K, s) : launch_gather128(a, lv->K, s);
+    rc = pl.quad ? launch_gather128q(a, lv->K, s) : pl.strip ? launch_gather128s(a, lv->K, s) : pl.patch ? launch_gather128p(a, lv->K, s) : launch_gather128(a, lv->K, s);
   else
     rc = lv->tgt_has_grad ? launch_c<true>(a, lv->C, lv->K, s) : launch_c<false>(a, lv->C, lv->K, s);
   if (rc != BANET_OK) return rc;

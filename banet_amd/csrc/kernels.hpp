@@ -20,6 +20,7 @@ struct GatherPlan {
   int patch;    // 1: ba_gather128p_kernel (same interface; taps from wave-private LDS patches) for large levels
   int strip;    // ba_gather128s_kernel (work items = 16-pixel-wide strip segments, rolling LDS window): pixel rows per segment
                 //    (32 or 16; 0 = another kernel); tiles_x / tiles_y / tiles then count segments
+  int quad;     // 1: ba_gather128q_kernel (work items = 4x4 pixel blocks, one step per item): latency-bound launches; tiles_x / tiles_y / tiles count items
   int strip_fp; // strip kernel, multi-frame windows: a workgroup = `pairs` waves on one segment, wave p against target frame p
   int rows;     // partial rows per window written by the gather kernel (tiles or G)
   int frows;    // rows per window handed to ba_reduce2_kernel (after ba_fold_kernel when rows > kFoldRows)
@@ -54,6 +55,9 @@ struct SyrkPlan {
   int x3;       // ba_syrk_bf16x6_kernel, opt-in: three products instead of six (reserved_ bit 29)
   int direct;   // 0: the LDS-tiled kernel, 1: ba_syrk_direct_kernel (fp32 MFMA, A/B), 2: ba_syrk_bf16x6_kernel (K = 64 / 128, <= 4 frames),
                 // 3: syrk_wide.hip jobs (K = 256, or K = 128 with more than 4 target frames)
+  int f16;      // ba_syrk_bf16x6_kernel: the fp16 two-piece form is eligible (plan_syrk); f16_standalone: also in a single assembly pass
+  int f16_standalone;
+  size_t off_colmax, off_recmax;   // f16: [B][K] basis column maxima, [B][32][2] record maxima, inside the partial buffer
   size_t off_aux;        // direct == 3: per-pixel (s, r) sums over the frames, inside the partial buffer
   size_t partial_bytes;
 };
@@ -62,7 +66,8 @@ int launch_syrk_wide(const float* basis, const float* rec, int B, int N, int K, 
                      const int32_t* active, int active_stride, float* partials, float* aux, hipStream_t s);
 int plan_syrk(int B, int N, int K, int pairs, int dbg, SyrkPlan* pl);
 int launch_syrk(const float* basis, const float* rec, int B, int N, int K, int pairs, const SyrkPlan& pl,
-                const int32_t* active, int active_stride, float* partials, hipStream_t s, const MlpRole* mr = nullptr);
+                const int32_t* active, int active_stride, float* partials, hipStream_t s, const MlpRole* mr = nullptr,
+                int f16_stats = -1);   // f16_stats: -1 = exact bf16 form; 0 / 1 = fp16 two-piece form (pl.f16), basis column maxima to compute / in place
 inline bool syrk_runs_mlp_role(const SyrkPlan& pl) { return pl.direct == 2; }   // ba_syrk_bf16x6_kernel only
 void launch_reduce2(const float* gpart, int Gg, int gstride, const float* spart, int Gs, int sstride,
                     const int32_t* active, int active_stride, int B, int K, int C, int pairs, float* AtA, float* Atb,
@@ -80,7 +85,7 @@ int plan_assemble(const banet_level_t* lv, AsmPlan* pl);
 int launch_assemble(const banet_level_t* lv, const AsmPlan& pl, const float* R, const float* T, const float* Wc,
                     const int32_t* active, int active_stride, void* ws, float* AtA, float* Atb, float* absres,
                     float* nvalid, hipStream_t s, bool reset_queue = true, const banet_mlp_t* role_mlp = nullptr,
-                    float* role_y = nullptr, unsigned char* mask_out = nullptr);
+                    float* role_y = nullptr, unsigned char* mask_out = nullptr, int f16_stats = -1);
 int* assemble_queue(const AsmPlan& pl, void* ws);   // the gather's tile-queue heads inside the workspace (or nullptr)
 int profile_ranges(int enable);             // roctx ranges around the launches (banet_profile_ranges)
 struct RangeScope {                         // pushes "banet.<role>[ N=<n>]" when ranges are on

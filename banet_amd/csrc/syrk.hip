@@ -16,6 +16,7 @@
 // Pipeline: registers <- tile t+1 (global loads issued before the MFMA phase of tile t),
 // LDS double buffer, one barrier per tile.  Wave w owns block rows w and NB-1-w of the upper
 // triangle (NB+1 blocks: balanced); accumulators stay in registers for the whole kernel.
+#include <algorithm>
 #include "kernels.hpp"
 #include "mlp.hpp"
 #include "syrk_split.hpp"
@@ -32,7 +33,10 @@ struct SyrkArgs {
   int pairs;           // target frames per window (records of pair i: rec + ((b pairs + i) N) 8)
   int pass;            // LDS-tiled kernel only: pass p adds H_cd of pair p; pass 0 also H_dd / Atb_d with s, r summed over pairs
   MlpRole mr;          // ba_syrk_bf16x6_kernel: workgroup Gs of every window evaluates the lambda MLP (mr.y != nullptr)
+  const float* colmax; // T0 = 16 (fp16 two-piece split): [B][K] max_n |b_nk| (ba_colmax_kernel)
+  const float* recmax; // T0 = 16: [B][kRecMaxBlocks][2] per-block max_n s_n and max_n,word word^2 / s_n (ba_recmax_kernel)
 };
+constexpr int kRecMaxBlocks = 32;
 
 template <int NB>
 __global__ __launch_bounds__(kBlock, NB > 8 ? 1 : 2) void ba_syrk_kernel(const SyrkArgs a) {
@@ -448,6 +452,7 @@ __global__ __launch_bounds__(kBlock, 1) void ba_syrk_direct_kernel(const SyrkArg
 // H_cd / Atb_d stay on v_mfma_f32_16x16x4_f32 with the raw fp32 values (u is not non-negative).
 // --------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <int KH, int PAIRS, int T0>   // T0 = 0: six products (fp32-exact, the product path); 3: the three largest only (opt-in, see plan_syrk)
@@ -492,6 +497,50 @@ __global__ __launch_bounds__(kBlock, 1) void ba_syrk_bf16x6_kernel(const SyrkArg
 #pragma unroll
     for (int q = 0; q < NBV; ++q) acu[j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // ---- T0 = 16: the fp16 two-piece split needs every operand inside fp16's range.  v = sqrt(s_n) b_nk is scaled per COLUMN by
+  // a power of two from max_n |b_nk| (ba_colmax_kernel, once per level: the basis does not change) and max_n s_n (ba_recmax_kernel,
+  // per pass), so that |v| < 2^14 and a column's largest entries keep 22 significand bits while its small ones carry an absolute
+  // error of 2^-25 of the scaled unit, i.e. <= 2^-39 of the column's bound; the record rows u / sqrt(s), r / sqrt(s) by one power
+  // of two from max word^2 / s.  Powers of two: the scaling and its inverse (epilogue) are exact.  Inputs that are not finite, or
+  // exponents beyond what the inverse can undo, fall back to the exact bf16 form below (use16 = false, wave-uniform per window).
+  [[maybe_unused]] float csc[4 * KH];       // this lane's columns 64 h + 4 m + e
+  [[maybe_unused]] float usc = 1.f, uinv = 1.f;
+  [[maybe_unused]] bool use16 = false;
+  [[maybe_unused]] __shared__ float sInv[K];
+  if constexpr (T0 == 16) {
+    float smx = 0.f, wmx = 0.f;
+    if (lane < kRecMaxBlocks) {
+      smx = a.recmax[((size_t)b * kRecMaxBlocks + lane) * 2];
+      wmx = a.recmax[((size_t)b * kRecMaxBlocks + lane) * 2 + 1];
+    }
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) {
+      smx = fmaxf(smx, __shfl_xor(smx, sh, 64));
+      wmx = fmaxf(wmx, __shfl_xor(wmx, sh, 64));
+    }
+    int es = 0, eu = 0;
+    (void)frexpf(sqrtf(smx), &es);          // sqrt(s) < 2^es
+    (void)frexpf(sqrtf(wmx), &eu);
+    bool ok = (smx < __builtin_inff()) && (wmx < __builtin_inff()) && !(smx != smx) && !(wmx != wmx);
+    usc = ldexpf(1.f, 14 - eu);
+    uinv = ldexpf(1.f, eu - 14);
+#pragma unroll
+    for (int h = 0; h < KH; ++h)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int col = 64 * h + 4 * m + e;
+        const float cm = a.colmax[(size_t)b * K + col];
+        int ek = 0;
+        (void)frexpf(cm, &ek);
+        const int sh = 14 - ek - es;          // |sqrt(s) b| 2^sh < 2^14
+        ok = ok && (cm < __builtin_inff()) && !(cm != cm) && sh > -100 && sh < 100;
+        csc[4 * h + e] = ldexpf(1.f, sh);
+        if (w == 0 && kq == 0) sInv[col] = ldexpf(1.f, -sh);
+      }
+    use16 = __ballot(!ok) == 0ull;           // the same decision in every wave of the window's workgroups (same inputs)
+    __syncthreads();
+  }
+
   // this wave's run of 32-pixel steps
   const int ns = (N + 31) >> 5, nwaves = a.Gs * kNumWaves, gw = g * kNumWaves + w;
   const int s0 = (int)(((long long)ns * gw) / nwaves), s1 = (int)(((long long)ns * (gw + 1)) / nwaves);
@@ -517,7 +566,64 @@ __global__ __launch_bounds__(kBlock, 1) void ba_syrk_bf16x6_kernel(const SyrkArg
   asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm0), "=s"(tr0)::"memory");
 #endif
   issue(s0);
-  for (int st = s0; st < s1; ++st) {
+  if constexpr (T0 == 16) {
+    if (use16) {
+      for (int st = s0; st < s1; ++st) {
+        float sq[8];
+        u32x4 opu[NU][2];
+        {
+          float ut[NU][8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const bool ok = 32 * st + 8 * kq + i < N;
+            float ssum = ps[i][0];
+#pragma unroll
+            for (int pr = 1; pr < PAIRS; ++pr) ssum += ps[i][pr];
+            sq[i] = ok ? sqrtf(fmaxf(ssum, 0.f)) : 0.f;          // zero switches the pixel off
+            const float inv = sq[i] > 0.f ? usc / sq[i] : 0.f;
+#pragma unroll
+            for (int j = 0; j < NU; ++j) ut[j][i] = uon[j] ? pu[i][j] * inv : 0.f;
+          }
+#pragma unroll
+          for (int j = 0; j < NU; ++j) split8_f16x2(ut[j], opu[j]);
+        }
+        u32x4 op[NBV][2];
+#pragma unroll
+        for (int h = 0; h < KH; ++h)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float vv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) vv[i] = (sq[i] * pb[i][h][e]) * csc[4 * h + e];
+            split8_f16x2(vv, op[4 * h + e]);
+          }
+        issue(st + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // three products, smallest first, term-major (consecutive MFMAs write different accumulators): lo hi' + hi lo' + hi hi'
+        constexpr int kFa[3] = {1, 0, 0}, kFb[3] = {0, 1, 0};
+#pragma unroll
+        for (int t3 = 0; t3 < 3; ++t3) {
+#pragma unroll
+          for (int j = 0; j < NU; ++j)
+#pragma unroll
+            for (int bj = 0; bj < NBV; ++bj)
+              acu[j][bj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, opu[j][kFa[t3]]),
+                                                                  __builtin_bit_cast(f16x8, op[bj][kFb[t3]]), acu[j][bj], 0, 0, 0);
+          int idx = 0;
+#pragma unroll
+          for (int bi = 0; bi < NBV; ++bi)
+#pragma unroll
+            for (int bj = bi; bj < NBV; ++bj) {
+              acc[idx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, op[bi][kFa[t3]]),
+                                                                __builtin_bit_cast(f16x8, op[bj][kFb[t3]]), acc[idx], 0, 0, 0);
+              ++idx;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  for (int st = (T0 == 16 && use16) ? s1 : s0; st < s1; ++st) {
     // ---- H_cd / Atb_d on the bf16 pipe too: sum u b = sum (u / sqrt(s)) (sqrt(s) b) = sum u~ v with the SAME split v
     // as H_dd (|u| <= sqrt(Jc^T M Jc) sqrt(s): u~ is bounded, and s = 0 implies M jd = 0, i.e. u = r = 0 exactly).
     // 6 NBV bf16 MFMAs (16 cycles) per record block row instead of 8 NBV fp32 MFMAs (32 cycles).
@@ -559,7 +665,7 @@ __global__ __launch_bounds__(kBlock, 1) void ba_syrk_bf16x6_kernel(const SyrkArg
 #if defined(BANET_SYRK_ABL) && BANET_SYRK_ABL >= 1   // development ablation (tools/time_syrk.py): one product instead of six
     constexpr int kT0 = 5;
 #else
-    constexpr int kT0 = T0;   // 3: mid hi' + hi mid' + hi hi' -- the third piece of the split is then dead code
+    constexpr int kT0 = T0 == 16 ? 0 : T0;   // 3: mid hi' + hi mid' + hi hi' -- the third piece of the split is then dead code
 #endif
 #pragma unroll
     for (int t6 = kT0; t6 < 6; ++t6) {
@@ -612,17 +718,27 @@ __global__ __launch_bounds__(kBlock, 1) void ba_syrk_bf16x6_kernel(const SyrkArg
     const int pair = 2 * j + brow / 6;
     if (brow < 12 && pair < PAIRS) {
 #pragma unroll
-      for (int bj = 0; bj < NBV; ++bj)
-        part[(6 * pair + brow % 6) * K + 64 * (bj >> 2) + 4 * m + (bj & 3)] = sAcc[NPAIR + j * NBV + bj][r][lane];
+      for (int bj = 0; bj < NBV; ++bj) {
+        const int cc = 64 * (bj >> 2) + 4 * m + (bj & 3);
+        float v = sAcc[NPAIR + j * NBV + bj][r][lane];
+        if constexpr (T0 == 16) {
+          if (use16) v = (v * uinv) * sInv[cc];          // undo the power-of-two scales: exact
+        }
+        part[(6 * pair + brow % 6) * K + cc] = v;
+      }
     }
   }
   if (brow == 12) {
 #pragma unroll
     for (int bj = 0; bj < NBV; ++bj) {
+      const int cc = 64 * (bj >> 2) + 4 * m + (bj & 3);
       float v = sAcc[NPAIR + bj][0][lane];
 #pragma unroll
       for (int i = 1; i < PAIRS; ++i) v += sAcc[NPAIR + bj][i][lane];
-      part[6 * PAIRS * K + 64 * (bj >> 2) + 4 * m + (bj & 3)] = v;
+      if constexpr (T0 == 16) {
+        if (use16) v = (v * uinv) * sInv[cc];
+      }
+      part[6 * PAIRS * K + cc] = v;
     }
   }
 #ifdef BANET_TIMING
@@ -640,7 +756,10 @@ __global__ __launch_bounds__(kBlock, 1) void ba_syrk_bf16x6_kernel(const SyrkArg
     for (int bi = 0; bi < NBV; ++bi)
       for (int bj = bi; bj < NBV; ++bj) {
         const int rr = 64 * (bi >> 2) + 4 * brow + (bi & 3), cc = 64 * (bj >> 2) + 4 * m + (bj & 3);
-        const float v = sAcc[idx][r][lane];
+        float v = sAcc[idx][r][lane];
+        if constexpr (T0 == 16) {
+          if (use16) v = (v * sInv[rr]) * sInv[cc];
+        }
         if (bj > bi || rr <= cc) {
           pd[rr * K + cc] = v;
           pd[cc * K + rr] = v;
@@ -738,6 +857,81 @@ __global__ __launch_bounds__(256) void ba_reduce2_kernel(const float* __restrict
 // --------------------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------------------
+// scales of the fp16 two-piece SYRK (ba_syrk_bf16x6_kernel<.., .., 16>)
+// --------------------------------------------------------------------------------------
+// per window and basis column: max_n |b_nk| as float bits (non-negative floats order like unsigned integers; a NaN ends up
+// above every finite value and is caught by the consumer).  colmax zeroed before the launch.  Streams the basis once.
+__global__ __launch_bounds__(256) void ba_colmax_kernel(const float* __restrict__ basis, int N, int K, const int32_t* active,
+                                                        int active_stride, unsigned* __restrict__ colmax) {
+  __shared__ unsigned sMax[256][4];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  if (active != nullptr && active[(size_t)b * active_stride] == 0) return;
+  const int QK = K >> 2;                    // 16-byte column quads per row (K % 4 == 0)
+  const int cq = tid % QK, r0 = tid / QK, rstep = 256 / QK;      // QK divides 256 for K = 64 / 128
+  const float* bas_b = basis + (size_t)b * N * K;
+  f32x4 mx = {0.f, 0.f, 0.f, 0.f};
+  const int rows_per_block = (N + gridDim.x - 1) / gridDim.x;
+  const int n0 = blockIdx.x * rows_per_block, n1 = min(N, n0 + rows_per_block);
+  for (int n = n0 + r0; n < n1; n += rstep) {
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(bas_b + (size_t)n * K + 4 * cq));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mx[e] = (fabsf(v[e]) > mx[e] || v[e] != v[e]) ? fabsf(v[e]) : mx[e];   // NaN sticks
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) sMax[tid][e] = __float_as_uint(mx[e]);
+  __syncthreads();
+  if (tid < QK) {
+    unsigned m[4] = {0u, 0u, 0u, 0u};
+    for (int r = 0; r < rstep; ++r)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m[e] = max(m[e], sMax[r * QK + tid][e]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicMax(&colmax[(size_t)b * K + 4 * tid + e], m[e]);
+  }
+}
+
+// per window and block: max_n s_n (s summed over the window's target frames, as the SYRK uses it) and max over pixels and
+// record words (u_0..u_5 of every frame, r of every frame) of word^2 / s_n.  No atomics: [B][kRecMaxBlocks][2].
+__global__ __launch_bounds__(256) void ba_recmax_kernel(const float* __restrict__ rec, int N, int pairs, const int32_t* active,
+                                                        int active_stride, float* __restrict__ out) {
+  __shared__ float sRed[4][2];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  if (active != nullptr && active[(size_t)b * active_stride] == 0) return;
+  const float* rec_b = rec + (size_t)b * pairs * N * 8;
+  float smx = 0.f, wmx = 0.f;
+  for (int n = blockIdx.x * 256 + tid; n < N; n += gridDim.x * 256) {
+    float ssum = 0.f, w2 = 0.f;
+    for (int p = 0; p < pairs; ++p) {
+      const float4 ua = *reinterpret_cast<const float4*>(rec_b + ((size_t)p * N + n) * 8);
+      const float4 ub = *reinterpret_cast<const float4*>(rec_b + ((size_t)p * N + n) * 8 + 4);
+      ssum += ub.z;
+      w2 = fmaxf(w2, fmaxf(fmaxf(ua.x * ua.x, ua.y * ua.y), fmaxf(ua.z * ua.z, ua.w * ua.w)));
+      w2 = fmaxf(w2, fmaxf(fmaxf(ub.x * ub.x, ub.y * ub.y), ub.w * ub.w));
+      if (ua.x != ua.x || ua.y != ua.y || ua.z != ua.z || ua.w != ua.w || ub.x != ub.x || ub.y != ub.y || ub.z != ub.z || ub.w != ub.w)
+        w2 = __builtin_nanf("");                                       // not finite: the consumer falls back
+    }
+    const float q = ssum > 0.f ? w2 / ssum : (w2 != w2 ? w2 : 0.f);   // s = 0 implies u = r = 0 exactly
+    smx = (ssum > smx || ssum != ssum) ? ssum : smx;
+    wmx = (q > wmx || q != q) ? q : wmx;
+  }
+  auto nanmax = [](float a_, float b_) { return (a_ != a_) ? a_ : (b_ != b_) ? b_ : fmaxf(a_, b_); };
+#pragma unroll
+  for (int sh = 1; sh < 64; sh <<= 1) {
+    smx = nanmax(smx, __shfl_xor(smx, sh, 64));
+    wmx = nanmax(wmx, __shfl_xor(wmx, sh, 64));
+  }
+  if ((tid & 63) == 0) {
+    sRed[tid >> 6][0] = smx;
+    sRed[tid >> 6][1] = wmx;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    out[((size_t)b * kRecMaxBlocks + blockIdx.x) * 2] = nanmax(nanmax(sRed[0][0], sRed[1][0]), nanmax(sRed[2][0], sRed[3][0]));
+    out[((size_t)b * kRecMaxBlocks + blockIdx.x) * 2 + 1] = nanmax(nanmax(sRed[0][1], sRed[1][1]), nanmax(sRed[2][1], sRed[3][1]));
+  }
+}
+
+// --------------------------------------------------------------------------------------
 static int nb_for_k(int K) {
   if (K <= 0) return 0;
   if (K <= 16) return 1;
@@ -748,6 +942,8 @@ static int nb_for_k(int K) {
   return -1;
 }
 
+constexpr long long kSyrkF16Pixels = 32LL * 76800;   // 320x240 x 32 windows, 640x480 x 8
+
 int plan_syrk(int B, int N, int K, int pairs, int dbg, SyrkPlan* pl) {
   pl->nb = nb_for_k(K);
   if (pl->nb < 0) return BANET_ERR_UNSUPPORTED;
@@ -756,6 +952,9 @@ int plan_syrk(int B, int N, int K, int pairs, int dbg, SyrkPlan* pl) {
     pl->tiles = 0;
     pl->pstride = 0;
     pl->partial_bytes = 0;
+    pl->f16 = pl->f16_standalone = 0;
+    pl->x3 = pl->direct = 0;
+    pl->off_aux = pl->off_colmax = pl->off_recmax = 0;
     return BANET_OK;
   }
   pl->tiles = (N + kTilePix - 1) / kTilePix;
@@ -778,6 +977,16 @@ int plan_syrk(int B, int N, int K, int pairs, int dbg, SyrkPlan* pl) {
   pl->partial_bytes = align_up((size_t)B * G * pl->pstride * sizeof(float), 256);
   pl->off_aux = pl->partial_bytes;
   if (pl->direct == 3) pl->partial_bytes += syrk_wide_aux_bytes(B, N, pairs);
+  // The fp16 two-piece form of ba_syrk_bf16x6_kernel (half the MFMAs, 5 instead of 9 split instructions per two values, the same
+  // accuracy class: ~2^-21 per product against the reference's fp32 GEMM) where the launch is throughput-bound -- at least
+  // kSyrkF16Pixels pixels in all -- so that its two small pre-passes (basis column maxima once per level, record maxima per pass)
+  // are noise.  LM loop (banet_lm_level_f32) only; the single assembly pass keeps the exact bf16 form unless reserved_ bit 24 asks
+  // for this one (tests).  reserved_ bit 31: never (A/B).
+  pl->f16 = (pl->direct == 2 && !pl->x3 && !(dbg & (1u << 31)) && ((long long)N * B >= kSyrkF16Pixels || (dbg & (1 << 24)))) ? 1 : 0;
+  pl->f16_standalone = (pl->f16 && (dbg & (1 << 24))) ? 1 : 0;
+  pl->off_colmax = pl->partial_bytes;
+  pl->off_recmax = pl->off_colmax + (pl->f16 ? align_up((size_t)B * K * sizeof(float), 256) : 0);
+  if (pl->f16) pl->partial_bytes = pl->off_recmax + align_up((size_t)B * kRecMaxBlocks * 2 * sizeof(float), 256);
   return BANET_OK;
 }
 
@@ -816,13 +1025,30 @@ static void launch_direct(const SyrkArgs& a, int B, hipStream_t s) {
 }
 
 int launch_syrk(const float* basis, const float* rec, int B, int N, int K, int pairs, const SyrkPlan& pl,
-                const int32_t* active, int active_stride, float* partials, hipStream_t s, const MlpRole* mr) {
+                const int32_t* active, int active_stride, float* partials, hipStream_t s, const MlpRole* mr, int f16_stats) {
   if (pl.direct == 3)
     return launch_syrk_wide(basis, rec, B, N, K, pairs, pl.Gs, pl.pstride, active, active_stride, partials,
                             reinterpret_cast<float*>(reinterpret_cast<char*>(partials) + pl.off_aux), s);
-  SyrkArgs a{basis, rec, active, active_stride, partials, N, K, pl.Gs, pl.tiles, pl.pstride, pairs, 0, MlpRole{}};
+  SyrkArgs a{basis, rec, active, active_stride, partials, N, K, pl.Gs, pl.tiles, pl.pstride, pairs, 0, MlpRole{}, nullptr, nullptr};
   if (pl.direct == 2) {
     if (mr != nullptr) a.mr = *mr;
+    if (pl.f16 && f16_stats >= 0) {     // fp16 two-piece form: f16_stats 0 = compute the basis column maxima now, 1 = they are in place
+      unsigned* colmax = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(partials) + pl.off_colmax);
+      float* recmax = reinterpret_cast<float*>(reinterpret_cast<char*>(partials) + pl.off_recmax);
+      if (f16_stats == 0) {
+        launch_zero_iters(reinterpret_cast<int32_t*>(colmax), B * K, s);
+        const int G = std::max(1, std::min((N + 255) / 256, (8 * num_cus() + B - 1) / B));
+        hipLaunchKernelGGL(ba_colmax_kernel, dim3(G, B), dim3(256), 0, s, basis, N, K, active, active_stride, colmax);
+      }
+      hipLaunchKernelGGL(ba_recmax_kernel, dim3(kRecMaxBlocks, B), dim3(256), 0, s, rec, N, pairs, active, active_stride, recmax);
+      a.colmax = reinterpret_cast<const float*>(colmax);
+      a.recmax = recmax;
+      if (K == 128)
+        launch_bf16x6<2, 16>(a, B, s);
+      else
+        launch_bf16x6<1, 16>(a, B, s);
+      return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;
+    }
     if (K == 128) {
       if (pl.x3)
         launch_bf16x6<2, 3>(a, B, s);

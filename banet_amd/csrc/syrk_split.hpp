@@ -26,4 +26,19 @@ __device__ __forceinline__ void split8_bf16x3(const float (&x)[8], u32x4_t (&out
   }
 }
 
+// two-piece fp16 split of 8 fp32 values, two at a time: hi = fp16(v) (v_cvt_pk_f16_f32, round to nearest even), lo = fp16(v - hi)
+// with v - hi exact in fp32: hi + lo = v up to 2^-22 |v| while lo is a normal fp16 number (|v| >= 2^-3), an ABSOLUTE 2^-25
+// below that (subnormal lo).  The caller scales v into fp16's range first (|v| < 2^14).  5 VALU instructions per two values.
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split8_f16x2(const float (&x)[8], u32x4_t (&out)[2]) {
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const f32x2_t v = {x[2 * d], x[2 * d + 1]};
+    const f16x2_t hp = __builtin_convertvector(v, f16x2_t);
+    const f32x2_t r1 = v - __builtin_convertvector(hp, f32x2_t);
+    out[0][d] = __builtin_bit_cast(unsigned, hp);
+    out[1][d] = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, f16x2_t));
+  }
+}
+
 }  // namespace banet

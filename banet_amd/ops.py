@@ -253,13 +253,28 @@ class LevelProblem:
         self.device = tgt.device
 
 
-GATHER_KERNELS = {0: "ba_gather_kernel", 1: "ba_gather128_kernel", 2: "ba_gather128p_kernel", 3: "ba_gather128s_kernel"}
+GATHER_KERNELS = {0: "ba_gather_kernel", 1: "ba_gather128_kernel", 2: "ba_gather128p_kernel", 3: "ba_gather128s_kernel",
+                  4: "ba_gather128q_kernel"}
+FORCE_QUAD_GATHER, NO_QUAD_GATHER = 1 << 25, 1 << 30   # banet_hip.h: BANET_DEV_FORCE_QUAD_GATHER / _NO_QUAD_GATHER
 FORCE_PATCH_GATHER, FORCE_STRIP_GATHER = 512, 262144     # banet_hip.h: BANET_DEV_FORCE_PATCH_GATHER / _STRIP_GATHER (parity checks at small batch sizes)
 SYRK_THREE_PRODUCTS = 1 << 29   # banet_hip.h: BANET_DEV_SYRK_THREE_PRODUCTS -- opt-in: the K = 128 SYRK with the three largest bf16 products only (~2^-16 per product instead of fp32-exact)
 
 
+SYRK_F16, NO_SYRK_F16 = 1 << 24, -2147483648          # banet_hip.h: BANET_DEV_SYRK_F16 / BANET_DEV_NO_SYRK_F16
+SYRK_KERNELS = {0: "ba_syrk_kernel", 1: "ba_syrk_direct_kernel", 2: "ba_syrk_bf16x6_kernel (bf16 x 3 pieces, 6 products)",
+                3: "syrk_wide.hip jobs", 4: "ba_syrk_bf16x6_kernel (fp16 x 2 pieces, 3 products, scaled)", -1000: "none (K = 0)"}
+
+
+def syrk_selection(level):
+    """banet_syrk_selection: the depth-block contraction kernel banet_lm_level_f32 runs for this level AND batch size"""
+    rc = capi.lib().banet_syrk_selection(ctypes.byref(level.c))
+    if rc < 0 and rc != -1000:
+        capi.check(rc)
+    return rc
+
+
 def gather_selection(level):
-    """banet_gather_selection: 0 generic / 1 C=128 direct / 2 LDS patches / 3 strip segments, for this level AND batch size"""
+    """banet_gather_selection: 0 generic / 1 C=128 direct / 2 LDS patches / 3 strip segments / 4 4x4-pixel items, for this level AND batch size"""
     rc = capi.lib().banet_gather_selection(ctypes.byref(level.c))
     if rc < 0:
         capi.check(rc)

@@ -132,8 +132,16 @@ def roofline_record(prob, prof, elapsed_s, traffic=None):
     syrk_flops, syrk_exec = 0.0, 0.0
     pairs = max(int(prob.pairs), 1)
     three = bool(int(getattr(ba.problems[0].c, "reserved_", 0)) & (1 << 29)) and int(ba.problems[0].c.K) == 128   # ops.SYRK_THREE_PRODUCTS (opt-in)
-    nprod = 3 if three else 6
+    forms = []
     for li, p in enumerate(ba.problems):
+        try:
+            from banet_amd import ops as _ops
+            f16 = _ops.syrk_selection(p) == 4          # the LM loop's fp16 two-piece form at this level (3 products)
+        except Exception:      # a stand-in problem object (tests/test_capi_cpu.py)
+            f16 = False
+        nprod = 3 if (three or f16) else 6
+        forms.append("%dx%d: %s" % (p.c.W, p.c.H, "fp16x2 pieces, 3 products" if f16 else "bf16x2 pieces, 3 products (opt-in)" if three
+                                     else "bf16x3 pieces, 6 products"))
         cnt, ms = prof.get(p.N, (0, 0.0))
         scnt, sms = prof.get(-p.N, (0, 0.0))
         by = ba.algorithmic_bytes_per_iteration(li) * B * cnt
@@ -173,7 +181,7 @@ def roofline_record(prob, prof, elapsed_s, traffic=None):
                             # the matrix-core side of the path (north_star: "MFMA utilisation against gfx950 peak")
                             "mfma": {"bound": "mfma", "kernel": ("ba_syrk_bf16x6_kernel, OPT-IN form (--reserved bit 29): 2 bf16 pieces, the 3 largest products, "
                                                                        "~2^-16 per product -- reduced precision, not the headline path") if three else
-                                               "ba_syrk_bf16x6_kernel (fp32 operands split exactly into 3 bf16 pieces, 6 products)",
+                                               "ba_syrk_bf16x6_kernel, fp32 operands split into " + " / ".join(forms),
                                      "algorithmic_fp32_TFLOPs": round(syrk_flops / max(syrk_ms, 1e-9) / 1e9, 1),
                                      "peak_fp32_matrix_TFLOPs": MFMA_F32_PEAK_TF,
                                      "frac_of_fp32_matrix_peak": round(syrk_flops / max(syrk_ms, 1e-9) / 1e9 / MFMA_F32_PEAK_TF, 4),
@@ -365,8 +373,12 @@ def chain_parity_record(prob, dev, window):
     kernels = []
     for p1, pb in zip(ba1.problems, prob.ba.problems):
         sel = ops.gather_selection(pb)
-        p1.c.reserved_ = int(pb.c.reserved_) | {3: ops.FORCE_STRIP_GATHER, 2: ops.FORCE_PATCH_GATHER}.get(sel, 0)
-        assert ops.gather_selection(p1) == sel or sel in (0, 1), (sel, ops.gather_selection(p1))
+        p1.c.reserved_ = int(pb.c.reserved_) | {4: ops.FORCE_QUAD_GATHER, 3: ops.FORCE_STRIP_GATHER, 2: ops.FORCE_PATCH_GATHER,
+                                                 1: ops.NO_QUAD_GATHER}.get(sel, 0)
+        assert ops.gather_selection(p1) == sel or sel == 0, (sel, ops.gather_selection(p1))
+        if ops.syrk_selection(pb) == 4:      # the batch's LM loop runs the fp16 two-piece SYRK at this level: so does the check
+            p1.c.reserved_ = int(p1.c.reserved_) | ops.SYRK_F16
+            assert ops.syrk_selection(p1) == 4
         kernels.append(ops.GATHER_KERNELS[ops.gather_selection(p1)])
     st = ba1.new_state(T=prob.T0[w].contiguous())
     snaps = []

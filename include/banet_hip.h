@@ -51,7 +51,7 @@ const char* banet_error_string(int code);
  *       left  AtA [B,P,P] = sum_n J_n^T (G_n^T G_n) J_n
  *       right Atb [B,P,1] = sum_n J_n^T  G_n^T d_n
  *     Never materialises the per-pixel PxP products (utils.cu:356-365 does: 22 GB/item at
- *     640x480, P=134).  Supported: 1 <= P <= 272, any C >= 1, any N >= 1 (P > 144: four passes over J).
+ *     640x480, P=134).  Supported: 1 <= P <= 304, any C >= 1, any N >= 1 (P <= 272: the matrix-pipe kernels; 272 < P <= 304, cfg-5's P = 298: the LDS-tiled first kernel).
  * ------------------------------------------------------------------------------------- */
 size_t banet_equation_construction_workspace_bytes(int B, int N, int C, int P);
 int banet_equation_construction_f32(const float* jacobian, const float* gradient,
@@ -96,7 +96,11 @@ enum { /* banet_level_t.variant: which reference iteration is restated */
 enum {
   BANET_DEV_FORCE_PATCH_GATHER = 1 << 9,
   BANET_DEV_FORCE_STRIP_GATHER = 1 << 18,
-  BANET_DEV_SYRK_THREE_PRODUCTS = 1 << 29
+  BANET_DEV_FORCE_QUAD_GATHER = 1 << 25,   /* the 4x4-pixel-item gather of latency-bound launches, at any size */
+  BANET_DEV_NO_QUAD_GATHER = 1 << 30,      /* ... never (the tile kernels instead) */
+  BANET_DEV_SYRK_THREE_PRODUCTS = 1 << 29,
+  BANET_DEV_SYRK_F16 = 1 << 24,             /* the fp16 two-piece SYRK also in banet_ba_assemble_f32 and at any launch size (tests) */
+  BANET_DEV_NO_SYRK_F16 = (int)0x80000000   /* ... never: the exact bf16 form everywhere (A/B) */
 };
 
 typedef struct banet_level {
@@ -329,10 +333,18 @@ int banet_profile_end(int max_tags, int32_t* tag_points, int32_t* tag_launches, 
 const char* banet_build_id(void);
 /*   banet_gather_selection: which assembly (gather) kernel a level of this shape runs -- 0 = ba_gather_kernel (generic),
  *     1 = ba_gather128_kernel (C = 128, 8x8 tiles, direct taps), 2 = ba_gather128p_kernel (wave-private LDS patches),
- *     3 = ba_gather128s_kernel (16x32 strip segments, rolling LDS window); negative = error code.  The selection depends on
+ *     3 = ba_gather128s_kernel (16x16 strip segments, rolling LDS window), 4 = ba_gather128q_kernel (4x4-pixel items, one step
+ *     per item: latency-bound launches); negative = error code.  The selection depends on
  *     the batch (work items per resident wave), so bench.py / the tests use this to run a one-window parity check on the
- *     kernel the full batch runs (banet_level_t.reserved_ bits 9 / 18 force the patch / strip kernel at any size).        */
+ *     kernel the full batch runs (the BANET_DEV_FORCE_* / _NO_QUAD_GATHER bits of banet_level_t.reserved_).                */
 int banet_gather_selection(const banet_level_t* lv);
+/*   banet_syrk_selection: which depth-block contraction (SYRK) kernel banet_lm_level_f32 runs for this level AND batch size --
+ *     0 = ba_syrk_kernel (LDS-tiled fp32 MFMA), 1 = ba_syrk_direct_kernel (fp32 MFMA, A/B), 2 = ba_syrk_bf16x6_kernel (fp32 operands
+ *     split exactly into three bf16 pieces, six products), 3 = the syrk_wide.hip jobs (K = 256 / many frames), 4 =
+ *     ba_syrk_bf16x6_kernel's fp16 two-piece form (three products, per-column power-of-two scales: throughput-bound launches of
+ *     the LM loop; BANET_DEV_SYRK_F16 runs it in a single assembly pass too, BANET_DEV_NO_SYRK_F16 never); -1000 = no depth block
+ *     (K = 0); other negative = error code.                                                                                    */
+int banet_syrk_selection(const banet_level_t* lv);
 int banet_profile_ranges(int enable);
 
 #ifdef __cplusplus

@@ -129,7 +129,8 @@ def test_argument_validation_without_gpu(capi):
     L = capi.lib()
     assert L.banet_equation_construction_workspace_bytes(1, 4096, 128, 6) > 0
     assert L.banet_equation_construction_workspace_bytes(1, 4096, 128, 134) > 0
-    assert L.banet_equation_construction_workspace_bytes(1, 4096, 128, 273) == 0      # > 17 blocks: unsupported
+    assert L.banet_equation_construction_workspace_bytes(1, 4096, 128, 298) > 0       # cfg-5's P: 19 blocks, the LDS-tiled kernel
+    assert L.banet_equation_construction_workspace_bytes(1, 4096, 128, 305) == 0      # > 19 blocks: unsupported
     assert L.banet_equation_construction_workspace_bytes(0, 4096, 128, 6) == 0
     assert L.banet_equation_construction_f32(None, None, None, None, None, 1, 8, 4, 6, None, 0, None) == -1
     assert L.banet_equation_construction_grad_f32(None, None, None, None, None, None, None, None, 1, 8, 4, 6, None, 0,

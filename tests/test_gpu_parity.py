@@ -50,7 +50,7 @@ def mlp_t(layers):
 # ======================================================================================
 @pytest.mark.parametrize("B,N,C,P", [(1, 4096, 128, 6), (2, 1000, 16, 38), (1, 2048, 128, 134), (3, 77, 7, 6),
                                      (1, 333, 6, 23), (1, 40, 128, 70), (1, 300, 32, 262), (2, 77, 5, 7), (3, 33, 64, 143), (1, 250, 9, 144),
-                                     (2, 130, 16, 145), (1, 1000, 8, 200), (2, 257, 128, 272)])
+                                     (2, 130, 16, 145), (1, 1000, 8, 200), (2, 257, 128, 272), (1, 300, 128, 298), (2, 77, 6, 304)])
 def test_equation_construction_matches_oracle(B, N, C, P):
     from banet_amd import ops
     rng = np.random.RandomState(B * 1000 + N + C + P)
@@ -87,7 +87,7 @@ def test_equation_construction_is_deterministic_and_handles_zeros():
 
 
 @pytest.mark.parametrize("B,N,C,P", [(1, 256, 16, 6), (2, 100, 7, 38), (1, 64, 128, 134), (2, 77, 5, 7), (1, 250, 128, 70), (3, 33, 64, 143),
-                                     (1, 40, 16, 150), (1, 90, 16, 262), (2, 50, 8, 200), (1, 70, 32, 165), (1, 33, 4, 272)])
+                                     (1, 40, 16, 150), (1, 90, 16, 262), (2, 50, 8, 200), (1, 70, 32, 165), (1, 33, 4, 272), (1, 45, 16, 298), (2, 20, 4, 304)])
 def test_equation_construction_grad_matches_oracle(B, N, C, P):
     from banet_amd import ops
     rng = np.random.RandomState(N + C + P)

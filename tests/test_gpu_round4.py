@@ -15,7 +15,8 @@ from oracle import banet_oracle as orc, torch_port
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
-GENERIC, DIRECT, PATCH, STRIP, STRIP_PAIR_LOOP = 32, 64 | 524288, 512, 262144, 262144 | (1 << 22)
+GENERIC, DIRECT, PATCH, STRIP, STRIP_PAIR_LOOP = 32 | (1 << 30), 64 | 524288 | (1 << 30), 512 | (1 << 30), 262144, 262144 | (1 << 22)
+QUAD = 1 << 25
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -51,7 +52,7 @@ def test_mask_output_of_every_gather_kernel(H, W, K, pairs, big):
           for l in levels]
     ba = bdense.DenseBA(t(intr), tl, mlps, "bundle" if K else "bundle_camera", 1000.0)
     masks = {}
-    for bits in (GENERIC, DIRECT, PATCH, STRIP) + ((STRIP_PAIR_LOOP,) if pairs > 1 else ()):
+    for bits in (GENERIC, DIRECT, PATCH, STRIP, QUAD) + ((STRIP_PAIR_LOOP,) if pairs > 1 else ()):
         ba.problems[0].c.reserved_ = bits
         plain = ops.ba_assemble(ba.problems[0], t(R), t(T), t(Wc) if K else None)
         withm = ops.ba_assemble(ba.problems[0], t(R), t(T), t(Wc) if K else None, return_mask=True)
@@ -80,6 +81,70 @@ def test_mask_output_of_every_gather_kernel(H, W, K, pairs, big):
             break
 
 
+@pytest.mark.parametrize("H,W,K,big,pairs", [(48, 64, 128, False, 1),      # whole items
+                                             (41, 57, 16, True, 1),        # ragged items, large motion: rim, masked pixels
+                                             (37, 53, 0, True, 2),         # pose only, 2 target frames
+                                             (30, 40, 128, False, 4),      # cfg-3's coarsest level
+                                             (35, 45, 256, False, 1),      # K = 256 (two basis chunks per row)
+                                             (10, 13, 32, True, 1)])       # a map of a few items
+def test_quad_gather_kernel_matches_oracle(H, W, K, big, pairs):
+    """ba_gather128q_kernel (4x4-pixel items, one step per item) forced at oracle-sized inputs: against the direct C = 128 kernel
+    (same arithmetic per pixel and -- the depth dot is reduced in the same tree order -- the same projections and mask bits;
+    the channel sums are added in another order), run to run, and against the float64 oracle."""
+    from banet_amd import dense as bdense, ops
+    from oracle import dense as odense, synth
+    B, C = 2, 128
+    scenes = [synth.make_window_scene(H, W, C, K, [1], 700 + b, pairs, rot_mag=0.012 * (6 if big else 1),
+                                      trans_mag=0.05 * (6 if big else 1)) for b in range(B)]
+    intr, levels = odense.batch_window_scene(scenes)
+    lv = levels[0]
+    rng = np.random.RandomState(11)
+    R = np.stack([[synth.rodrigues(rng.uniform(-1, 1, 3) * 0.004) for _ in range(pairs)] for _ in range(B)]).astype(np.float32)
+    T = (np.stack([s["T_gt"] for s in scenes]) * 0.8).reshape(B, pairs, 3, 1).astype(np.float32)
+    Wc = (rng.standard_normal((B, K, 1)) * 0.01).astype(np.float32)
+    mlps = [orc.he_normal_mlp_weights(C, 9)]
+    tl = [bdense.DenseLevel(l["scale"], t(l["src"]), t(l["tgt"]), t(l["D0"]), t(l["basis"]) if l["basis"].shape[-1] else None)
+          for l in levels]
+    ba = bdense.DenseBA(t(intr), tl, mlps, "bundle" if K else "bundle_camera", 1000.0)
+    outs = {}
+    for bits in (QUAD, DIRECT):
+        ba.problems[0].c.reserved_ = bits
+        assert ops.gather_selection(ba.problems[0]) == (4 if bits == QUAD else 1)
+        outs[bits] = [n(x) for x in ops.ba_assemble(ba.problems[0], t(R), t(T), t(Wc) if K else None, return_mask=True)]
+        again = [n(x) for x in ops.ba_assemble(ba.problems[0], t(R), t(T), t(Wc) if K else None, return_mask=True)]
+        for x, y in zip(outs[bits], again):                       # bit-reproducible run to run
+            np.testing.assert_array_equal(x, y)
+    ba.problems[0].c.reserved_ = 0
+
+    def relerr(got, want):
+        want, got = np.asarray(want, np.float64), np.asarray(got, np.float64)
+        return float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-30))
+    for name, x, y in zip(("AtA", "Atb", "absres"), outs[QUAD], outs[DIRECT]):
+        assert relerr(x, y) < 3e-6, (name, relerr(x, y))
+    np.testing.assert_array_equal(outs[QUAD][3], outs[DIRECT][3])   # nvalid
+    np.testing.assert_array_equal(outs[QUAD][4], outs[DIRECT][4])   # every mask bit
+    got = outs[QUAD][0]
+    np.testing.assert_array_equal(got, np.swapaxes(got, 1, 2))
+    one = dict(lv)
+    one["tgt"] = lv["tgt"][:, 0]
+    a = odense.level_inputs(intr, one, True, np.float64)
+    R64 = [R[:, i].astype(np.float64) for i in range(pairs)]
+    T64 = [T[:, i].astype(np.float64) for i in range(pairs)]
+    if K:
+        conv2s = [orc.target_map(lv["tgt"][:, i].astype(np.float64)) for i in range(pairs)]
+        dbg = orc.bundle_window_iteration(a["conv1"], conv2s, a["fx"], a["fy"], a["ox"], a["oy"], a["p"], a["D"], a["Bs"],
+                                          R64, T64, Wc.astype(np.float64), mlps[0], 1000.0)[3]
+        assert relerr(outs[QUAD][0], dbg["AtA"]) < 3e-5 and relerr(outs[QUAD][1][..., None], dbg["Atb"]) < 3e-5
+        nv = sum(m.sum(axis=(1, 2)) for m in dbg["mask"])
+        assert np.abs(outs[QUAD][3] - nv).max() <= 1
+        assert relerr(outs[QUAD][2] / (H * W * pairs), dbg["avg"][:, 0]) < 1e-5
+    else:
+        for i in range(pairs):
+            d = orc.bundle_camera_iteration(a["conv1"], orc.target_map(lv["tgt"][:, i].astype(np.float64)), a["fx"], a["fy"],
+                                            a["ox"], a["oy"], a["p"], a["D"], R64[i], T64[i], mlps[0], 1.0)[2]
+            assert relerr(outs[QUAD][0][:, 6 * i:6 * i + 6, 6 * i:6 * i + 6], d["AtA"]) < 3e-5
+
+
 def test_twin_with_forced_mask():
     """torch_port.window_iteration(mask_override=...): its own mask reproduces its own result; one flipped bit moves lambda by
     about one pixel's worth (what a float32 / float64 disagreement on a border pixel does)."""
@@ -105,3 +170,140 @@ def test_twin_with_forced_mask():
     *_, d3 = torch_port.window_iteration(*args, mask_override=m2.to(torch.uint8))
     dl = float((d3["lam"] - d["lam"]).abs() / d["lam"].abs())
     assert 0 < dl < 50.0 / (H * W * pairs)
+
+
+# ======================================================================================
+# the fp16 two-piece form of the depth-block contraction (syrk.hip, ba_syrk_bf16x6_kernel<.., .., 16>)
+# ======================================================================================
+SYRK_F16 = 1 << 24          # the single assembly pass runs it too (default: LM loop, throughput-bound launches only)
+
+
+def _entry_errors(AtA, Atb, absres, A64, b64):
+    dg = np.sqrt(np.maximum(np.diag(A64), 1e-300))
+    eA = np.abs(n(AtA).astype(np.float64) - A64) / np.outer(dg, dg)
+    rs = float(np.sqrt((n(absres).astype(np.float64) ** 2).sum()))
+    eb = np.abs(n(Atb).astype(np.float64) - b64) / (dg * max(rs, 1e-30))
+    return eA, eb, dg
+
+
+@pytest.mark.parametrize("K,H,W,pairs,span", [(128, 96, 128, 1, 12.0), (64, 48, 64, 1, 12.0), (128, 64, 96, 3, 12.0), (128, 96, 128, 1, 40.0)])
+def test_syrk_f16_two_piece_with_basis_columns_spanning_many_octaves(K, H, W, pairs, span):
+    """Same gate as test_syrk_bf16x6_with_basis_columns_spanning_4096x (every entry of AtA / Atb within 3e-5 of ITS OWN scale
+    sqrt(A_ii A_jj) against the float64 twin), for the fp16 two-piece form: column k scaled by 2^(span k / (K-1)) -- 2^12 as there,
+    and 2^40, far beyond fp16's range: the per-column power-of-two scales absorb it.  Pose block and sum|d| untouched (gather)."""
+    from banet_amd import dense as bdense, ops, synth as bsynth
+    B, C = 2, 128
+    intr, levels, gt = bsynth.make_dense_windows(B, H, W, C, K, [1], 91, DEV, trans_mag=0.06, pairs=pairs)
+    lv = levels[0]
+    scale = torch.pow(2.0, span * torch.arange(K, dtype=torch.float64) / (K - 1) - span / 2).to(torch.float32).to(DEV)
+    perm = torch.randperm(K, generator=torch.Generator().manual_seed(5)).to(DEV)
+    lv.basis = (lv.basis * scale[perm]).contiguous()
+    ba = bdense.DenseBA(intr, levels, [orc.he_normal_mlp_weights(C, 5)], "bundle", 1000.0)
+    p = ba.problems[0]
+    R = torch.eye(3, device=DEV).repeat(B, pairs, 1, 1) if pairs > 1 else torch.eye(3, device=DEV).repeat(B, 1, 1)
+    T = (gt["T"] * 0.7).reshape(B, pairs, 3, 1).to(DEV) if pairs > 1 else (gt["T"] * 0.7).reshape(B, 3, 1).to(DEV)
+    Wc = torch.zeros(B, K, 1, device=DEV)
+    exact = [x.clone() for x in ops.ba_assemble(p, R, T, Wc)]
+    p.c.reserved_ = SYRK_F16
+    f16 = [x.clone() for x in ops.ba_assemble(p, R, T, Wc)]
+    again = [x.clone() for x in ops.ba_assemble(p, R, T, Wc)]
+    p.c.reserved_ = 0
+    assert all(torch.equal(a, b) for a, b in zip(f16, again))                  # bit-reproducible
+    assert not torch.equal(exact[0], f16[0])                                   # another kernel ran
+    o = 6 * pairs
+    assert torch.equal(exact[0][:, :o, :o], f16[0][:, :o, :o]) and torch.equal(exact[2], f16[2])
+    assert torch.equal(f16[0], f16[0].transpose(1, 2))
+    tg = lv.tgt if lv.tgt.dim() == 5 else lv.tgt.unsqueeze(1)
+    for b in range(B):
+        sl = slice(b, b + 1)
+        A64, b64, _, _ = torch_port.window_assemble(intr[sl], lv.scale, lv.src[sl], tg[sl], lv.depth[sl], lv.basis[sl],
+                                                    R.reshape(B, pairs, 3, 3)[sl], T.reshape(B, pairs, 3, 1)[sl], Wc[sl])
+        A64, b64 = n(A64[0]), n(b64[0])
+        eA, eb, dg = _entry_errors(f16[0][b], f16[1][b], f16[2][b], A64, b64)
+        xA, xb, _ = _entry_errors(exact[0][b], exact[1][b], exact[2][b], A64, b64)
+        print("K=%d pairs=%d span 2^%g window %d: fp16 two-piece AtA %.2e Atb %.2e | bf16x6 AtA %.2e Atb %.2e" % (
+            K, pairs, span, b, eA.max(), eb.max(), xA.max(), xb.max()))
+        assert eA.max() < 3e-5, (b, eA.max(), np.unravel_index(eA.argmax(), eA.shape))
+        assert eb.max() < 3e-5, (b, eb.max())
+        assert dg[o:].max() / dg[o:].min() > 2.0 ** (span - 3)
+
+
+def test_syrk_f16_flush_and_fallback_cases():
+    """(a) pixels whose s_n lies 2^-40 .. 1 below the window's largest (their sqrt(s) b is flushed by the split): the sums still
+    agree with float64 per entry; (b) a window whose basis holds an Inf: the scales cannot be formed, that window runs the exact
+    bf16 form -- bit-identical to the default kernel -- while the other window runs the fp16 form."""
+    from banet_amd import dense as bdense, ops, synth as bsynth
+    B, C, K, H, W = 2, 128, 128, 96, 128
+    intr, levels, gt = bsynth.make_dense_windows(B, H, W, C, K, [1], 93, DEV, trans_mag=0.06)
+    lv = levels[0]
+    # (a) the target features of the image's lower half scaled by 2^-20: their gradients, hence s_n, drop by 2^-40
+    tgt = lv.tgt.clone()
+    tgt[:, H // 2:] *= 2.0 ** -20
+    src = lv.src.clone()
+    src[:, H // 2:] *= 2.0 ** -20
+    lva = bdense.DenseLevel(lv.scale, src, tgt, lv.depth, lv.basis)
+    ba = bdense.DenseBA(intr, [lva], [orc.he_normal_mlp_weights(C, 5)], "bundle", 1000.0)
+    p = ba.problems[0]
+    R = torch.eye(3, device=DEV).repeat(B, 1, 1)
+    T = (gt["T"] * 0.7).reshape(B, 3, 1).to(DEV)
+    Wc = torch.zeros(B, K, 1, device=DEV)
+    p.c.reserved_ = SYRK_F16
+    f16 = [x.clone() for x in ops.ba_assemble(p, R, T, Wc)]
+    p.c.reserved_ = 0
+    for b in range(B):
+        sl = slice(b, b + 1)
+        r = torch_port.dense_assemble(intr[sl], lva.scale, lva.src[sl], lva.tgt[sl], lva.depth[sl], lva.basis[sl], R[sl], T[sl], Wc[sl], True, True)
+        eA, eb, _ = _entry_errors(f16[0][b], f16[1][b], f16[2][b], n(r[0][0]), n(r[1][0]))
+        assert eA.max() < 3e-5 and eb.max() < 3e-5, (b, eA.max(), eb.max())
+    # (b) one Inf in window 1's basis
+    basis = lv.basis.clone()
+    basis[1, 777, 5] = float("inf")
+    lvb = bdense.DenseLevel(lv.scale, lv.src, lv.tgt, lv.depth, basis)
+    bb = bdense.DenseBA(intr, [lvb], [orc.he_normal_mlp_weights(C, 5)], "bundle", 1000.0)
+    pb = bb.problems[0]
+    exact = [x.clone() for x in ops.ba_assemble(pb, R, T, Wc)]
+    pb.c.reserved_ = SYRK_F16
+    mixed = [x.clone() for x in ops.ba_assemble(pb, R, T, Wc)]
+    pb.c.reserved_ = 0
+    assert torch.equal(mixed[0][1].nan_to_num(1.0, 2.0, 3.0), exact[0][1].nan_to_num(1.0, 2.0, 3.0))     # window 1: the exact form's bits
+    assert not torch.equal(mixed[0][0], exact[0][0]) and torch.isfinite(mixed[0][0]).all()                # window 0: the fp16 form
+
+
+def test_lm_loop_with_the_f16_syrk_matches_the_exact_form_and_the_twin():
+    """The LM loop's default at throughput-bound launches (here forced by reserved_ bit 24 at a small size; bit 31 = never): ten
+    iterations with the fp16 two-piece SYRK stay within 1e-4 of the same loop on the exact bf16 form, iteration counts equal, and
+    one step agrees with the float64 twin per coefficient group like the exact form's."""
+    from banet_amd import dense as bdense, synth as bsynth
+    from banet_amd.bundlenet import he_normal_lambda_weights
+    B, H, W, C, K = 4, 120, 160, 128, 128
+    intr, levels, gt = bsynth.make_dense_windows(B, H, W, C, K, [2, 1], 611, DEV, trans_mag=0.06)
+    mlps = [he_normal_lambda_weights(C, 100 + i) for i in range(2)]
+    ba = bdense.DenseBA(intr, levels, mlps, "bundle", 1000.0)
+    T0 = (gt["T"] * 0.7).reshape(B, 3, 1).to(DEV)
+    res = {}
+    for bits in (SYRK_F16, -2147483648):
+        for prob in ba.problems:
+            prob.c.reserved_ = bits
+        st, counts = ba.solve([10, 10], ba.new_state(T=T0.clone()))
+        res[bits] = (st.R.clone(), st.T.clone(), st.Wc.clone(), [c.clone() for c in counts])
+        s1 = ba.step_from(1, torch.eye(3, device=DEV).repeat(B, 1, 1), T0.clone(), torch.zeros(B, K, 1, device=DEV))
+        res[bits] += (s1.delta.clone(), s1.lambda_out.clone())
+    for prob in ba.problems:
+        prob.c.reserved_ = 0
+    a, e = res[SYRK_F16], res[-2147483648]
+
+    def rel(x, y):
+        return float((x - y).abs().max() / y.abs().max())
+    assert rel(a[0], e[0]) < 1e-5 and rel(a[1], e[1]) < 1e-4 and rel(a[2], e[2]) < 1e-4, (rel(a[0], e[0]), rel(a[1], e[1]), rel(a[2], e[2]))
+    assert all(torch.equal(x, y) for x, y in zip(a[3], e[3]))
+    assert not torch.equal(a[4], e[4])                                 # the fp16 form really ran in the LM loop
+    lv = levels[1]
+    for b in (0, B - 1):
+        sl = slice(b, b + 1)
+        *_, d = torch_port.window_iteration(intr[sl], lv.scale, lv.src[sl], lv.tgt[sl].unsqueeze(1), lv.depth[sl], lv.basis[sl],
+                                            torch.eye(3, device=DEV).reshape(1, 1, 3, 3), T0[sl].unsqueeze(1), torch.zeros(1, K, 1, device=DEV),
+                                            [(n(w_), n(b_)) for w_, b_ in mlps[1]], 1000.0)
+        sol = d["solution"][0]
+        for name, slc in (("pose", slice(0, 6)), ("depth", slice(6, -1)), ("last", slice(-1, None))):
+            err = float((a[4][b][slc].double() - sol[slc]).abs().max() / sol[slc].abs().max())
+            assert err < 1e-4, (b, name, err)
