@@ -514,7 +514,7 @@ int plan_gather(const banet_level_t* lv, GatherPlan* pl) {
   // per resident wave (2 workgroups x 4 waves per CU); beyond that the tile kernels' shared stencils win.
   // reserved_ bit 25: force it at any size (parity tests, A/B); bit 30: off.
   pl->quad = 0;
-  if (pl->c128 && lv->dense && !(lv->reserved_ & (1 << 30))) {
+  if (pl->c128 && lv->dense && !(lv->reserved_ & ((1 << 30) | 512 | 64))) {   // (bits 9 / 6 force the patch / direct tile kernels)
     const int qxn = (lv->W + 3) / 4, qyn = (lv->H + 3) / 4;
     const long long qitems = (long long)qxn * qyn * lv->B * npairs(lv);
     if (qitems <= (long long)kQuadRounds * kCUs * 8 || (lv->reserved_ & (1 << 25))) {

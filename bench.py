@@ -275,8 +275,8 @@ def twin_parity(prob, dev, window=0):
         rec.update(R=rel(s1.R.reshape(B, pairs, 3, 3)[window].cpu().numpy(), R2[0].cpu().numpy()),
                    T=rel(s1.T.reshape(B, pairs, 3, 1)[window].cpu().numpy(), T2[0].cpu().numpy()),
                    W=rel(s1.Wc[window].cpu().numpy(), W2[0].cpu().numpy()),
-                   mask_pixels_gpu=nv_gpu, mask_pixels_f64=nv64, mask_bits_differing=flips,
-                   mask_borderline_pixels=float(d["borderline"][0]))
+                   mask_pixels_gpu=int(nv_gpu), mask_pixels_f64=int(nv64), mask_bits_differing=flips,     # integers: exact in the record
+                   mask_borderline_pixels=int(d["borderline"][0]))
         if flips:
             so = own["solution"][0].cpu().numpy()
             rec["flipped_pixels"] = flipped
@@ -325,7 +325,20 @@ def twin_parity(prob, dev, window=0):
             "mask_bits_differing": nflips, "per_level": per_level}
 
 
-def sub_record(frames, B, Hh, Ww, Kk, iters_per_level, steps, warmup, seed, dev, fence, reserved, scales=None, parity=True):
+def sweep_traffic(name, B):
+    """HBM-side bytes per gather launch of a sweep workload from profiles/pmc_traffic.json ("workloads"[name], same build)"""
+    try:
+        from banet_amd import _capi
+        pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        w = (pj.get("workloads") or {}).get(name)
+        if w and w.get("windows") == B and w.get("build_id") == _capi.lib().banet_build_id().decode():
+            return w.get("hbm_bytes_per_launch")
+    except Exception:  # noqa: BLE001
+        pass
+    return None
+
+
+def sub_record(frames, B, Hh, Ww, Kk, iters_per_level, steps, warmup, seed, dev, fence, reserved, scales=None, parity=True, name=None):
     """One sweep entry measured like the headline (smaller step count) + its own in-line parity record."""
     import torch
     prob = Problem(B, frames, Hh, Ww, Kk, seed, dev, reserved, scales)
@@ -333,15 +346,15 @@ def sub_record(frames, B, Hh, Ww, Kk, iters_per_level, steps, warmup, seed, dev,
     iters = [iters_per_level] * nl
     elapsed, prof, st = timed_run(prob, iters, steps, warmup, B, fence)
     chk = prob.convergence_check(st, dev)
-    rl = roofline_record(prob, prof, elapsed)
+    rl = roofline_record(prob, prof, elapsed, sweep_traffic(name, B) if name else None)
     step_bytes = sum(prob.ba.algorithmic_bytes_per_iteration(li) for li in range(nl)) * B * iters_per_level
     rec = {"workload": workload_name(frames, B, Hh, Ww, Kk, iters_per_level, nl), "windows": B, "frames": frames,
            "value": round(B * sum(iters) * steps / elapsed, 2), "unit": "LM iterations/s", "steps": steps, "warmup": warmup,
            "ms_per_step": round(1e3 * elapsed / steps, 3), "ms_per_solve": round(1e3 * elapsed / steps / B, 3),
            "end_to_end_hbm_frac": round(step_bytes / (elapsed / steps) / 1e9 / HBM_PEAK_GBS, 4),
            "finest_level_only_value": round(B * iters_per_level / (prob.level_ms[-1] * 1e-3), 2) if getattr(prob, "level_ms", None) else None,
-           "roofline": {k: rl[k] for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "kernel_time_share",
-                                           "syrk_kernel", "per_level")},
+           "roofline": {k: rl[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_GBps", "algorithmic_bytes_per_launch",
+                                           "avg_launch_us", "kernel_time_share", "kernel", "syrk_kernel", "per_level")},
            "check": chk}
     if parity:
         rec["parity"] = twin_parity(prob, dev)
@@ -538,6 +551,8 @@ def compact_record(out):
         for name, rec in sw.items():
             e = {"value": rec.get("value"), "ms_per_step": rec.get("ms_per_step"), "steps": rec.get("steps"),
                  "frac": (rec.get("roofline") or {}).get("frac"), "e2e_frac": rec.get("end_to_end_hbm_frac")}
+            if (rec.get("roofline") or {}).get("traffic"):
+                e["traffic_x"] = round(rec["roofline"]["traffic"] / max(rec["roofline"].get("algorithmic_bytes_per_launch") or 1, 1), 3)
             if "parity" in rec:
                 e["parity_max"] = rec["parity"].get("max_rel_err")
                 e["parity_ok"] = rec["parity"].get("ok")
@@ -719,7 +734,7 @@ def main():
                     entries += [("B256_2frame",    2,   256, H,  W,    K,   10,  3,    1,   None),
                                 ("cfg5_8frame_1280x960_K256_B8", 8, 8, 960, 1280, 256, 15, 3, 1, None)]
                 for name, fr, bb, hh, ww, kk, it, stp, wu, sc in entries:
-                    sweep[name] = sub_record(fr, bb, hh, ww, kk, it, stp, wu, 4321, dev, fence, args.reserved, sc, par)
+                    sweep[name] = sub_record(fr, bb, hh, ww, kk, it, stp, wu, 4321, dev, fence, args.reserved, sc, par, name)
                 out["sweep"] = sweep
                 out["co_headline"] = {"cfg3_5frame_B32": {k: sweep["cfg3_5frame_B32"][k] for k in ("value", "unit", "ms_per_step", "steps")},
                                       "note": "configs[2] is the only configuration BASELINE.json quotes literally at batch 32 on one "

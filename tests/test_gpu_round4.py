@@ -257,7 +257,7 @@ def test_syrk_f16_flush_and_fallback_cases():
         assert eA.max() < 3e-5 and eb.max() < 3e-5, (b, eA.max(), eb.max())
     # (b) one Inf in window 1's basis
     basis = lv.basis.clone()
-    basis[1, 777, 5] = float("inf")
+    basis.reshape(B, H * W, K)[1, 777, 5] = float("inf")
     lvb = bdense.DenseLevel(lv.scale, lv.src, lv.tgt, lv.depth, basis)
     bb = bdense.DenseBA(intr, [lvb], [orc.he_normal_mlp_weights(C, 5)], "bundle", 1000.0)
     pb = bb.problems[0]
