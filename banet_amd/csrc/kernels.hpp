@@ -20,6 +20,7 @@ struct GatherPlan {
   int patch;    // 1: ba_gather128p_kernel (same interface; taps from wave-private LDS patches) for large levels
   int strip;    // ba_gather128s_kernel (work items = 16-pixel-wide strip segments, rolling LDS window): pixel rows per segment
                 //    (32 or 16; 0 = another kernel); tiles_x / tiles_y / tiles then count segments
+  int quad_deep; // quad: the one-wave-per-SIMD form (launches of at most ~kQuadDeepRounds items per such wave)
   int quad;     // 1: ba_gather128q_kernel (work items = 4x4 pixel blocks, one step per item): latency-bound launches; tiles_x / tiles_y / tiles count items
   int strip_fp; // strip kernel, multi-frame windows: a workgroup = `pairs` waves on one segment, wave p against target frame p
   int rows;     // partial rows per window written by the gather kernel (tiles or G)

@@ -350,7 +350,9 @@ def test_cg_solve_and_ldlt_fallback_match_the_oracle_lu(l2_base, pairs):
             for bits in sols:
                 err = np.abs(sols[bits][0][b][sl] - truth[sl]).max() / scale
                 assert err < 1e-4, (l2_base, pairs, b, name, bits, err, lam)
-    assert np.abs(sols[0][0] - sols[1 << 23][0]).max() <= 2e-5 * np.abs(sols[1 << 23][0]).max()
+    # (both are within 1e-4 of the float64 solution per group; against each other: 5e-5 of the largest entry -- the weakly damped
+    # cases, l2_base <= 1, are conditioned ~1e3 and sit at 2-3e-5 depending on the rounding of the assembled matrix)
+    assert np.abs(sols[0][0] - sols[1 << 23][0]).max() <= 5e-5 * np.abs(sols[1 << 23][0]).max()
 
 
 def test_strip_gather_under_the_legacy_early_terminated_lm():
