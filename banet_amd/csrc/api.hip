@@ -304,7 +304,9 @@ int banet_lm_level_ex_f32(const banet_level_t* lv, const banet_mlp_t* mlp, float
     for (int it = 0; it < max_iters; ++it) {
       rc = launch_assemble(lv, pl, st->R, st->T, st->Wc, nullptr, 0, w.partials, w.AtA, w.Atb, w.absres, w.nvalid, s,
                            a.queue == nullptr, role ? mlp : nullptr, role ? w.mlp_y : nullptr, nullptr,
-                           pl.s.f16 ? (it == 0 ? 0 : 1) : -1);   // basis column maxima: once per level
+                           // fp16 two-piece SYRK: the level's first pass runs the exact form and leaves the basis column maxima
+                           // on the way (no extra pass over the basis); a one-iteration call computes them up front instead
+                           pl.s.f16 ? (it == 0 ? (max_iters > 1 ? 2 : 0) : 1) : -1);
       if (rc != BANET_OK) return rc;
       {
         RangeScope r("solve", lv->N);

@@ -432,8 +432,7 @@ __global__ __launch_bounds__(kBlock, BANET_GATHER_WAVES) void ba_gather_kernel(c
 // --------------------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------------------
-constexpr int kQuadDeepRounds = 3;   // ... in its one-wave-per-SIMD form
-constexpr int kQuadRounds = 6;       // ba_gather128q_kernel: most items per resident wave (measured: tools/gpu_r4_quad.sh)
+constexpr int kQuadRounds = 12;      // ba_gather128q_kernel: most items per resident wave (measured, profiles/r04_run6_*: wins up to 19200 items -- 640x480 x 1, 160x120 x 8, 80x60 x 32 -- loses at 38400)
 constexpr int kStripSegW = 16, kStripSegH = 32, kStripMinW = 21;   // = kStripW, kStripH, kWinTex of strip_plan.hpp (gather128s.hip)
 constexpr int kGenericBlocksPerCU = BANET_GATHER_WAVES;  // ba_gather_kernel: launch bounds
 constexpr int kC128BlocksPerCU = BANET_G128_WAVES;       // ba_gather128_kernel: launch bounds (LDS: 18 KB)
@@ -484,7 +483,7 @@ int plan_gather(const banet_level_t* lv, GatherPlan* pl) {
     if ((long long)sxn * syn * lv->B >= 4LL * slots || (lv->reserved_ & 262144)) {
       pl->strip = segh;
       pl->strip_fp = fp ? 1 : 0;
-      pl->quad = pl->quad_deep = 0;
+      pl->quad = 0;
       pl->tiles_x = sxn;
       pl->tiles_y = syn;
       pl->tiles = sxn * syn;
@@ -514,23 +513,20 @@ int plan_gather(const banet_level_t* lv, GatherPlan* pl) {
   // ~4x shorter serial chain per item than a tile's 16 steps (gather128q.hip) -- while the launch has at most kQuadRounds items
   // per resident wave (2 workgroups x 4 waves per CU); beyond that the tile kernels' shared stencils win.
   // reserved_ bit 25: force it at any size (parity tests, A/B); bit 30: off.
-  pl->quad = pl->quad_deep = 0;
+  pl->quad = 0;
   if (pl->c128 && lv->dense && !(lv->reserved_ & ((1 << 30) | 512 | 64))) {   // (bits 9 / 6 force the patch / direct tile kernels)
     const int qxn = (lv->W + 3) / 4, qyn = (lv->H + 3) / 4;
     const long long qitems = (long long)qxn * qyn * lv->B * npairs(lv);
     if (qitems <= (long long)kQuadRounds * kCUs * 8 || (lv->reserved_ & (1 << 25))) {
       const int VBq = lv->B * npairs(lv);
       pl->quad = 1;
-      // the one-wave-per-SIMD form (all of an item's loads in flight at once) while the launch has at most kQuadDeepRounds items
-      // per such wave (kCUs x 4 of them); reserved_ bit 7: always, bit 13: never (A/B)
-      pl->quad_deep = ((qitems <= (long long)kQuadDeepRounds * kCUs * 4 || (lv->reserved_ & 128)) && !(lv->reserved_ & 8192)) ? 1 : 0;
       pl->patch = 0;
       pl->pairloop = 0;
       pl->qshift = 0;
       pl->tiles_x = qxn;
       pl->tiles_y = qyn;
       pl->tiles = qxn * qyn;
-      int G = (kCUs * (pl->quad_deep ? 1 : 2) + VBq - 1) / VBq;   // one resident round of 256-thread workgroups, 2 (deep: 1) per CU
+      int G = (kCUs * 2 + VBq - 1) / VBq;            // one resident round of 256-thread workgroups, 2 per CU
       const int want = (pl->tiles + kNumWaves - 1) / kNumWaves;
       if (G > want) G = want;
       if (G < 1) G = 1;
@@ -686,7 +682,6 @@ int launch_gather(const banet_level_t* lv, const GatherPlan& pl, const float* R,
   a.pairloop = pl.pairloop;
   a.seg_h = pl.strip;
   a.strip_fp = pl.strip_fp;
-  a.quad_deep = pl.quad_deep;
   a.mask_out = mask_out;
   int rc;
   if (pl.c128)

@@ -14,9 +14,11 @@
 //   * per-pixel algebra on the quad's lanes (redundantly), lane q = 0 contributes; one partial row per item (28 pose sums
 //     through the transposing butterfly, C x sum|d| folded over the 16 pixels in a fixed order): bit-reproducible, and the
 //     result does not depend on which wave processed which item;
-//   * no LDS staging, no workgroup barrier (a workgroup is 4 independent waves); two forms: 2 waves per SIMD with two units of
-//     loads in flight (104 registers), or -- DEEP, launches of about one item per wave -- 1 wave per SIMD with all 8 units in
-//     flight (416 registers): the taps of an item then cost one memory round trip.
+//   * no LDS staging, no workgroup barrier (a workgroup is 4 independent waves), 2 waves per SIMD with two units of loads in
+//     flight (104 registers).  (A form with 1 wave per SIMD and all 8 units = 416 registers in flight was measured: no faster
+//     anywhere, slower from 3 items per wave on -- profiles/r04_run5_*: the item's time is not its tap round trips.)
+//   * items are assigned statically (wave g of the launch takes items g, g + waves, ...: they cost the same), no atomic queue:
+//     at one window the queue's single counter was popped 2 x items times and serialised the launch.
 // Same arithmetic per pixel as ba_gather128_kernel; the channel sums are added unit by unit (different rounding order).
 // Selected by plan_gather for launches with few items per resident wave (reserved_ bit 25 forces it, bit 30 disables it).
 #include "quad_common.hpp"
@@ -45,9 +47,8 @@ struct QTaps {           // one unit: the 13 rows of 4 channels a pixel's stenci
 __device__ __forceinline__ float4 f4(const f32x4& v) { return make_float4(v[0], v[1], v[2], v[3]); }
 
 // KV4 = number of 128-coefficient chunks of a basis row (0: pose only; K % 4 == 0, K <= 128 KV4)
-// DEEP: one wave per SIMD, every load of an item's taps in flight at once (launches of at most ~one item per such wave)
-template <int KV4, bool DEEP>
-__global__ __launch_bounds__(kBlock, DEEP ? 1 : 2) void ba_gather128q_kernel(const GatherArgs a) {
+template <int KV4>
+__global__ __launch_bounds__(kBlock, 2) void ba_gather128q_kernel(const GatherArgs a) {
   __shared__ float sAbs[kNumWaves][kC128q];
   const banet_level_t& lv = a.lv;
   const int vb = blockIdx.y;                   // vb = (window, pair)
@@ -70,18 +71,8 @@ __global__ __launch_bounds__(kBlock, DEEP ? 1 : 2) void ba_gather128q_kernel(con
   const int qx = p & 3, qy = p >> 2;
   const int rowC = W * C;
 
-  int* __restrict__ queue = a.queue + vb * 8;
-  auto pop_raw = [&]() {
-    int v = 0;
-    if (lane == 0) v = atomicAdd(&queue[0], 1);
-    return v;
-  };
-  int raw_next = pop_raw();
-
-  while (true) {
-    const int wi = rfl(raw_next);
-    if (wi >= nitems) return;
-    raw_next = pop_raw();   // issued now, read at the top of the next item
+  const int nwaves = gridDim.x * kNumWaves;
+  for (int wi = blockIdx.x * kNumWaves + w; wi < nitems; wi += nwaves) {
     const int iy = wi / items_x, ix = wi - iy * items_x;
     const int px = 4 * ix + qx, py = 4 * iy + qy;
     const bool valid = (px < W) && (py < H);
@@ -162,23 +153,8 @@ __global__ __launch_bounds__(kBlock, DEEP ? 1 : 2) void ba_gather128q_kernel(con
       tap_math_s(f4(cur.f1), f4(cur.a0), f4(cur.a1), f4(cur.a2), f4(cur.a3), f4(cur.b0), f4(cur.b1), f4(cur.b2), f4(cur.b3),
                  f4(cur.m1), f4(cur.m2), f4(cur.p1), f4(cur.p2), w00, w01, w10, w11, mk, qq, absd[u]);
     };
-    if constexpr (DEEP) {
-      // one wave per SIMD (512 registers): all 8 units = 104 x 16 bytes per lane in flight at once -- the item's taps cost ONE
-      // memory round trip
-      QTaps tt[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) issue(tt[u], u);
-      __builtin_amdgcn_sched_barrier(0);
-      compute(tt[0], QC<0>{});
-      compute(tt[1], QC<1>{});
-      compute(tt[2], QC<2>{});
-      compute(tt[3], QC<3>{});
-      compute(tt[4], QC<4>{});
-      compute(tt[5], QC<5>{});
-      compute(tt[6], QC<6>{});
-      compute(tt[7], QC<7>{});
-    } else {
-      // two waves per SIMD: two register buffers, unit u + 1 in flight while unit u is computed
+    {
+      // two register buffers, unit u + 1 in flight while unit u is computed
       QTaps t0, t1;
       issue(t0, 0);
       auto unit = [&](auto uc) __attribute__((always_inline)) {
@@ -234,11 +210,6 @@ __global__ __launch_bounds__(kBlock, DEEP ? 1 : 2) void ba_gather128q_kernel(con
     // ---- 5. per-pixel 6x6 algebra; lane q = 0 of a quad contributes; records; the item's 28 pose sums ---------------------------
     float* __restrict__ part = part_b + (size_t)wi * (kGHdr + C);
     const bool own = q == 0;
-    if constexpr (DEEP) {     // the Jacobian rows again (same statements, same bits) rather than 30 registers held across the taps
-      float Dq = D;
-      asm volatile("" : "+v"(Dq));      // opaque: the compiler must not keep the first evaluation's values alive instead
-      strip_geometry(lv, b, Rm, Tv, valid, px, py, Dq, ge);
-    }
     {
       const float* jc = ge.jc;
       float mj[12];
@@ -303,16 +274,14 @@ __global__ __launch_bounds__(kBlock, DEEP ? 1 : 2) void ba_gather128q_kernel(con
 
 int launch_gather128q(const GatherArgs& a, int K, hipStream_t s) {
   dim3 grid(a.G, a.lv.B * a.pairs), block(kBlock);
-#define BANET_LAUNCH_Q(KV4)                                                                        \
-  do {                                                                                             \
-    if (a.quad_deep) hipLaunchKernelGGL((ba_gather128q_kernel<KV4, true>), grid, block, 0, s, a);  \
-    else hipLaunchKernelGGL((ba_gather128q_kernel<KV4, false>), grid, block, 0, s, a);             \
-  } while (0)
-  if (K == 0) BANET_LAUNCH_Q(0);
-  else if ((K & 3) == 0 && K <= 128) BANET_LAUNCH_Q(1);
-  else if ((K & 3) == 0 && K <= 256) BANET_LAUNCH_Q(2);
-  else return BANET_ERR_UNSUPPORTED;
-#undef BANET_LAUNCH_Q
+  if (K == 0)
+    hipLaunchKernelGGL((ba_gather128q_kernel<0>), grid, block, 0, s, a);
+  else if ((K & 3) == 0 && K <= 128)
+    hipLaunchKernelGGL((ba_gather128q_kernel<1>), grid, block, 0, s, a);
+  else if ((K & 3) == 0 && K <= 256)
+    hipLaunchKernelGGL((ba_gather128q_kernel<2>), grid, block, 0, s, a);
+  else
+    return BANET_ERR_UNSUPPORTED;
   return BANET_OK;
 }
 

@@ -22,7 +22,6 @@ struct GatherArgs {
   int qshift;       // ba_gather128_kernel: 0 = a work item is a tile, 2 = a quarter tile (small levels)
   int seg_h;        // ba_gather128s_kernel: pixel rows per strip segment (32 or 16)
   unsigned char* mask_out;   // optional (parity diagnostics): [B * pairs][N] the in-image mask bit of every pixel, or nullptr
-  int quad_deep;    // ba_gather128q_kernel: 1 = one wave per SIMD, all of an item's loads in flight
   int strip_fp;     // ba_gather128s_kernel: 1 = frame-parallel workgroups (`pairs` waves per segment, one per target frame)
 };
 

@@ -20,7 +20,6 @@ struct GatherPlan {
   int patch;    // 1: ba_gather128p_kernel (same interface; taps from wave-private LDS patches) for large levels
   int strip;    // ba_gather128s_kernel (work items = 16-pixel-wide strip segments, rolling LDS window): pixel rows per segment
                 //    (32 or 16; 0 = another kernel); tiles_x / tiles_y / tiles then count segments
-  int quad_deep; // quad: the one-wave-per-SIMD form (launches of at most ~kQuadDeepRounds items per such wave)
   int quad;     // 1: ba_gather128q_kernel (work items = 4x4 pixel blocks, one step per item): latency-bound launches; tiles_x / tiles_y / tiles count items
   int strip_fp; // strip kernel, multi-frame windows: a workgroup = `pairs` waves on one segment, wave p against target frame p
   int rows;     // partial rows per window written by the gather kernel (tiles or G)
@@ -68,7 +67,8 @@ int launch_syrk_wide(const float* basis, const float* rec, int B, int N, int K, 
 int plan_syrk(int B, int N, int K, int pairs, int dbg, SyrkPlan* pl);
 int launch_syrk(const float* basis, const float* rec, int B, int N, int K, int pairs, const SyrkPlan& pl,
                 const int32_t* active, int active_stride, float* partials, hipStream_t s, const MlpRole* mr = nullptr,
-                int f16_stats = -1);   // f16_stats: -1 = exact bf16 form; 0 / 1 = fp16 two-piece form (pl.f16), basis column maxima to compute / in place
+                int f16_stats = -1);   // f16_stats: -1 = exact bf16 form; 0 / 1 = fp16 two-piece form (pl.f16), basis column maxima to compute / in
+                                       // place; 2 = exact bf16 form that also leaves the column maxima (first iteration of a level)
 inline bool syrk_runs_mlp_role(const SyrkPlan& pl) { return pl.direct == 2; }   // ba_syrk_bf16x6_kernel only
 void launch_reduce2(const float* gpart, int Gg, int gstride, const float* spart, int Gs, int sstride,
                     const int32_t* active, int active_stride, int B, int K, int C, int pairs, float* AtA, float* Atb,

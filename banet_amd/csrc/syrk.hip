@@ -455,7 +455,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int KH, int PAIRS, int T0>   // T0 = 0: six products (fp32-exact, the product path); 3: the three largest only (opt-in, see plan_syrk)
+// T0 = 0: six bf16 products (fp32-exact); 1: the same + this launch also leaves max_n |b_nk| per column in a.colmax (the first
+// iteration of a level in the LM loop: the later ones run T0 = 16 with it, no extra pass over the basis); 3: the three largest
+// bf16 products only (opt-in, see plan_syrk); 16: two fp16 pieces, three products, scaled (below)
+template <int KH, int PAIRS, int T0>
 __global__ __launch_bounds__(kBlock, 1) void ba_syrk_bf16x6_kernel(const SyrkArgs a) {
   constexpr int NBV = 4 * KH, NPAIR = NBV * (NBV + 1) / 2, K = 64 * KH;
   constexpr int NU = (PAIRS + 1) / 2;
@@ -504,6 +507,11 @@ __global__ __launch_bounds__(kBlock, 1) void ba_syrk_bf16x6_kernel(const SyrkArg
   // of two from max word^2 / s.  Powers of two: the scaling and its inverse (epilogue) are exact.  Inputs that are not finite, or
   // exponents beyond what the inverse can undo, fall back to the exact bf16 form below (use16 = false, wave-uniform per window).
   [[maybe_unused]] float csc[4 * KH];       // this lane's columns 64 h + 4 m + e
+  [[maybe_unused]] float cmx[4 * KH];       // T0 = 1: running max |b| of those columns over this wave's pixels
+  if constexpr (T0 == 1) {
+#pragma unroll
+    for (int c = 0; c < 4 * KH; ++c) cmx[c] = 0.f;
+  }
   [[maybe_unused]] float usc = 1.f, uinv = 1.f;
   [[maybe_unused]] bool use16 = false;
   [[maybe_unused]] __shared__ float sInv[K];
@@ -655,6 +663,10 @@ __global__ __launch_bounds__(kBlock, 1) void ba_syrk_bf16x6_kernel(const SyrkArg
 #pragma unroll
         for (int i = 0; i < 8; ++i) vv[i] = sq[i] * pb[i][h][e];
         split8_bf16x3(vv, op[4 * h + e]);
+        if constexpr (T0 == 1) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) cmx[4 * h + e] = fmaxf(cmx[4 * h + e], fabsf(pb[i][h][e]));   // (rows past N repeat row 0)
+        }
       }
     issue(st + 1);                                          // the raw registers are free again
     __builtin_amdgcn_sched_barrier(0);                      // keep the prefetch ahead of the MFMA block
@@ -665,7 +677,7 @@ __global__ __launch_bounds__(kBlock, 1) void ba_syrk_bf16x6_kernel(const SyrkArg
 #if defined(BANET_SYRK_ABL) && BANET_SYRK_ABL >= 1   // development ablation (tools/time_syrk.py): one product instead of six
     constexpr int kT0 = 5;
 #else
-    constexpr int kT0 = T0 == 16 ? 0 : T0;   // 3: mid hi' + hi mid' + hi hi' -- the third piece of the split is then dead code
+    constexpr int kT0 = (T0 == 16 || T0 == 1) ? 0 : T0;   // 3: mid hi' + hi mid' + hi hi' -- the third piece of the split is then dead code
 #endif
 #pragma unroll
     for (int t6 = kT0; t6 < 6; ++t6) {
@@ -692,6 +704,16 @@ __global__ __launch_bounds__(kBlock, 1) void ba_syrk_bf16x6_kernel(const SyrkArg
   asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm1), "=s"(tr1)::"memory");
 #endif
 
+  if constexpr (T0 == 1) {   // column maxima: over the 4 pixel groups of the wave, then every wave of the window by atomic max
+    unsigned* cm = reinterpret_cast<unsigned*>(const_cast<float*>(a.colmax)) + (size_t)b * K;     // (non-negative floats order like
+#pragma unroll                                                                                   //  unsigned integers; zeroed before)
+    for (int c = 0; c < 4 * KH; ++c) {
+      float v = cmx[c];
+      v = fmaxf(v, __shfl_xor(v, 16, 64));
+      v = fmaxf(v, __shfl_xor(v, 32, 64));
+      if (kq == 0 && s1 > s0) atomicMax(&cm[64 * (c >> 2) + 4 * m + (c & 3)], __float_as_uint(v));
+    }
+  }
   // ---- epilogue (as ba_syrk_direct_kernel) ------------------------------------------------------
   for (int ww = 0; ww < kNumWaves; ++ww) {
     if (w == ww) {
@@ -780,12 +802,18 @@ __global__ __launch_bounds__(256) void ba_reduce2_kernel(const float* __restrict
                                                          float* __restrict__ absres, float* __restrict__ nvalid) {
   // Parameter order [pose_1 .. pose_pairs | depth]; the gather partials of pair i are the rows of
   // virtual window b pairs + i.  Pose blocks of different pairs do not couple: exact zeros.
+  // 64 output elements per 256-thread block; the four thread groups rq = 0..3 split the SYRK partial rows of an element into
+  // four contiguous runs (a small batch has up to one row per CU: 256 dependent adds in one thread were 26 us at one window)
+  // and are added ((q0 + q1) + (q2 + q3)) through LDS; the gather rows of an element are summed by group 0 alone, in the
+  // order mlp.hpp's role workgroup uses.  Fixed orders: bit-reproducible.
+  __shared__ float sQ[4][64];
   const int b = blockIdx.y;
   if (active != nullptr && active[(size_t)b * active_stride] == 0) return;
   const int P6 = 6 * pairs, P = P6 + K;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int rq = threadIdx.x >> 6, ej = threadIdx.x & 63;
+  const int e = blockIdx.x * 64 + ej;
   const int total = P * P + P + C + 1;
-  if (e >= total) return;
+  const bool live = e < total;
   int off = 0, pair = -1;      // pair >= 0: one pair's gather rows; -2: gather rows of all pairs; -1: syrk rows
   bool zero = false;
   float sign = 1.f;
@@ -824,15 +852,18 @@ __global__ __launch_bounds__(256) void ba_reduce2_kernel(const float* __restrict
     off = 27;
   }
   float v = 0.f;
-  if (!zero) {
-    const bool from_s = pair == -1;
+  const bool from_s = pair == -1;
+  if (live && !zero && (from_s || rq == 0)) {
     const int p0 = pair == -2 ? 0 : pair, p1 = pair == -2 ? pairs : pair + 1;
     for (int pp = p0; pp < (from_s ? p0 + 1 : p1); ++pp) {   // fixed order: pairs, then rows
       const float* p = from_s ? spart + (size_t)b * Gs * sstride + off : gpart + ((size_t)b * pairs + pp) * Gg * gstride + off;
-      const int n = from_s ? Gs : Gg;
       const size_t st = from_s ? sstride : gstride;
+      int i = 0, n = Gg;
+      if (from_s) {            // this group's run of the SYRK rows
+        i = (Gs * rq) >> 2;
+        n = (Gs * (rq + 1)) >> 2;
+      }
       float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-      int i = 0;
       for (; i + 3 < n; i += 4) {
         s0 += p[(size_t)(i + 0) * st];
         s1 += p[(size_t)(i + 1) * st];
@@ -844,6 +875,10 @@ __global__ __launch_bounds__(256) void ba_reduce2_kernel(const float* __restrict
     }
     v *= sign;
   }
+  sQ[rq][ej] = v;
+  __syncthreads();
+  if (rq != 0 || !live) return;
+  if (from_s && !zero) v = (sQ[0][ej] + sQ[1][ej]) + (sQ[2][ej] + sQ[3][ej]);
   if (e < P * P)
     AtA[(size_t)b * P * P + e] = v;
   else if (e < P * P + P)
@@ -1032,6 +1067,16 @@ int launch_syrk(const float* basis, const float* rec, int B, int N, int K, int p
   SyrkArgs a{basis, rec, active, active_stride, partials, N, K, pl.Gs, pl.tiles, pl.pstride, pairs, 0, MlpRole{}, nullptr, nullptr};
   if (pl.direct == 2) {
     if (mr != nullptr) a.mr = *mr;
+    if (pl.f16 && f16_stats == 2) {     // the exact form, which also leaves the basis column maxima for the passes that follow
+      unsigned* colmax = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(partials) + pl.off_colmax);
+      launch_zero_iters(reinterpret_cast<int32_t*>(colmax), B * K, s);
+      a.colmax = reinterpret_cast<const float*>(colmax);
+      if (K == 128)
+        launch_bf16x6<2, 1>(a, B, s);
+      else
+        launch_bf16x6<1, 1>(a, B, s);
+      return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;
+    }
     if (pl.f16 && f16_stats >= 0) {     // fp16 two-piece form: f16_stats 0 = compute the basis column maxima now, 1 = they are in place
       unsigned* colmax = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(partials) + pl.off_colmax);
       float* recmax = reinterpret_cast<float*>(reinterpret_cast<char*>(partials) + pl.off_recmax);
@@ -1084,7 +1129,7 @@ void launch_reduce2(const float* gpart, int Gg, int gstride, const float* spart,
                     const int32_t* active, int active_stride, int B, int K, int C, int pairs, float* AtA, float* Atb,
                     float* absres, float* nvalid, hipStream_t s) {
   const int P = 6 * pairs + K, total = P * P + P + C + 1;
-  hipLaunchKernelGGL(ba_reduce2_kernel, dim3((total + 255) / 256, B), dim3(256), 0, s, gpart, Gg, gstride, spart, Gs,
+  hipLaunchKernelGGL(ba_reduce2_kernel, dim3((total + 63) / 64, B), dim3(256), 0, s, gpart, Gg, gstride, spart, Gs,
                      sstride, active, active_stride, K, C, pairs, AtA, Atb, absres, nvalid);
 }
 

@@ -17,7 +17,6 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 GENERIC, DIRECT, PATCH, STRIP, STRIP_PAIR_LOOP = 32 | (1 << 30), 64 | 524288 | (1 << 30), 512 | (1 << 30), 262144, 262144 | (1 << 22)
 QUAD = 1 << 25
-QUAD_DEEP, QUAD_SHALLOW = QUAD | 128, QUAD | 8192     # one wave per SIMD, all loads of an item in flight / two waves per SIMD
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -108,7 +107,7 @@ def test_quad_gather_kernel_matches_oracle(H, W, K, big, pairs):
           for l in levels]
     ba = bdense.DenseBA(t(intr), tl, mlps, "bundle" if K else "bundle_camera", 1000.0)
     outs = {}
-    for bits in (QUAD, DIRECT, QUAD_DEEP, QUAD_SHALLOW):
+    for bits in (QUAD, DIRECT):
         ba.problems[0].c.reserved_ = bits
         assert ops.gather_selection(ba.problems[0]) == (1 if bits == DIRECT else 4)
         outs[bits] = [n(x) for x in ops.ba_assemble(ba.problems[0], t(R), t(T), t(Wc) if K else None, return_mask=True)]
@@ -120,9 +119,6 @@ def test_quad_gather_kernel_matches_oracle(H, W, K, big, pairs):
     def relerr(got, want):
         want, got = np.asarray(want, np.float64), np.asarray(got, np.float64)
         return float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-30))
-    for x, y, z in zip(outs[QUAD_DEEP], outs[QUAD_SHALLOW], outs[QUAD]):       # the two forms: the same sums in the same order
-        np.testing.assert_array_equal(x, y)
-        np.testing.assert_array_equal(x, z)
     for name, x, y in zip(("AtA", "Atb", "absres"), outs[QUAD], outs[DIRECT]):
         assert relerr(x, y) < 3e-6, (name, relerr(x, y))
     np.testing.assert_array_equal(outs[QUAD][3], outs[DIRECT][3])   # nvalid
