@@ -517,7 +517,10 @@ int plan_gather(const banet_level_t* lv, GatherPlan* pl) {
   if (pl->c128 && lv->dense && !(lv->reserved_ & ((1 << 30) | 512 | 64))) {   // (bits 9 / 6 force the patch / direct tile kernels)
     const int qxn = (lv->W + 3) / 4, qyn = (lv->H + 3) / 4;
     const long long qitems = (long long)qxn * qyn * lv->B * npairs(lv);
-    if (qitems <= (long long)kQuadRounds * kCUs * 8 || (lv->reserved_ & (1 << 25))) {
+    // (multi-frame windows: every virtual window redoes the depth dot -- half the limit: cfg-3's 40x30 x 32 x 4 = 9600 items wins,
+    //  cfg-5's 80x60 x 8 x 7 = 16800 loses 329 vs 210 us, profiles/r04_run9_*)
+    const long long qlimit = (long long)kQuadRounds * kCUs * 8 / (npairs(lv) > 1 ? 2 : 1);
+    if (qitems <= qlimit || (lv->reserved_ & (1 << 25))) {
       const int VBq = lv->B * npairs(lv);
       pl->quad = 1;
       pl->patch = 0;

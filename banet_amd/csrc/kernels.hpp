@@ -63,7 +63,8 @@ struct SyrkPlan {
 };
 size_t syrk_wide_aux_bytes(int B, int N, int pairs);
 int launch_syrk_wide(const float* basis, const float* rec, int B, int N, int K, int pairs, int Gs, int pstride,
-                     const int32_t* active, int active_stride, float* partials, float* aux, hipStream_t s);
+                     const int32_t* active, int active_stride, float* partials, float* aux, hipStream_t s,
+                     const float* colmax = nullptr, const float* recmax = nullptr);   // both given: the fp16 two-piece form
 int plan_syrk(int B, int N, int K, int pairs, int dbg, SyrkPlan* pl);
 int launch_syrk(const float* basis, const float* rec, int B, int N, int K, int pairs, const SyrkPlan& pl,
                 const int32_t* active, int active_stride, float* partials, hipStream_t s, const MlpRole* mr = nullptr,

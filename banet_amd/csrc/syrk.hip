@@ -1017,7 +1017,7 @@ int plan_syrk(int B, int N, int K, int pairs, int dbg, SyrkPlan* pl) {
   // kSyrkF16Pixels pixels in all -- so that its two small pre-passes (basis column maxima once per level, record maxima per pass)
   // are noise.  LM loop (banet_lm_level_f32) only; the single assembly pass keeps the exact bf16 form unless reserved_ bit 24 asks
   // for this one (tests).  reserved_ bit 31: never (A/B).
-  pl->f16 = (pl->direct == 2 && !pl->x3 && !(dbg & (1u << 31)) && ((long long)N * B >= kSyrkF16Pixels || (dbg & (1 << 24)))) ? 1 : 0;
+  pl->f16 = ((pl->direct == 2 || pl->direct == 3) && !pl->x3 && !(dbg & (1u << 31)) && ((long long)N * B >= kSyrkF16Pixels || (dbg & (1 << 24)))) ? 1 : 0;
   pl->f16_standalone = (pl->f16 && (dbg & (1 << 24))) ? 1 : 0;
   pl->off_colmax = pl->partial_bytes;
   pl->off_recmax = pl->off_colmax + (pl->f16 ? align_up((size_t)B * K * sizeof(float), 256) : 0);
@@ -1061,9 +1061,23 @@ static void launch_direct(const SyrkArgs& a, int B, hipStream_t s) {
 
 int launch_syrk(const float* basis, const float* rec, int B, int N, int K, int pairs, const SyrkPlan& pl,
                 const int32_t* active, int active_stride, float* partials, hipStream_t s, const MlpRole* mr, int f16_stats) {
-  if (pl.direct == 3)
+  if (pl.direct == 3) {
+    const float* colmax_w = nullptr;
+    float* recmax_w = nullptr;
+    if (pl.f16 && f16_stats >= 0) {      // the job kernels' fp16 two-piece form: column maxima by their own pass at the level's first call
+      unsigned* cm = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(partials) + pl.off_colmax);
+      recmax_w = reinterpret_cast<float*>(reinterpret_cast<char*>(partials) + pl.off_recmax);
+      if (f16_stats != 1) {
+        launch_zero_iters(reinterpret_cast<int32_t*>(cm), B * K, s);
+        const int G = std::max(1, std::min((N + 255) / 256, (8 * num_cus() + B - 1) / B));
+        hipLaunchKernelGGL(ba_colmax_kernel, dim3(G, B), dim3(256), 0, s, basis, N, K, active, active_stride, cm);
+      }
+      hipLaunchKernelGGL(ba_recmax_kernel, dim3(kRecMaxBlocks, B), dim3(256), 0, s, rec, N, pairs, active, active_stride, recmax_w);
+      colmax_w = reinterpret_cast<const float*>(cm);
+    }
     return launch_syrk_wide(basis, rec, B, N, K, pairs, pl.Gs, pl.pstride, active, active_stride, partials,
-                            reinterpret_cast<float*>(reinterpret_cast<char*>(partials) + pl.off_aux), s);
+                            reinterpret_cast<float*>(reinterpret_cast<char*>(partials) + pl.off_aux), s, colmax_w, recmax_w);
+  }
   SyrkArgs a{basis, rec, active, active_stride, partials, N, K, pl.Gs, pl.tiles, pl.pstride, pairs, 0, MlpRole{}, nullptr, nullptr};
   if (pl.direct == 2) {
     if (mr != nullptr) a.mr = *mr;

@@ -186,7 +186,8 @@ def _entry_errors(AtA, Atb, absres, A64, b64):
     return eA, eb, dg
 
 
-@pytest.mark.parametrize("K,H,W,pairs,span", [(128, 96, 128, 1, 12.0), (64, 48, 64, 1, 12.0), (128, 64, 96, 3, 12.0), (128, 96, 128, 1, 40.0)])
+@pytest.mark.parametrize("K,H,W,pairs,span", [(128, 96, 128, 1, 12.0), (64, 48, 64, 1, 12.0), (128, 64, 96, 3, 12.0), (128, 96, 128, 1, 40.0),
+                                              (256, 64, 96, 1, 12.0), (256, 48, 64, 7, 24.0), (128, 48, 64, 5, 12.0)])   # the syrk_wide.hip jobs
 def test_syrk_f16_two_piece_with_basis_columns_spanning_many_octaves(K, H, W, pairs, span):
     """Same gate as test_syrk_bf16x6_with_basis_columns_spanning_4096x (every entry of AtA / Atb within 3e-5 of ITS OWN scale
     sqrt(A_ii A_jj) against the float64 twin), for the fp16 two-piece form: column k scaled by 2^(span k / (K-1)) -- 2^12 as there,
