@@ -432,6 +432,7 @@ __global__ __launch_bounds__(kBlock, BANET_GATHER_WAVES) void ba_gather_kernel(c
 // --------------------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------------------
+constexpr int kStrip8PerWave = 2;     // 8-row strip segments: fewest per resident wave (tools/gpu_r4_k.sh)
 constexpr int kQuadRounds = 12;      // ba_gather128q_kernel: most items per resident wave (measured, profiles/r04_run6_*: wins up to 19200 items -- 640x480 x 1, 160x120 x 8, 80x60 x 32 -- loses at 38400)
 constexpr int kStripSegW = 16, kStripSegH = 32, kStripMinW = 21;   // = kStripW, kStripH, kWinTex of strip_plan.hpp (gather128s.hip)
 constexpr int kGenericBlocksPerCU = BANET_GATHER_WAVES;  // ba_gather_kernel: launch bounds
@@ -469,18 +470,27 @@ int plan_gather(const banet_level_t* lv, GatherPlan* pl) {
     // windows 11.03 vs 10.77 ms; profiles/r03_run11_*, r03_run12_*): half as many, twice as long work items leave a longer
     // tail in the last round of the queue.  reserved_ bit 21: 32-row segments (A/B, parity tests).
     const int sxn = (lv->W + kStripSegW - 1) / kStripSegW;
-    const int segh = (lv->reserved_ & (1 << 21)) ? kStripSegH : kStripSegH / 2;
+    // Mid-size two-frame launches (too few 16-row segments per wave, too many pixels for the 4x4-item kernel: 160x120 x 32,
+    // 320x240 x 8 .. 16, 640x480 x 2 .. 4): 8-row segments (target rows 11/8 x) where the launch has at least kStrip8PerWave of
+    // them per resident wave.  reserved_ bits 18 + 10: force them (parity tests); A/B: bit 19 (no strip gather at all).
+    const int np = npairs(lv);
+    const int syn16 = (lv->H + kStripSegH / 2 - 1) / (kStripSegH / 2), syn8 = (lv->H + 7) / 8;
+    const bool force8 = (lv->reserved_ & 262144) && (lv->reserved_ & 1024);
+    const bool low = force8 || (np == 1 && !(lv->reserved_ & ((1 << 21) | 262144)) &&
+                                (long long)sxn * syn16 * lv->B < 4LL * kCUs * 8 &&
+                                (long long)sxn * syn8 * lv->B >= (long long)kStrip8PerWave * kCUs * 8 &&
+                                (long long)((lv->W + 3) / 4) * ((lv->H + 3) / 4) * lv->B > (long long)kQuadRounds * kCUs * 8);
+    const int segh = (lv->reserved_ & (1 << 21)) ? kStripSegH : low ? 8 : kStripSegH / 2;
     const int syn = (lv->H + segh - 1) / segh;
     // (A single resident round at tiny batches -- every segment on a wave of its own -- does not pay: one segment is a serial chain
     // of ~200-270 us whatever the load; batch 1: 640x480 270 vs 272 us, 320x240 205 vs 168 us for the tile kernels.)
     // multi-frame windows: frame-parallel workgroups (gather128s.hip, FP) -- `pairs` waves per segment, so a launch has
     // 2048 / pairs resident work-item slots instead of 2048.  reserved_ bit 22: the frames looped over inside one wave (A/B).
-    const int np = npairs(lv);
     const bool fp = np >= 2 && np <= 7 && segh == kStripSegH / 2 && !(lv->reserved_ & (1 << 22));
     const int fp_wg_per_cu = fp ? (int)std::min<size_t>(8 / np, (size_t)(160 * 1024) / (((size_t)np * (7 * 21 * 32 + 128) + 4 * 64 + 4) * 4)) : 0;
     const long long slots = fp ? (long long)kCUs * fp_wg_per_cu : (long long)kCUs * 8;
     pl->strip_fp = 0;
-    if ((long long)sxn * syn * lv->B >= 4LL * slots || (lv->reserved_ & 262144)) {
+    if ((long long)sxn * syn * lv->B >= 4LL * slots || low || (lv->reserved_ & 262144)) {
       pl->strip = segh;
       pl->strip_fp = fp ? 1 : 0;
       pl->quad = 0;

@@ -144,7 +144,8 @@ struct IC {
 };
 
 // KV4 = number of 128-coefficient chunks of a basis row (0: pose only; K % 4 == 0, K <= 128 KV4)
-// NCH = chunks per segment: 8 (16 x 32 pixels, target rows fetched 35/32 x) where a launch has enough of them to fill the
+// NCH = chunks per segment: 2 (16 x 8 pixels, 11/8 x: mid-size launches that have too few 16-row segments per wave), 4 (the default),
+// 8 (16 x 32 pixels, target rows fetched 35/32 x) where a launch has enough of them to fill the
 // chip evenly, 4 (16 x 16 pixels, 19/16 x) on launches with fewer, coarser items (gather.hip::plan_gather)
 // FP ("frame-parallel", multi-frame windows): a workgroup is `pairs` waves that process the SAME segment at the same time, wave p
 // against target frame p.  The key frame's data is then fetched from HBM once per window instead of once per target frame: the
@@ -160,7 +161,8 @@ inline size_t strip_fp_lds_bytes(int pairs, int nch) { return ((size_t)pairs * k
 template <int KV4, int NCH, bool FP>
 __global__ __launch_bounds__(FP ? 512 : kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVgprs / 2))) void ba_gather128s_kernel(const GatherArgs a) {
   constexpr int SEGH = 4 * NCH;          // pixel rows per segment
-  constexpr int NH = NCH / 4;            // groups of four chunks
+  constexpr int NH = (NCH + 3) / 4;      // groups of four chunks
+  constexpr int CPG = NCH < 4 ? NCH : 4; // chunks per group (NCH = 2: 8-row segments for mid-size launches, one half-filled group)
   __shared__ __attribute__((aligned(16))) float sWinS[FP ? 1 : kSWaves][FP ? 4 : kWinFloats];    // the rolling window: [slot][texel][32 channels]
   __shared__ __attribute__((aligned(16))) float sScrS[FP ? 1 : kSWaves][FP ? 4 : kC128s];        // row statistics (plan input), later C x sum|d|
   const banet_level_t& lv = a.lv;
@@ -295,13 +297,13 @@ __global__ __launch_bounds__(FP ? 512 : kSBlock, 2) __attribute__((amdgpu_num_vg
 #pragma unroll
         for (int hh = 0; hh < NH; ++hh)
 #pragma unroll
-          for (int c4 = 0; c4 < 4; ++c4) Dv[hh][c4] = sDep[(4 * hh + c4) * 64 + lane];
+          for (int c4 = 0; c4 < CPG; ++c4) Dv[hh][c4] = sDep[(4 * hh + c4) * 64 + lane];
       } else {
       issue_batch(IC<0>{}, 0, 0);
 #pragma unroll
       for (int hh = 0; hh < NH; ++hh)
 #pragma unroll 1
-      for (int c4 = 0; c4 < 4; ++c4) {
+      for (int c4 = 0; c4 < CPG; ++c4) {
         const int c = 4 * hh + c4;
         const int py = py0 + 4 * c;
         const bool valid = (px < W) && (py < H);
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(FP ? 512 : kSBlock, 2) __attribute__((amdgpu_num_vg
 #pragma unroll
       for (int hh = 0; hh < NH; ++hh)
 #pragma unroll 1
-      for (int c4 = 0; c4 < 4; ++c4) {
+      for (int c4 = 0; c4 < CPG; ++c4) {
         const int c = 4 * hh + c4;
         const int py = py0 + 4 * c;
         const bool valid = (px < W) && (py < H);
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(FP ? 512 : kSBlock, 2) __attribute__((amdgpu_num_vg
 #pragma unroll
       for (int hh = 0; hh < NH; ++hh)
 #pragma unroll 1
-      for (int c4 = 0; c4 < 4; ++c4) {
+      for (int c4 = 0; c4 < CPG; ++c4) {
         const int c = 4 * hh + c4;
         const int py = py0 + 4 * c;
         const bool valid = (px < W) && (py < H);
@@ -449,7 +451,7 @@ __global__ __launch_bounds__(FP ? 512 : kSBlock, 2) __attribute__((amdgpu_num_vg
 #pragma unroll
         for (int hh = 0; hh < NH; ++hh)
 #pragma unroll 1
-        for (int c4 = 0; c4 < 4; ++c4) {
+        for (int c4 = 0; c4 < CPG; ++c4) {
           const int c = 4 * hh + c4;
           const int p0c = P0v[hh][c4];
           const float dxc = DXv[hh][c4], dyc = DYv[hh][c4];
@@ -587,7 +589,7 @@ __global__ __launch_bounds__(FP ? 512 : kSBlock, 2) __attribute__((amdgpu_num_vg
 #pragma unroll
       for (int hh = 0; hh < NH; ++hh)
 #pragma unroll 1
-      for (int c4 = 0; c4 < 4; ++c4) {
+      for (int c4 = 0; c4 < CPG; ++c4) {
         const int c = 4 * hh + c4;
         const int py = py0 + 4 * c;
         const bool valid = (px < W) && (py < H);
@@ -704,10 +706,10 @@ __global__ __launch_bounds__(FP ? 512 : kSBlock, 2) __attribute__((amdgpu_num_vg
 
 int launch_gather128s(const GatherArgs& a, int K, hipStream_t s) {
   dim3 grid(a.G, a.lv.B), block(kSBlock);
-  const bool tall = a.seg_h == 32;
-  if (a.seg_h != 32 && a.seg_h != 16) return BANET_ERR_INVALID_ARG;
+  const bool tall = a.seg_h == 32, low = a.seg_h == 8;
+  if (a.seg_h != 32 && a.seg_h != 16 && a.seg_h != 8) return BANET_ERR_INVALID_ARG;
   if (a.strip_fp) {    // frame-parallel workgroups: `pairs` waves, dynamic LDS (16-row segments only)
-    if (tall || a.pairs < 2 || a.pairs > 7) return BANET_ERR_INVALID_ARG;
+    if (tall || low || a.pairs < 2 || a.pairs > 7) return BANET_ERR_INVALID_ARG;
     const size_t shm = strip_fp_lds_bytes(a.pairs, 4);
     block = dim3(64 * a.pairs);
 #define BANET_LAUNCH_FP(KV4)                                                                                              \
@@ -727,6 +729,7 @@ int launch_gather128s(const GatherArgs& a, int K, hipStream_t s) {
 #define BANET_LAUNCH_S(KV4)                                                                     \
   do {                                                                                          \
     if (tall) hipLaunchKernelGGL((ba_gather128s_kernel<KV4, 8, false>), grid, block, 0, s, a);  \
+    else if (low) hipLaunchKernelGGL((ba_gather128s_kernel<KV4, 2, false>), grid, block, 0, s, a); \
     else hipLaunchKernelGGL((ba_gather128s_kernel<KV4, 4, false>), grid, block, 0, s, a);       \
   } while (0)
   if (K == 0) BANET_LAUNCH_S(0);

@@ -206,6 +206,7 @@ def _torch_levels(levels):
 
 STRIP, DIRECT, STRIP_ALL_DIRECT, SEG32 = 262144, 64 | 524288, 262144 | (1 << 20), 1 << 21
 PAIR_LOOP = 1 << 22      # multi-frame strip gather: frames looped over inside one wave (A/B)
+SEG8 = 1024              # with STRIP: 8-row segments (mid-size two-frame launches)
 
 
 @pytest.mark.parametrize("H,W,K,big,pairs", [(48, 64, 128, False, 1),      # whole segments, unit-scale footprints: all from the window
@@ -234,7 +235,7 @@ def test_strip_gather_kernel_matches_oracle(H, W, K, big, pairs):
     mlps = [orc.he_normal_mlp_weights(C, 9)]
     ba = bdense.DenseBA(t(intr), _torch_levels(levels), mlps, "bundle" if K else "bundle_camera", 1000.0)
     outs = {}
-    variants = (STRIP, DIRECT, STRIP_ALL_DIRECT, STRIP | SEG32) + ((STRIP | PAIR_LOOP,) if pairs > 1 else ())
+    variants = (STRIP, DIRECT, STRIP_ALL_DIRECT, STRIP | SEG32, STRIP | SEG8) + ((STRIP | PAIR_LOOP,) if pairs > 1 else ())
     for bits in variants:
         ba.problems[0].c.reserved_ = bits
         assert ops.gather_selection(ba.problems[0]) == (1 if bits == DIRECT else 3)
@@ -249,6 +250,8 @@ def test_strip_gather_kernel_matches_oracle(H, W, K, big, pairs):
         assert relerr(x, y) < 1e-6, (name, relerr(x, y))          # window and direct taps read the same texels
     for name, x, y in zip(("AtA", "Atb", "absres", "nvalid"), outs[STRIP | SEG32], outs[STRIP]):
         assert relerr(x, y) < 3e-6, (name, relerr(x, y))          # 32-row segments: the same sums, other partial rows
+    for name, x, y in zip(("AtA", "Atb", "absres", "nvalid"), outs[STRIP | SEG8], outs[STRIP]):
+        assert relerr(x, y) < 3e-6, (name, relerr(x, y))          # 8-row segments likewise
     np.testing.assert_array_equal(outs[STRIP][3], outs[DIRECT][3])
     if pairs > 1:     # frame-parallel workgroups (the default) == the frames looped over inside one wave, bit for bit
         for x, y in zip(outs[STRIP], outs[STRIP | PAIR_LOOP]):

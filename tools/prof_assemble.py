@@ -24,7 +24,7 @@ R = torch.eye(3, device=dev).repeat(B, 1, 1) if PP == 1 else torch.eye(3, device
 T = (gt["T"] * 0.7).reshape(B, 3, 1).to(dev) if PP == 1 else (gt["T"] * 0.7).reshape(B, PP, 3, 1).to(dev)
 Wc = torch.zeros(B, max(K, 1), 1, device=dev)[:, :K]
 byts = ba.algorithmic_bytes_per_iteration(0) * B
-ALL = ((0, "full"), (1 << 25, "quad gather forced"), (1 << 30, "no quad gather"), (4194304, "strip: frames looped in a wave"), (1 << 24, "fp16 two-piece SYRK forced"), (1024, "quarter tiles forced"), (512, "patch kernel forced"), (64, "direct gather kernel"), (128, "patch kernel, direct loads only"), (256, "fp32-MFMA syrk"), (16, "no quarter tiles"), (32, "generic kernel"), (1, "all taps -> texel(1,1)"), (4, "no depth dot"), (8, "no gather loop"), (12, "geometry only"), (8192, "patch gather at ONE workgroup per CU"), (16384, "patch gather, 4-step units"), (65536, "patch gather, packed patch + flat loads"), (131072, "patch gather, column-major unit order"), (2, "P: src rows -> pixels 0..3"), (3, "P: taps+src fixed"), (7, "P: taps+src fixed, no depth dot"), (15, "P: no loads but records, no tap math"), (9, "P: fixed taps, no tap math"), (5, "P: fixed taps, no depth dot"))
+ALL = ((0, "full"), (1 << 25, "quad gather forced"), (524288, "no strip gather"), (262144 | 1024, "strip gather, 8-row segments forced"), (262144, "strip gather, 16-row segments forced"), (1 << 30, "no quad gather"), (4194304, "strip: frames looped in a wave"), (1 << 24, "fp16 two-piece SYRK forced"), (1024, "quarter tiles forced"), (512, "patch kernel forced"), (64, "direct gather kernel"), (128, "patch kernel, direct loads only"), (256, "fp32-MFMA syrk"), (16, "no quarter tiles"), (32, "generic kernel"), (1, "all taps -> texel(1,1)"), (4, "no depth dot"), (8, "no gather loop"), (12, "geometry only"), (8192, "patch gather at ONE workgroup per CU"), (16384, "patch gather, 4-step units"), (65536, "patch gather, packed patch + flat loads"), (131072, "patch gather, column-major unit order"), (2, "P: src rows -> pixels 0..3"), (3, "P: taps+src fixed"), (7, "P: taps+src fixed, no depth dot"), (15, "P: no loads but records, no tap math"), (9, "P: fixed taps, no tap math"), (5, "P: fixed taps, no depth dot"))
 sel = [int(x) for x in os.environ.get("PBITS", "0").split(",")]
 cfgs = [a for a in ALL if a[0] in sel]
 res = {bits: [] for bits, _ in cfgs}
