@@ -70,5 +70,45 @@ for c in cases_ss:
         bad += 1
         print("sample_stats case", c, "FAILED")
         traceback.print_exc(limit=2)
-print("EquationConstruction cases %s, sample_stats cases %s: %d failures in all" % (cases_eq, cases_ss, bad))
+print("EquationConstruction cases %s, sample_stats cases %s: %d failures so far" % (cases_eq, cases_ss, bad))
+# round 4: the 4x4-pixel-item gather forced at random shapes; the mask output of every gather kernel; the fp16 two-piece SYRK
+# (both engines: K = 64 / 128 up to 4 frames, and the syrk_wide.hip jobs) with random column spans; the literal op up to P = 304
+import test_gpu_round4 as T4  # noqa: E402
+cases_quad = [(int(rng.randint(4, 90)), int(rng.randint(4, 120)), int(rng.choice([0, 4, 16, 32, 64, 128, 256])), bool(rng.randint(2)),
+               int(rng.randint(1, 5))) for _ in range(max(4, count // 3))]
+for c in cases_quad:
+    try:
+        T4.test_quad_gather_kernel_matches_oracle(*c)
+    except Exception:
+        bad += 1
+        print("quad gather case", c, "FAILED")
+        traceback.print_exc(limit=2)
+cases_mask = [(int(rng.randint(24, 70)), int(rng.randint(24, 100)), int(rng.choice([0, 32, 128])), int(rng.randint(1, 5)), True)
+              for _ in range(max(2, count // 8))]
+for c in cases_mask:
+    try:
+        T4.test_mask_output_of_every_gather_kernel(*c)
+    except Exception:
+        bad += 1
+        print("mask output case", c, "FAILED")
+        traceback.print_exc(limit=2)
+cases_f16 = [(int(k), int(rng.randint(24, 100)), int(rng.randint(32, 130)), int(rng.randint(1, 8 if k != 64 else 5)), float(rng.choice([0.0, 6.0, 12.0, 30.0, 60.0])))
+             for k in rng.choice([64, 128, 256], size=max(4, count // 4))]
+for c in cases_f16:
+    try:
+        T4.test_syrk_f16_two_piece_with_basis_columns_spanning_many_octaves(*c)
+    except Exception:
+        bad += 1
+        print("fp16 SYRK case", c, "FAILED")
+        traceback.print_exc(limit=2)
+cases_eq2 = [(int(rng.randint(1, 3)), int(rng.randint(1, 300)), int(rng.choice([1, 8, 128])), int(rng.choice([273, 280, 298, 300, 304]))) for _ in range(max(2, count // 10))]
+for c in cases_eq2:
+    for fn in (T.test_equation_construction_matches_oracle, T.test_equation_construction_grad_matches_oracle):
+        try:
+            fn(*c)
+        except Exception:
+            bad += 1
+            print("EquationConstruction case", c, fn.__name__, "FAILED")
+            traceback.print_exc(limit=2)
+print("quad gather cases %s, mask cases %s, fp16 SYRK cases %s, P > 272 op cases %s: %d failures in all" % (cases_quad, cases_mask, cases_f16, cases_eq2, bad))
 sys.exit(1 if bad else 0)
