@@ -36,6 +36,13 @@ for i in "${!pids[@]}"; do
   fi
 done
 [ "$fail" = 0 ] || exit 1
+# gather128s.hip keeps data in flight in v224..v255 behind the compiler's back (amdgpu_num_vgpr + inline asm): when it was rebuilt,
+# check that the compiler did not allocate those registers and did not spill in the default variants (tools/check_strip_regs.py)
+for n in "${names[@]:-}"; do
+  if [ "$n" = gather128s ] && [ -z "${BANET_SKIP_STRIP_CHECK:-}" ] && [ -z "${EXTRA_HIPCC_FLAGS:-}" ]; then
+    python3 ../../tools/check_strip_regs.py || { echo "build.sh: gather128s.hip violates its register contract" >&2; rm -f "$OUT/gather128s.o"; exit 1; }
+  fi
+done
 OBJS=""
 for f in $SRCS; do OBJS="$OBJS $OUT/$f.o"; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libbanet_hip.so" $OBJS -ldl   # dlopen of the roctx marker library (assemble.hip)

@@ -309,3 +309,52 @@ def test_bench_compact_line_stays_under_4_kb(tmp_path, capsys, monkeypatch):
     for i in range(200):
         full["sweep"]["more_%d" % i] = dict(full["sweep"]["B8_2frame"])
     assert len(bench.compact_record(full)) < 4096
+
+
+def test_strip_gather_register_contract():
+    """ba_gather128s_kernel reserves v224..v255 behind the compiler's back (amdgpu_num_vgpr + inline asm naming them): the
+    compiler-emitted instructions of every instantiation must not touch them and the default variants must not spill
+    (tools/check_strip_regs.py; build.sh runs the same check whenever it recompiles gather128s.hip)."""
+    import shutil
+    import subprocess
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_strip_regs.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 violations" in r.stdout
+
+
+def _level(capi, B, H, W, K, pairs, reserved=0):
+    lv = capi.Level()
+    lv.B, lv.N, lv.C, lv.K, lv.H, lv.W = B, H * W, 128, K, H, W
+    lv.variant, lv.dense, lv.scale, lv.pairs, lv.normalize_rays = capi.BUNDLE, 1, 1.0, pairs, 1
+    lv.reserved_ = reserved
+    return lv
+
+
+def test_kernel_selection_table_of_the_baseline_configs(capi):
+    """Which assembly (gather) and depth-block (SYRK) kernels BASELINE.json's configurations run, level by level -- the host-side
+    plans need no GPU (256 CUs assumed when no device is visible).  banet_gather_selection: 1 direct tiles, 2 LDS patches,
+    3 strip segments, 4 4x4-pixel items; banet_syrk_selection: 2 bf16 x 3 pieces, 3 wide-basis jobs (bf16), 4 fp16 x 2 pieces."""
+    L = capi.lib()
+    sel = lambda *a, **k: (L.banet_gather_selection(ctypes.byref(_level(capi, *a, **k))),       # noqa: E731
+                           L.banet_syrk_selection(ctypes.byref(_level(capi, *a, **k))))
+    pyr = [(30, 40), (60, 80), (120, 160), (240, 320), (480, 640)]
+    # the metric's configuration: 2-frame, batch 32
+    assert [sel(32, h, w, 128, 1) for h, w in pyr] == [(4, 2), (4, 2), (3, 2), (3, 4), (3, 4)]
+    # batch 1: every level on the 4x4-item gather, exact SYRK (latency-bound launches)
+    assert [sel(1, h, w, 128, 1) for h, w in pyr] == [(4, 2)] * 5
+    # batch 8
+    assert [sel(8, h, w, 128, 1) for h, w in pyr] == [(4, 2), (4, 2), (4, 2), (3, 2), (3, 4)]
+    # cfg-3: 5-frame windows, batch 32 (frame-parallel strip gather from 160x120 up)
+    assert [sel(32, h, w, 128, 4) for h, w in pyr] == [(4, 2), (2, 2), (3, 2), (3, 4), (3, 4)]
+    # cfg-5 share: 8 windows x 8 frames, 1280x960, K = 256 (wide-basis SYRK jobs; fp16 form on the two finest levels)
+    pyr5 = [(60, 80), (120, 160), (240, 320), (480, 640), (960, 1280)]
+    assert [sel(8, h, w, 256, 7) for h, w in pyr5] == [(1, 3), (2, 3), (3, 3), (3, 4), (3, 4)]
+    # cfg-1: 160x120, K = 32, one window
+    assert sel(1, 120, 160, 32, 1) == (4, 0)
+    # the documented development bits
+    h, w = pyr[0]
+    assert sel(32, h, w, 128, 1, reserved=1 << 30)[0] == 1 and sel(32, 480, 640, 128, 1, reserved=-2147483648)[1] == 2
+    assert sel(32, h, w, 128, 1, reserved=(1 << 18) | 1024)[0] == 3
+    assert sel(6, 240, 320, 128, 1)[0] == 2 and sel(6, 240, 320, 128, 1, reserved=1 << 25)[0] == 4      # (28800 items: beyond its limit)
