@@ -357,4 +357,4 @@ def test_kernel_selection_table_of_the_baseline_configs(capi):
     h, w = pyr[0]
     assert sel(32, h, w, 128, 1, reserved=1 << 30)[0] == 1 and sel(32, 480, 640, 128, 1, reserved=-2147483648)[1] == 2
     assert sel(32, h, w, 128, 1, reserved=(1 << 18) | 1024)[0] == 3
-    assert sel(6, 240, 320, 128, 1)[0] == 2 and sel(6, 240, 320, 128, 1, reserved=1 << 25)[0] == 4      # (28800 items: beyond its limit)
+    assert sel(6, 240, 320, 128, 1)[0] == 1 and sel(6, 240, 320, 128, 1, reserved=1 << 25)[0] == 4      # (28800 items: beyond its limit -> tiles)
