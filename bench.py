@@ -727,8 +727,8 @@ def main():
                 par = not args.no_parity
                 #            name                frames B   H    W     K   iters steps warm scales
                 entries = [("cfg1_160x120_K32_B1", 2,   1,  120, 160,  32,  3,   20,   3,   [1]),
-                           ("B1_2frame",           2,   1,  H,   W,    K,   10,  5,    1,   None),
-                           ("B8_2frame",           2,   8,  H,   W,    K,   10,  5,    1,   None),
+                           ("B1_2frame",           2,   1,  H,   W,    K,   10,  20,   5,   None),    # (7 ms steps: enough of them for
+                           ("B8_2frame",           2,   8,  H,   W,    K,   10,  10,   3,   None),    #  the clocks to settle)
                            ("cfg3_5frame_B32",     5,   32, H,   W,    K,   10,  5,    1,   None)]
                 if not args.no_sweep_large:      # 161 GB / 67 GB of inputs in the 288 GB of HBM
                     entries += [("B256_2frame",    2,   256, H,  W,    K,   10,  3,    1,   None),
