@@ -27,9 +27,16 @@ class Level(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int32), ("N", ctypes.c_int32), ("C", ctypes.c_int32), ("K", ctypes.c_int32),
                 ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("variant", ctypes.c_int32),
                 ("dense", ctypes.c_int32), ("tgt_has_grad", ctypes.c_int32), ("normalize_rays", ctypes.c_int32),
-                ("scale", ctypes.c_float), ("pairs", ctypes.c_int32), ("reserved_", ctypes.c_int32), ("pad_", ctypes.c_int32),
+                ("scale", ctypes.c_float), ("pairs", ctypes.c_int32), ("flags", ctypes.c_int32), ("policy", ctypes.c_int32),
                 ("src", _FP), ("tgt", _FP), ("depth", _FP), ("basis", _FP), ("rays", _FP),
                 ("fx", _FP), ("fy", _FP), ("ox", _FP), ("oy", _FP), ("intr", _FP)]
+
+    # the field's name until round 4 (tools/ and older tests still say `reserved_`): same storage
+    reserved_ = property(lambda self: self.flags, lambda self, v: setattr(self, "flags", v))
+
+
+POLICY_THROUGHPUT, POLICY_BATCH_INVARIANT = 0, 1   # banet_hip.h: BANET_POLICY_*
+CANONICAL_BATCH = 32
 
 
 class Mlp(ctypes.Structure):

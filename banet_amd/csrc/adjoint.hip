@@ -164,7 +164,7 @@ __global__ __launch_bounds__(kBlock, 2) void adj_basis_kernel(const AdjArgs a) {
 // The seed block is split ONCE per workgroup into LDS as MFMA B operands ([k step][column block][piece][lane], 3 KB per block and
 // k step: 108 KB at K = 128); a wave takes 16 pixels at a time: lane (m, kq) loads the 8 coefficients 32 ks + 8 kq .. + 7 of pixel
 // m (32 contiguous bytes; the four kq lanes of a pixel read 128), splits them (registers) and accumulates.  512 threads: two
-// waves per SIMD.  Epilogue as adj_basis_kernel (same accumulator layout).  reserved_ bit 26 keeps the fp32-MFMA kernel (A/B).
+// waves per SIMD.  Epilogue as adj_basis_kernel (same accumulator layout).  flags bit 26 keeps the fp32-MFMA kernel (A/B).
 constexpr int kAdjB6Threads = 512, kAdjB6Waves = kAdjB6Threads / 64;
 template <int NK>   // KP = 16 NK >= K, NK <= 8
 __global__ __launch_bounds__(kAdjB6Threads) void adj_basis6_kernel(const AdjArgs a) {
@@ -1466,7 +1466,7 @@ __global__ __launch_bounds__(kBlock) void sstats_rows_kernel(const float* __rest
 
 static void launch_adj_map(const AdjArgs& a, int C, dim3 grid, dim3 block, hipStream_t s) {
   const int C3 = 3 * C, J3 = (C3 + 63) / 64;
-  const bool half = (C3 & 3) == 0 && !(a.lv.reserved_ & (1 << 28));   // bit 28: one texel per wave (A/B; bits 18 / 19 belong to the forward's gather selection)
+  const bool half = (C3 & 3) == 0 && !(a.lv.flags & (1 << 28));   // bit 28: one texel per wave (A/B; bits 18 / 19 belong to the forward's gather selection)
   if (J3 <= 3) {
     if (half)
       hipLaunchKernelGGL((adj_map2_kernel<2, 3>), grid, block, 0, s, a);
@@ -1598,7 +1598,7 @@ int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T
   const size_t tot = (size_t)B * P * P;
   hipLaunchKernelGGL(adj_sym_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, gAtA, S, P, tot);
   if (hipMemsetAsync(a.cnt, 0, (size_t)B * HW * sizeof(int), s) != hipSuccess) return BANET_ERR_LAUNCH;
-  const bool b6 = !(lv->reserved_ & (1 << 26));   // the bf16x6 form of the GEMM-shaped piece (bit 26: fp32 MFMA, A/B)
+  const bool b6 = !(lv->flags & (1 << 26));   // the bf16x6 form of the GEMM-shaped piece (bit 26: fp32 MFMA, A/B)
   switch ((K + 15) / 16) {
     case 1: launch_adj_basis<1>(a, pl.Ga, s); break;
     case 2: b6 ? launch_adj_basis6<2>(a, pl.Ga, s) : launch_adj_basis<2>(a, pl.Ga, s); break;
@@ -1617,7 +1617,7 @@ int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T
       break;
     default: return BANET_ERR_UNSUPPORTED;
   }
-  if ((lv->C & 3) == 0 && (K & 3) == 0 && lv->C <= 128 && K <= 128 && !(lv->reserved_ & (1 << 27))) {   // bit 27: one pixel per wave (A/B)
+  if ((lv->C & 3) == 0 && (K & 3) == 0 && lv->C <= 128 && K <= 128 && !(lv->flags & (1 << 27))) {   // bit 27: one pixel per wave (A/B)
     hipLaunchKernelGGL((adj_pixel2_kernel<1>), dim3(pl.G, B), dim3(kBlock), 0, s, a);   // (C = 256: 264 B of spills -> the one-pixel kernel)
   } else {
     const int CJ = (lv->C + 63) / 64, KJ = std::max(1, (K + 63) / 64);

@@ -11,7 +11,7 @@ static int check_level(const banet_level_t* lv) {
   if (lv->variant < BANET_LEGACY_LM || lv->variant > BANET_BUNDLE) return BANET_ERR_INVALID_ARG;
   if (lv->K > 0 && !lv->basis) return BANET_ERR_INVALID_ARG;
   if ((lv->variant == BANET_BUNDLE) != (lv->K > 0)) return BANET_ERR_INVALID_ARG;
-  if (lv->pairs < 0 || lv->pad_ != 0) return BANET_ERR_INVALID_ARG;
+  if (lv->pairs < 0 || (lv->policy != BANET_POLICY_THROUGHPUT && lv->policy != BANET_POLICY_BATCH_INVARIANT)) return BANET_ERR_INVALID_ARG;
   if (lv->pairs > 1 && lv->variant != BANET_BUNDLE && lv->variant != BANET_BUNDLE_CAMERA) return BANET_ERR_INVALID_ARG;
   if (lv->dense) {
     if (!lv->intr || !(lv->scale > 0.f)) return BANET_ERR_INVALID_ARG;
@@ -81,7 +81,7 @@ static SolveArgs make_solve_args(const banet_level_t* lv, const banet_mlp_t* mlp
   a.nqueue = 0;
   a.bigA = nullptr;
   a.mlp_y = nullptr;
-  a.flags = lv->reserved_;
+  a.flags = lv->flags;
   banet_lm_params_default(&a.lm);
   return a;
 }
@@ -293,13 +293,14 @@ int banet_lm_level_ex_f32(const banet_level_t* lv, const banet_mlp_t* mlp, float
     // Small batches only (B <= 8) otherwise: the SYRK kernel runs one workgroup per CU (512 registers per wave), so the role workgroups
     // need CUs of their own -- at B = 32 (8 + 1 workgroups per window = 288 > 256 CUs) a second round of workgroups doubled
     // the SYRK time (640x480 x 32: 1326 -> 2457 us); with B <= 8 one SYRK workgroup per window is given up where needed.
+    const int Bsel = selection_batch(lv);   // (the role changes Gs, i.e. the summation split: decided like every other selection)
     const bool role = lv->variant == BANET_BUNDLE && mlp != nullptr && a.use_mlp && syrk_runs_mlp_role(pl.s) && lv->C <= 256 &&
-                      (lv->C & 3) == 0 && ((long long)lv->B * (pl.s.Gs + 1) <= num_cus() || (lv->B <= 8 && pl.s.Gs >= 16) ||
+                      (lv->C & 3) == 0 && ((long long)Bsel * (pl.s.Gs + 1) <= num_cus() || (Bsel <= 8 && pl.s.Gs >= 16) ||
                        (lv->N <= kRoleSmallLevel && pl.s.Gs >= 4)) &&
-                      !(lv->reserved_ & 32768);   // reserved_ bit 15: MLP inside the solve kernel (A/B)
+                      !(lv->flags & 32768);   // flags bit 15: MLP inside the solve kernel (A/B)
     if (role) {
       a.mlp_y = w.mlp_y;
-      if ((long long)lv->B * (pl.s.Gs + 1) > num_cus()) pl.s.Gs -= 1;
+      if ((long long)Bsel * (pl.s.Gs + 1) > num_cus()) pl.s.Gs -= 1;
     }
     for (int it = 0; it < max_iters; ++it) {
       rc = launch_assemble(lv, pl, st->R, st->T, st->Wc, nullptr, 0, w.partials, w.AtA, w.Atb, w.absres, w.nvalid, s,

@@ -119,6 +119,14 @@ int profile_end(int max_tags, int32_t* tag_points, int32_t* tag_launches, double
 int num_cus() {
   constexpr int kMaxDev = 64, kDefault = 256;
   static std::atomic<int> cached[kMaxDev];        // 0 = not queried yet
+  // BANET_NUM_CUS: pin the CU count the plans are made for (the selection-table test pins 256 so that it does not depend on the
+  // host's GPU; also a way to reproduce another part's plans).  Read once.
+  static const int pinned = [] {
+    const char* e = std::getenv("BANET_NUM_CUS");
+    const int v = e ? std::atoi(e) : 0;
+    return v > 0 && v <= 4096 ? v : 0;
+  }();
+  if (pinned) return pinned;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) {
     (void)hipGetLastError();
@@ -138,7 +146,7 @@ int num_cus() {
 int plan_assemble(const banet_level_t* lv, AsmPlan* pl) {
   int rc = plan_gather(lv, &pl->g);
   if (rc != BANET_OK) return rc;
-  rc = plan_syrk(lv->B, lv->N, lv->K, npairs(lv), lv->reserved_, &pl->s);
+  rc = plan_syrk(lv->B, selection_batch(lv), lv->N, lv->K, npairs(lv), lv->flags, &pl->s);
   if (rc != BANET_OK) return rc;
   pl->P = 6 * npairs(lv) + lv->K;
   pl->off_rec = pl->g.partial_bytes;

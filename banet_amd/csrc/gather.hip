@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kBlock, BANET_GATHER_WAVES) void ba_gather_kernel(c
   const int N = lv.N, C = lv.C, K = lv.K, H = lv.H, W = lv.W;
   const int Ct = GRAD ? 3 * C : C;
   const bool dense = lv.dense != 0;
-  const int dbg = lv.reserved_;  // profiling ablation bits (tools/prof_assemble.py); 0 in production
+  const int dbg = lv.flags;  // profiling ablation bits (tools/prof_assemble.py); 0 in production
   const float* __restrict__ tgt_b = lv.tgt + (size_t)vb * H * W * Ct;
   const float* __restrict__ src_b = lv.src + (size_t)b * N * C;
   const float* __restrict__ dep_b = lv.depth + (size_t)b * N;
@@ -439,12 +439,13 @@ constexpr int kGenericBlocksPerCU = BANET_GATHER_WAVES;  // ba_gather_kernel: la
 constexpr int kC128BlocksPerCU = BANET_G128_WAVES;       // ba_gather128_kernel: launch bounds (LDS: 18 KB)
 
 static bool use_c128(const banet_level_t* lv) {
-  // reserved_ bit 5 (A/B experiments only): force the generic kernel
-  return lv->C == 128 && !lv->tgt_has_grad && !(lv->reserved_ & 32) && (lv->K & 3) == 0 && lv->K <= 256;
+  // flags bit 5 (A/B experiments only): force the generic kernel
+  return lv->C == 128 && !lv->tgt_has_grad && !(lv->flags & 32) && (lv->K & 3) == 0 && lv->K <= 256;
 }
 
 int plan_gather(const banet_level_t* lv, GatherPlan* pl) {
   const int kCUs = num_cus();
+  const int Bsel = lv ? selection_batch(lv) : 0;   // decisions: Bsel; grids and buffer sizes: lv->B
   if (!lv || lv->B <= 0 || lv->N <= 0 || lv->C <= 0 || lv->K < 0 || lv->H < 4 || lv->W < 4) return BANET_ERR_INVALID_ARG;
   if (lv->C > 256 || lv->K > 256) return BANET_ERR_UNSUPPORTED;
   if (lv->dense && lv->N != lv->H * lv->W) return BANET_ERR_INVALID_ARG;
@@ -460,37 +461,37 @@ int plan_gather(const banet_level_t* lv, GatherPlan* pl) {
   pl->c128 = use_c128(lv) ? 1 : 0;
   // The strip gather (gather128s.hip: 16 x 32-pixel segments, rolling LDS window, target map fetched 1.44 x instead of 2.15 x)
   // where a launch has at least 4 segments per resident wave (coarser items than the 8x8 tiles: below that the tail of the
-  // last round costs more than the halo saves).  reserved_ bit 18: force it at any size (parity tests); bit 19: off (A/B).
+  // last round costs more than the halo saves).  flags bit 18: force it at any size (parity tests); bit 19: off (A/B).
   pl->strip = 0;
   pl->strip_fp = 0;
-  if (pl->c128 && lv->dense && !(lv->reserved_ & 524288) && lv->W >= kStripMinW && lv->W < 4096 && lv->H < 4096 &&
+  if (pl->c128 && lv->dense && !(lv->flags & 524288) && lv->W >= kStripMinW && lv->W < 4096 && lv->H < 4096 &&
       (size_t)lv->N * lv->C * 4 < ((size_t)1 << 31)) {
     // segment height: 16 rows.  32-row segments fetch less (target rows 35/32 x instead of 19/16 x: launch 1.12 x vs 1.16 x the
     // algorithmic bytes) but lose 5 % at every size measured (640x480 x 32: 3396 vs 3230 us, x 256: 27.3 vs 26.1 ms, 5-frame
     // windows 11.03 vs 10.77 ms; profiles/r03_run11_*, r03_run12_*): half as many, twice as long work items leave a longer
-    // tail in the last round of the queue.  reserved_ bit 21: 32-row segments (A/B, parity tests).
+    // tail in the last round of the queue.  flags bit 21: 32-row segments (A/B, parity tests).
     const int sxn = (lv->W + kStripSegW - 1) / kStripSegW;
     // Mid-size two-frame launches (too few 16-row segments per wave, too many pixels for the 4x4-item kernel: 160x120 x 32,
     // 320x240 x 8 .. 16, 640x480 x 2 .. 4): 8-row segments (target rows 11/8 x) where the launch has at least kStrip8PerWave of
-    // them per resident wave.  reserved_ bits 18 + 10: force them (parity tests); A/B: bit 19 (no strip gather at all).
+    // them per resident wave.  flags bits 18 + 10: force them (parity tests); A/B: bit 19 (no strip gather at all).
     const int np = npairs(lv);
     const int syn16 = (lv->H + kStripSegH / 2 - 1) / (kStripSegH / 2), syn8 = (lv->H + 7) / 8;
-    const bool force8 = (lv->reserved_ & 262144) && (lv->reserved_ & 1024);
-    const bool low = force8 || (np == 1 && !(lv->reserved_ & ((1 << 21) | 262144)) &&
-                                (long long)sxn * syn16 * lv->B < 4LL * kCUs * 8 &&
-                                (long long)sxn * syn8 * lv->B >= (long long)kStrip8PerWave * kCUs * 8 &&
-                                (long long)((lv->W + 3) / 4) * ((lv->H + 3) / 4) * lv->B > (long long)kQuadRounds * kCUs * 8);
-    const int segh = (lv->reserved_ & (1 << 21)) ? kStripSegH : low ? 8 : kStripSegH / 2;
+    const bool force8 = (lv->flags & 262144) && (lv->flags & 1024);
+    const bool low = force8 || (np == 1 && !(lv->flags & ((1 << 21) | 262144)) &&
+                                (long long)sxn * syn16 * Bsel < 4LL * kCUs * 8 &&
+                                (long long)sxn * syn8 * Bsel >= (long long)kStrip8PerWave * kCUs * 8 &&
+                                (long long)((lv->W + 3) / 4) * ((lv->H + 3) / 4) * Bsel > (long long)kQuadRounds * kCUs * 8);
+    const int segh = (lv->flags & (1 << 21)) ? kStripSegH : low ? 8 : kStripSegH / 2;
     const int syn = (lv->H + segh - 1) / segh;
     // (A single resident round at tiny batches -- every segment on a wave of its own -- does not pay: one segment is a serial chain
     // of ~200-270 us whatever the load; batch 1: 640x480 270 vs 272 us, 320x240 205 vs 168 us for the tile kernels.)
     // multi-frame windows: frame-parallel workgroups (gather128s.hip, FP) -- `pairs` waves per segment, so a launch has
-    // 2048 / pairs resident work-item slots instead of 2048.  reserved_ bit 22: the frames looped over inside one wave (A/B).
-    const bool fp = np >= 2 && np <= 7 && segh == kStripSegH / 2 && !(lv->reserved_ & (1 << 22));
+    // 2048 / pairs resident work-item slots instead of 2048.  flags bit 22: the frames looped over inside one wave (A/B).
+    const bool fp = np >= 2 && np <= 7 && segh == kStripSegH / 2 && !(lv->flags & (1 << 22));
     const int fp_wg_per_cu = fp ? (int)std::min<size_t>(8 / np, (size_t)(160 * 1024) / (((size_t)np * (7 * 21 * 32 + 128) + 4 * 64 + 4) * 4)) : 0;
     const long long slots = fp ? (long long)kCUs * fp_wg_per_cu : (long long)kCUs * 8;
     pl->strip_fp = 0;
-    if ((long long)sxn * syn * lv->B >= 4LL * slots || low || (lv->reserved_ & 262144)) {
+    if ((long long)sxn * syn * Bsel >= 4LL * slots || low || (lv->flags & 262144)) {
       pl->strip = segh;
       pl->strip_fp = fp ? 1 : 0;
       pl->quad = 0;
@@ -522,15 +523,15 @@ int plan_gather(const banet_level_t* lv, GatherPlan* pl) {
   // Latency-bound launches (coarse levels, small batches): ba_gather128q_kernel -- 4x4-pixel items, the whole item one step,
   // ~4x shorter serial chain per item than a tile's 16 steps (gather128q.hip) -- while the launch has at most kQuadRounds items
   // per resident wave (2 workgroups x 4 waves per CU); beyond that the tile kernels' shared stencils win.
-  // reserved_ bit 25: force it at any size (parity tests, A/B); bit 30: off.
+  // flags bit 25: force it at any size (parity tests, A/B); bit 30: off.
   pl->quad = 0;
-  if (pl->c128 && lv->dense && !(lv->reserved_ & ((1 << 30) | 512 | 64))) {   // (bits 9 / 6 force the patch / direct tile kernels)
+  if (pl->c128 && lv->dense && !(lv->flags & ((1 << 30) | 512 | 64))) {   // (bits 9 / 6 force the patch / direct tile kernels)
     const int qxn = (lv->W + 3) / 4, qyn = (lv->H + 3) / 4;
-    const long long qitems = (long long)qxn * qyn * lv->B * npairs(lv);
+    const long long qitems = (long long)qxn * qyn * Bsel * npairs(lv);
     // (multi-frame windows: every virtual window redoes the depth dot -- half the limit: cfg-3's 40x30 x 32 x 4 = 9600 items wins,
     //  cfg-5's 80x60 x 8 x 7 = 16800 loses 329 vs 210 us, profiles/r04_run9_*)
     const long long qlimit = (long long)kQuadRounds * kCUs * 8 / (npairs(lv) > 1 ? 2 : 1);
-    if (qitems <= qlimit || (lv->reserved_ & (1 << 25))) {
+    if (qitems <= qlimit || (lv->flags & (1 << 25))) {
       const int VBq = lv->B * npairs(lv);
       pl->quad = 1;
       pl->patch = 0;
@@ -561,30 +562,34 @@ int plan_gather(const banet_level_t* lv, GatherPlan* pl) {
   // across the windows.
   // Large dense levels (>= 4 tiles per resident wave): ba_gather128p_kernel -- wave-private LDS patches with a
   // software-pipelined box prefetch, 2 workgroups per CU (measured 640x480 x 8: 138 -> 125 us/window, 320x240 x 8:
-  // 48 -> 38); smaller levels are latency-bound and keep the 3-per-CU direct kernel.  reserved_ bit 6: direct (A/B).
-  pl->patch = (pl->c128 && lv->dense && !(lv->reserved_ & 64) &&
-               ((long long)pl->tiles * lv->B * npairs(lv) >= 4LL * kCUs * BANET_G128P_WAVES * kNumWaves ||
-                (lv->reserved_ & 512))) ? 1 : 0;   // bit 9: force it at any size (parity tests)
+  // 48 -> 38); smaller levels are latency-bound and keep the 3-per-CU direct kernel.  flags bit 6: direct (A/B).
+  pl->patch = (pl->c128 && lv->dense && !(lv->flags & 64) &&
+               ((long long)pl->tiles * Bsel * npairs(lv) >= 4LL * kCUs * BANET_G128P_WAVES * kNumWaves ||
+                (lv->flags & 512))) ? 1 : 0;   // bit 9: force it at any size (parity tests)
   const int resident = kCUs * (pl->patch ? BANET_G128P_WAVES : pl->c128 ? kC128BlocksPerCU : kGenericBlocksPerCU);
   const int VB = lv->B * npairs(lv);   // virtual windows
+  const int VBsel = Bsel * npairs(lv);
+  // the generic kernel publishes one partial row per WORKGROUP (rows = G), so its grid is part of the arithmetic: taken from Bsel;
+  // the C = 128 kernels publish one row per work item in a fixed place, their grid is free to follow the launch
+  const int Bgrid = pl->c128 ? lv->B : Bsel;
   // the patch kernel loops over a window's target frames inside a tile (depth dot once per window) where a window alone has
   // >= 4 tiles per resident wave; below that the 4x coarser items cost more than the shared depth saves (80x60 x 32
   // windows x 4 frames: 327 -> 478 us) and a work item stays one pair's tile
-  pl->pairloop = (pl->patch && npairs(lv) > 1 && ((long long)pl->tiles * lv->B >= 4LL * kCUs * BANET_G128P_WAVES * kNumWaves ||
-                                                   (lv->reserved_ & 4096))) ? 1 : 0;   // bit 12: force it (parity tests)
-  const int gy = pl->pairloop ? lv->B : VB;
+  pl->pairloop = (pl->patch && npairs(lv) > 1 && ((long long)pl->tiles * Bsel >= 4LL * kCUs * BANET_G128P_WAVES * kNumWaves ||
+                                                   (lv->flags & 4096))) ? 1 : 0;   // bit 12: force it (parity tests)
+  const int gy = pl->pairloop ? Bgrid : Bgrid * npairs(lv);
   int target = (resident + gy - 1) / gy;
   // Mid-size levels (a few tiles per wave at most) start all their waves in the same phase: measured, ~1300 waves
   // finish a tile in 67 us but 2560 need 169 us (160x120 x 8: one tile per wave 21.1 us/window, two per wave on half
   // the waves 16.7).  Such levels run on at most 320 workgroups (1280 waves).
-  if (pl->c128 && !pl->patch && (long long)pl->tiles * VB < 4LL * kCUs * BANET_G128P_WAVES * kNumWaves)
+  if (pl->c128 && !pl->patch && (long long)pl->tiles * VBsel < 4LL * kCUs * BANET_G128P_WAVES * kNumWaves)
     target = min(target, (320 + VB - 1) / VB);
   // quarter-tile work items pay (measured: 40x30 x 8 windows 94 -> 50 us) only while they still leave the chip
   // mostly empty -- at most one item per SIMD; beyond that the redone depth dot / geometry costs more than
-  // the shorter step chain saves (80x60 x 8: 101 -> 132 us).  reserved_ bit 4: off (A/B).
-  pl->qshift = (pl->c128 && !pl->patch && pl->tiles <= 32 && (long long)pl->tiles * VB * 4 <= (long long)kCUs * 4 &&
-                !(lv->reserved_ & 16)) ? 2 : 0;
-  if (pl->c128 && !pl->patch && (lv->reserved_ & 1024)) pl->qshift = 2;   // bit 10: force quarter tiles (A/B)   // (80x60 x 2 windows, also 640 items, LOSES 82 vs 51 us: coarsest levels only)
+  // the shorter step chain saves (80x60 x 8: 101 -> 132 us).  flags bit 4: off (A/B).
+  pl->qshift = (pl->c128 && !pl->patch && pl->tiles <= 32 && (long long)pl->tiles * VBsel * 4 <= (long long)kCUs * 4 &&
+                !(lv->flags & 16)) ? 2 : 0;
+  if (pl->c128 && !pl->patch && (lv->flags & 1024)) pl->qshift = 2;   // bit 10: force quarter tiles (A/B)   // (80x60 x 2 windows, also 640 items, LOSES 82 vs 51 us: coarsest levels only)
   int G = pl->c128 ? ((pl->tiles << pl->qshift) + 3) / 4 : pl->groups;
   if (G > target) {
     G = target >= 8 ? (target & ~7) : target;   // several work items per wave: one resident round, no more

@@ -270,8 +270,8 @@ __global__ __launch_bounds__(kBlock, BANET_G128_WAVES) void ba_gather128_kernel(
       const int j = 4 * s + grp;
       const float4 pa = *reinterpret_cast<const float4*>(&sPar[w][j][0]);
       const float4 pb = *reinterpret_cast<const float4*>(&sPar[w][j][4]);
-#ifdef BANET_ABLATE   // development aid (tools/prof_assemble.py): reserved_ bit 0 -> every tap reads texel (1,1) / point 0
-      const bool abl = (lv.reserved_ & 1) != 0;
+#ifdef BANET_ABLATE   // development aid (tools/prof_assemble.py): flags bit 0 -> every tap reads texel (1,1) / point 0
+      const bool abl = (lv.flags & 1) != 0;
       const unsigned osrc = abl ? 0u : (unsigned)__float_as_int(pa.x), oa = abl ? (unsigned)((W + 1) * C) : (unsigned)__float_as_int(pa.y);
 #else
       const unsigned osrc = (unsigned)__float_as_int(pa.x), oa = (unsigned)__float_as_int(pa.y);

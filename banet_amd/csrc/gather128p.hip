@@ -115,8 +115,8 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
   const int grp = lane >> 4, sub = lane & 15;
   const int half = lane >> 5, li = lane & 31;
 
-#ifdef BANET_ABLATE   // development aid (tools/prof_assemble.py): reserved_ bits 0..3 switch phases of this kernel off
-  const int abl = lv.reserved_;
+#ifdef BANET_ABLATE   // development aid (tools/prof_assemble.py): flags bits 0..3 switch phases of this kernel off
+  const int abl = lv.flags;
 #else
   constexpr int abl = 0;
 #endif
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
   // the first tiles (depth-dot burst, then every unit's loads at the same time); measured 320x240 x 8: 39.0 -> 37.6
   // us/window, 640x480 x 8: 125.5 -> 124.1; 15 us per wave: no better.  (On the short levels, which run the direct
   // kernel, any stagger loses.)
-  if (!(lv.reserved_ & 2048))   // bit 11: no stagger (A/B)
+  if (!(lv.flags & 2048))   // bit 11: no stagger (A/B)
     for (int i = 0; i < 2 * w; ++i) __builtin_amdgcn_s_sleep(127);
   if constexpr (KV4 > 0) {
 #pragma unroll
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
         const int bx0 = red8(fast ? x0 : big, false), bx1 = red8(fast ? x0 : -big, true);
         const int by0 = red8(fast ? y0 : big, false), by1 = red8(fast ? y0 : -big, true);
         const int x_lo = bx0 - 1, y_lo = by0 - 1, pw = bx1 - bx0 + 4, ph = by1 - by0 + 4;
-        const bool st = bx1 >= bx0 && (FS ? (pw <= 8 && ph <= 5) : pw * ph <= PT) && !(lv.reserved_ & 128);
+        const bool st = bx1 >= bx0 && (FS ? (pw <= 8 && ph <= 5) : pw * ph <= PT) && !(lv.flags & 128);
         pb.w = __int_as_float(((fast ? y0 - y_lo : 1) * (FS ? 8 : pw) + (fast ? x0 - x_lo : 1)) * 64);
         if ((lane & (GL - 1)) == 0) {
           sGrp[w][lane / GL][0] = st ? (y_lo * W + x_lo) * C : 0;
@@ -403,9 +403,9 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
       }
     };
     const int sp_end = s_hi / US;
-    // unit order: 0..7 = left / right unit of pixel rows 0-1, 2-3, ... (Z order); reserved_ bit 17 (experiment, US = 2 only):
+    // unit order: 0..7 = left / right unit of pixel rows 0-1, 2-3, ... (Z order); flags bit 17 (experiment, US = 2 only):
     // the left column top to bottom, then the right column bottom to top -- horizontal neighbours 1..7 units apart instead of 1
-    const bool colmajor = US == 2 && (lv.reserved_ & 131072) != 0;
+    const bool colmajor = US == 2 && (lv.flags & 131072) != 0;
     auto unit_at = [&](int it) { return colmajor ? (it < 4 ? 2 * it : 2 * (7 - it) + 1) : it; };
     for (int it = s_lo / US; it < sp_end; ++it) {
       const int sp = unit_at(it);
@@ -628,15 +628,15 @@ __global__ __launch_bounds__(kBlock, BANET_G128P_WAVES) void ba_gather128p_kerne
 
 int launch_gather128p(const GatherArgs& a, int K, hipStream_t s) {
   dim3 grid(a.G, a.pairloop ? a.lv.B : a.lv.B * a.pairs), block(kBlock);
-  // reserved_ bit 13 (A/B experiment, experiments/README.md): 60 KB of unused dynamic LDS per workgroup -> ONE workgroup per CU
+  // flags bit 13 (A/B experiment, experiments/README.md): 60 KB of unused dynamic LDS per workgroup -> ONE workgroup per CU
   // (one gather wave per SIMD), the occupancy a wave-specialised gather + MFMA-accumulator kernel would leave the gather
   size_t dyn = 0;
-  if (a.lv.reserved_ & 8192) {
+  if (a.lv.flags & 8192) {
     dyn = 60 * 1024;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_gather128p_kernel<1, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
   }
-  const bool u4 = (a.lv.reserved_ & 16384) != 0;   // bit 14: 4-step units (A/B, experiments/README.md)
-  const bool packed = (a.lv.reserved_ & 65536) != 0;   // bit 16: the packed patch with flat loads (A/B)
+  const bool u4 = (a.lv.flags & 16384) != 0;   // bit 14: 4-step units (A/B, experiments/README.md)
+  const bool packed = (a.lv.flags & 65536) != 0;   // bit 16: the packed patch with flat loads (A/B)
   const bool small = (size_t)a.lv.H * a.lv.W * a.lv.C * 4 < ((size_t)1 << 31) && (size_t)a.lv.N * a.lv.C * 4 < ((size_t)1 << 31);
   const bool fs = small && !packed && !dyn;          // the fixed-stride patch addresses the maps with 32-bit buffer offsets
   if (K == 0 && fs)

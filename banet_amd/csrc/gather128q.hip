@@ -20,7 +20,7 @@
 //   * items are assigned statically (wave g of the launch takes items g, g + waves, ...: they cost the same), no atomic queue:
 //     at one window the queue's single counter was popped 2 x items times and serialised the launch.
 // Same arithmetic per pixel as ba_gather128_kernel; the channel sums are added unit by unit (different rounding order).
-// Selected by plan_gather for launches with few items per resident wave (reserved_ bit 25 forces it, bit 30 disables it).
+// Selected by plan_gather for launches with few items per resident wave (flags bit 25 forces it, bit 30 disables it).
 #include "quad_common.hpp"
 
 namespace banet {

@@ -410,7 +410,7 @@ __global__ __launch_bounds__(FP ? 512 : kSBlock, 2) __attribute__((amdgpu_num_vg
         // counts kRowOps = 3 operations per row, and an instruction whose lanes are all off is branched around.
         ncol3 = 8 * max(rfl(xe) + 1 - 16, 1);
         strip_plan_dynamic(env, SEGH, rfl(ye));
-        if (lv.reserved_ & (1 << 20)) {   // parity tests: every pixel row takes the direct (window-less) path
+        if (lv.flags & (1 << 20)) {   // parity tests: every pixel row takes the direct (window-less) path
           if (step_mode(env.ctlv) == kStepWindow) env.ctlv = kStepDirect;
         }
         plan_ctl = env.ctlv;

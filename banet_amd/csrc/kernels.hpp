@@ -8,6 +8,9 @@ constexpr int kGHdr = 32;       // gather partial header: 21 H_cc + 6 Atb_c + nv
 constexpr int kUStrideS = 8;    // per-pixel record: u0..u5, s, r
 
 inline int npairs(const banet_level_t* lv) { return lv->pairs > 1 ? lv->pairs : 1; }
+// the batch size every kernel / arithmetic-form / partial-row decision is taken from (banet_level_t.policy): the launch's own, or
+// -- BANET_POLICY_BATCH_INVARIANT -- the canonical one, so that a window's bits do not depend on who shares its launch
+inline int selection_batch(const banet_level_t* lv) { return lv->policy == BANET_POLICY_BATCH_INVARIANT ? BANET_CANONICAL_BATCH : lv->B; }
 
 // compute units of the current device (hipDeviceAttributeMultiprocessorCount, queried once per device; 256 = MI355X when no
 // device is visible, e.g. the host-only plan / workspace arithmetic of the CPU tests).  The launch plans size their grids by it.
@@ -52,7 +55,7 @@ struct MlpRole {        // one extra workgroup per window of the SYRK launch eva
 };
 struct SyrkPlan {
   int Gs, tiles, pstride, nb;
-  int x3;       // ba_syrk_bf16x6_kernel, opt-in: three products instead of six (reserved_ bit 29)
+  int x3;       // ba_syrk_bf16x6_kernel, opt-in: three products instead of six (flags bit 29)
   int direct;   // 0: the LDS-tiled kernel, 1: ba_syrk_direct_kernel (fp32 MFMA, A/B), 2: ba_syrk_bf16x6_kernel (K = 64 / 128, <= 4 frames),
                 // 3: syrk_wide.hip jobs (K = 256, or K = 128 with more than 4 target frames)
   int f16;      // ba_syrk_bf16x6_kernel: the fp16 two-piece form is eligible (plan_syrk); f16_standalone: also in a single assembly pass
@@ -65,7 +68,7 @@ size_t syrk_wide_aux_bytes(int B, int N, int pairs);
 int launch_syrk_wide(const float* basis, const float* rec, int B, int N, int K, int pairs, int Gs, int pstride,
                      const int32_t* active, int active_stride, float* partials, float* aux, hipStream_t s,
                      const float* colmax = nullptr, const float* recmax = nullptr);   // both given: the fp16 two-piece form
-int plan_syrk(int B, int N, int K, int pairs, int dbg, SyrkPlan* pl);
+int plan_syrk(int B, int Bsel, int N, int K, int pairs, int dbg, SyrkPlan* pl);   // Bsel: the batch the decisions are taken from (selection_batch)
 int launch_syrk(const float* basis, const float* rec, int B, int N, int K, int pairs, const SyrkPlan& pl,
                 const int32_t* active, int active_stride, float* partials, hipStream_t s, const MlpRole* mr = nullptr,
                 int f16_stats = -1);   // f16_stats: -1 = exact bf16 form; 0 / 1 = fp16 two-piece form (pl.f16), basis column maxima to compute / in
@@ -154,7 +157,7 @@ struct SolveArgs {
   int nqueue;  // words per window
   const float* mlp_y;   // [B] lambda-MLP outputs precomputed by the SYRK launch's role workgroups, or nullptr
   banet_lm_params_t lm;   // run-time LM configuration (legacy/ba.py:5-9)
-  int flags;              // banet_level_t.reserved_ (development switches: bit 23 = blocked LDL^T only, no conjugate gradients)
+  int flags;              // banet_level_t.flags (development switches: bit 23 = blocked LDL^T only, no conjugate gradients)
 };
 int launch_solve(const SolveArgs& a, hipStream_t s);
 int launch_spd_solve(const float* A, const float* rhs, float* x, int B, int P, hipStream_t s);   // 32 <= P, matrix in LDS

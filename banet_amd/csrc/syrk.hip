@@ -2,7 +2,7 @@
 //   ba_syrk_bf16x6_kernel  the product path for K = 64 / 128 and <= 4 target frames: bf16 matrix pipe at fp32 accuracy,
 //                          operands straight from registers (see its header comment further down);
 //                          K = 256 and more frames: the same scheme cut into jobs, syrk_wide.hip;
-//   ba_syrk_direct_kernel  its fp32-MFMA predecessor, kept for A/B (reserved_ bit 8);
+//   ba_syrk_direct_kernel  its fp32-MFMA predecessor, kept for A/B (flags bit 8);
 //   ba_syrk_kernel<NB>     LDS-tiled fp32 MFMA, any K <= 256 (the remaining basis sizes), described first:
 //
 // ba_syrk_kernel -- the depth-basis blocks of the normal equations on gfx950:
@@ -979,7 +979,7 @@ static int nb_for_k(int K) {
 
 constexpr long long kSyrkF16Pixels = 32LL * 76800;   // 320x240 x 32 windows, 640x480 x 8
 
-int plan_syrk(int B, int N, int K, int pairs, int dbg, SyrkPlan* pl) {
+int plan_syrk(int B, int Bsel, int N, int K, int pairs, int dbg, SyrkPlan* pl) {
   pl->nb = nb_for_k(K);
   if (pl->nb < 0) return BANET_ERR_UNSUPPORTED;
   if (K == 0) {
@@ -994,16 +994,16 @@ int plan_syrk(int B, int N, int K, int pairs, int dbg, SyrkPlan* pl) {
   }
   pl->tiles = (N + kTilePix - 1) / kTilePix;
   // K = 64 / 128: barrier-free kernels, one wave per SIMD, one workgroup per CU in all: 2 = ba_syrk_bf16x6_kernel
-  // (default), 1 = ba_syrk_direct_kernel (fp32 MFMA; reserved_ bit 8, A/B only)
+  // (default), 1 = ba_syrk_direct_kernel (fp32 MFMA; flags bit 8, A/B only)
   pl->direct = ((K == 64 || K == 128) && pairs <= 4) ? ((dbg & 256) ? 1 : 2) : 0;
-  // OPT-IN (reserved_ bit 29, K = 128): the three largest of the six products only -- a two-piece split, 16 significand bits per
+  // OPT-IN (flags bit 29, K = 128): the three largest of the six products only -- a two-piece split, 16 significand bits per
   // operand, ~2^-16 relative error per product instead of 2^-24.  Not the product path and not what bench.py's `value` is measured
   // with (its dtype is "f32": fp32-exact products); measured beside it: profiles/r03_run31_*, DESIGN.md section 7.
   pl->x3 = (pl->direct == 2 && K == 128 && (dbg & (1 << 29))) ? 1 : 0;
-  // K = 256, or K = 128 with more than 4 target frames: the job kernels of syrk_wide.hip (reserved_ bit 8: the LDS-tiled kernel, A/B)
+  // K = 256, or K = 128 with more than 4 target frames: the job kernels of syrk_wide.hip (flags bit 8: the LDS-tiled kernel, A/B)
   if (!(dbg & 256) && (K == 256 || (K == 128 && pairs > 4))) pl->direct = 3;
   const int cus = num_cus();
-  int target = (((pl->direct || pl->nb > 8) ? cus : 2 * cus) + B - 1) / B;   // LDS kernel: 2 resident workgroups per CU (1 at K > 128)
+  int target = (((pl->direct || pl->nb > 8) ? cus : 2 * cus) + Bsel - 1) / Bsel;   // Gs = partial rows per window: part of the arithmetic, hence from Bsel   // LDS kernel: 2 resident workgroups per CU (1 at K > 128)
   int G = pl->direct ? (N + 4 * 4 * 16 - 1) / (4 * 4 * 16) : pl->tiles / 4;   // direct: >= 16 quads per wave
   if (G > target) G = target;
   if (G < 1) G = 1;
@@ -1015,9 +1015,9 @@ int plan_syrk(int B, int N, int K, int pairs, int dbg, SyrkPlan* pl) {
   // The fp16 two-piece form of ba_syrk_bf16x6_kernel (half the MFMAs, 5 instead of 9 split instructions per two values, the same
   // accuracy class: ~2^-21 per product against the reference's fp32 GEMM) where the launch is throughput-bound -- at least
   // kSyrkF16Pixels pixels in all -- so that its two small pre-passes (basis column maxima once per level, record maxima per pass)
-  // are noise.  LM loop (banet_lm_level_f32) only; the single assembly pass keeps the exact bf16 form unless reserved_ bit 24 asks
-  // for this one (tests).  reserved_ bit 31: never (A/B).
-  pl->f16 = ((pl->direct == 2 || pl->direct == 3) && !pl->x3 && !(dbg & (1u << 31)) && ((long long)N * B >= kSyrkF16Pixels || (dbg & (1 << 24)))) ? 1 : 0;
+  // are noise.  LM loop (banet_lm_level_f32) only; the single assembly pass keeps the exact bf16 form unless flags bit 24 asks
+  // for this one (tests).  flags bit 31: never (A/B).
+  pl->f16 = ((pl->direct == 2 || pl->direct == 3) && !pl->x3 && !(dbg & (1u << 31)) && ((long long)N * Bsel >= kSyrkF16Pixels || (dbg & (1 << 24)))) ? 1 : 0;
   pl->f16_standalone = (pl->f16 && (dbg & (1 << 24))) ? 1 : 0;
   pl->off_colmax = pl->partial_bytes;
   pl->off_recmax = pl->off_colmax + (pl->f16 ? align_up((size_t)B * K * sizeof(float), 256) : 0);

@@ -87,7 +87,7 @@ class Problem:
             return
         self.ba = bdense.DenseBA(self.intr, self.levels, self.mlps, "bundle", 1000.0)
         for prob in self.ba.problems:
-            prob.c.reserved_ = reserved
+            prob.c.flags = reserved
         # translation prior: from T = 0 the depth Jacobian is identically zero (depth unobservable) and the reference's
         # undamped last coefficient diverges (bundlenet.py:266)
         self.T0 = (self.gt["T"] * 0.7).reshape(B * self.pairs, 3, 1).to(dev)
@@ -131,7 +131,7 @@ def roofline_record(prob, prof, elapsed_s, traffic=None):
     alg_bytes, kern_ms, nlaunch, per_level, syrk_ms, syrk_n = 0.0, 0.0, 0, {}, 0.0, 0
     syrk_flops, syrk_exec = 0.0, 0.0
     pairs = max(int(prob.pairs), 1)
-    three = bool(int(getattr(ba.problems[0].c, "reserved_", 0)) & (1 << 29)) and int(ba.problems[0].c.K) == 128   # ops.SYRK_THREE_PRODUCTS (opt-in)
+    three = bool(int(getattr(ba.problems[0].c, "flags", 0)) & (1 << 29)) and int(ba.problems[0].c.K) == 128   # ops.SYRK_THREE_PRODUCTS (opt-in)
     forms = []
     for li, p in enumerate(ba.problems):
         try:
@@ -386,11 +386,11 @@ def chain_parity_record(prob, dev, window):
     kernels = []
     for p1, pb in zip(ba1.problems, prob.ba.problems):
         sel = ops.gather_selection(pb)
-        p1.c.reserved_ = int(pb.c.reserved_) | {4: ops.FORCE_QUAD_GATHER, 3: ops.FORCE_STRIP_GATHER, 2: ops.FORCE_PATCH_GATHER,
+        p1.c.flags = int(pb.c.flags) | {4: ops.FORCE_QUAD_GATHER, 3: ops.FORCE_STRIP_GATHER, 2: ops.FORCE_PATCH_GATHER,
                                                  1: ops.NO_QUAD_GATHER}.get(sel, 0)
         assert ops.gather_selection(p1) == sel or sel == 0, (sel, ops.gather_selection(p1))
         if ops.syrk_selection(pb) == 4:      # the batch's LM loop runs the fp16 two-piece SYRK at this level: so does the check
-            p1.c.reserved_ = int(p1.c.reserved_) | ops.SYRK_F16
+            p1.c.flags = int(p1.c.flags) | ops.SYRK_F16
             assert ops.syrk_selection(p1) == 4
         kernels.append(ops.GATHER_KERNELS[ops.gather_selection(p1)])
     st = ba1.new_state(T=prob.T0[w].contiguous())
@@ -616,7 +616,7 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the in-line oracle parity records")
     ap.add_argument("--no-sweep-large", action="store_true", help="leave B = 256 two-frame windows (161 GB of inputs) and the "
                     "cfg-5 share (8 x 8-frame 1280x960 K=256 windows, 67 GB) out of the sweep")
-    ap.add_argument("--reserved", type=int, default=0, help="development: banet_level_t.reserved_ bits for every level (A/B switches)")
+    ap.add_argument("--reserved", type=int, default=0, help="development: banet_level_t.flags bits for every level (A/B switches)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -87,21 +87,49 @@ enum { /* banet_level_t.variant: which reference iteration is restated */
   BANET_BUNDLE = 3         /* bundlenet.py:193-278 BundleIteration (pose + depth basis)   */
 };
 
-/* Documented bits of banet_level_t.reserved_ (everything else is internal A/B plumbing and must be 0):
- *   BANET_DEV_FORCE_PATCH_GATHER / _STRIP_GATHER : run that C = 128 gather kernel at any launch size (parity tests compare
- *       the kernels at oracle sizes; banet_gather_selection reports what a level runs);
- *   BANET_DEV_SYRK_THREE_PRODUCTS : OPT-IN, reduced precision -- the K = 128 depth-block contraction with the three largest
+/* banet_level_t.flags -- named overrides of the kernel / arithmetic-form selection (0 in production).  The BANET_FLAG_* bits are the
+ * documented ones; every other bit is development A/B plumbing (tools/, profiles/) and must be 0 in a caller's code.
+ *   BANET_FLAG_FORCE_PATCH_GATHER / _STRIP_GATHER / _QUAD_GATHER, BANET_FLAG_NO_QUAD_GATHER : run (never run) that C = 128 gather kernel
+ *       at any launch size (parity tests compare the kernels at oracle sizes; banet_gather_selection reports what a level runs);
+ *   BANET_FLAG_SYRK_F16 / BANET_FLAG_NO_SYRK_F16 : the arithmetic FORM of the depth-block contraction.  Default (neither bit): the LM loop
+ *       (banet_lm_level_f32) runs the fp16 two-piece form -- fp32 operands as two scaled fp16 pieces, three products, ~2^-21 per
+ *       product, <= 2e-7 per entry of the matrix's own scale; an absolute 2^-25 of the column bound for entries more than 17 octaves
+ *       below it -- on throughput-bound launches (N * B >= 32 * 76 800 pixels; banet_level_t.policy decides whether B counts), and the
+ *       exact form (three bf16 pieces, six products, fp32-exact) elsewhere; the single pass banet_ba_assemble_f32 always runs the
+ *       exact form.  _SYRK_F16: the fp16 form at any launch size and in the single pass too; _NO_SYRK_F16: the exact form everywhere.
+ *       banet_syrk_selection reports the form;
+ *   BANET_FLAG_SYRK_THREE_PRODUCTS : OPT-IN, reduced precision -- the K = 128 depth-block contraction with the three largest
  *       bf16 products only (~2^-16 per product instead of fp32-exact).  Never the default, never what bench.py's `value`
- *       is measured with.                                                                                              */
+ *       is measured with.
+ * (Until round 4 this field was called `reserved_` and the bits BANET_DEV_*: same offset, same values; the old names stay as aliases.) */
 enum {
-  BANET_DEV_FORCE_PATCH_GATHER = 1 << 9,
-  BANET_DEV_FORCE_STRIP_GATHER = 1 << 18,
-  BANET_DEV_FORCE_QUAD_GATHER = 1 << 25,   /* the 4x4-pixel-item gather of latency-bound launches, at any size */
-  BANET_DEV_NO_QUAD_GATHER = 1 << 30,      /* ... never (the tile kernels instead) */
-  BANET_DEV_SYRK_THREE_PRODUCTS = 1 << 29,
-  BANET_DEV_SYRK_F16 = 1 << 24,             /* the fp16 two-piece SYRK also in banet_ba_assemble_f32 and at any launch size (tests) */
-  BANET_DEV_NO_SYRK_F16 = (int)0x80000000   /* ... never: the exact bf16 form everywhere (A/B) */
+  BANET_FLAG_FORCE_PATCH_GATHER = 1 << 9,
+  BANET_FLAG_FORCE_STRIP_GATHER = 1 << 18,
+  BANET_FLAG_FORCE_QUAD_GATHER = 1 << 25,   /* the 4x4-pixel-item gather of latency-bound launches, at any size */
+  BANET_FLAG_NO_QUAD_GATHER = 1 << 30,      /* ... never (the tile kernels instead) */
+  BANET_FLAG_SYRK_THREE_PRODUCTS = 1 << 29,
+  BANET_FLAG_SYRK_F16 = 1 << 24,             /* the fp16 two-piece SYRK also in banet_ba_assemble_f32 and at any launch size */
+  BANET_FLAG_NO_SYRK_F16 = (int)0x80000000,  /* ... never: the exact bf16 form everywhere */
+  BANET_DEV_FORCE_PATCH_GATHER = BANET_FLAG_FORCE_PATCH_GATHER,
+  BANET_DEV_FORCE_STRIP_GATHER = BANET_FLAG_FORCE_STRIP_GATHER,
+  BANET_DEV_FORCE_QUAD_GATHER = BANET_FLAG_FORCE_QUAD_GATHER,
+  BANET_DEV_NO_QUAD_GATHER = BANET_FLAG_NO_QUAD_GATHER,
+  BANET_DEV_SYRK_THREE_PRODUCTS = BANET_FLAG_SYRK_THREE_PRODUCTS,
+  BANET_DEV_SYRK_F16 = BANET_FLAG_SYRK_F16,
+  BANET_DEV_NO_SYRK_F16 = BANET_FLAG_NO_SYRK_F16
 };
+
+/* banet_level_t.policy -- what the kernel / form selection may depend on.
+ *   BANET_POLICY_THROUGHPUT (0, default): kernels, the SYRK form and the number of partial rows are chosen from the whole LAUNCH
+ *       (N, K, pairs AND the batch B): fastest, and results are within rounding (<= 1e-5 relative on a solve, tested) of any other
+ *       batching of the same windows -- but not bit-identical to them: a window solved in a batch of 8 and in a batch of 32 may run
+ *       different gather kernels, SYRK forms and summation splits.
+ *   BANET_POLICY_BATCH_INVARIANT (1): every such decision is taken from the LEVEL alone (N, K, pairs, as if B = BANET_CANONICAL_BATCH),
+ *       so a window's bits do not depend on how many windows share its launch or on how a batch is sharded over GPUs (tested:
+ *       batches of 1 / 8 / 32 bit-identical).  Small batches then run the kernels tuned for 32 windows: slower below ~8 windows.
+ *       The reference has no such dependence either way (utils.cu:181-198 reduces per item).                                        */
+enum { BANET_POLICY_THROUGHPUT = 0, BANET_POLICY_BATCH_INVARIANT = 1 };
+#define BANET_CANONICAL_BATCH 32
 
 typedef struct banet_level {
   int32_t B;            /* windows                                                        */
@@ -124,9 +152,10 @@ typedef struct banet_level {
                            of SURVEY.md 8(d): the key frame carries depth / basis / Wc, every
                            other frame its own pose; P = 6 pairs + K, parameter order
                            [pose_1 .. pose_pairs, depth]                                     */
-  int32_t reserved_;    /* 0 in production; development switches (A/B kernel selection), of which
-                           the BANET_DEV_* bits below are the documented ones                  */
-  int32_t pad_;         /* must be 0                                                      */
+  int32_t flags;        /* 0 in production; BANET_FLAG_* overrides of the kernel / arithmetic-form selection
+                           (above); was `reserved_` until round 4 (same offset)                */
+  int32_t policy;       /* BANET_POLICY_THROUGHPUT (0) or BANET_POLICY_BATCH_INVARIANT (1); was `pad_`,
+                           which had to be 0: existing callers get the default                  */
   const float* src;     /* dense: source map [B,H,W,C];  sparse: conv1 [B,N,C]            */
   const float* tgt;     /* target maps [B,pairs,H,W,C] or [B,pairs,H,W,3C]                */
   const float* depth;   /* D  [B,N]   (legacy: z-depth; bundle: range along the ray)      */
@@ -336,7 +365,7 @@ const char* banet_build_id(void);
  *     3 = ba_gather128s_kernel (16x16 strip segments, rolling LDS window), 4 = ba_gather128q_kernel (4x4-pixel items, one step
  *     per item: latency-bound launches); negative = error code.  The selection depends on
  *     the batch (work items per resident wave), so bench.py / the tests use this to run a one-window parity check on the
- *     kernel the full batch runs (the BANET_DEV_FORCE_* / _NO_QUAD_GATHER bits of banet_level_t.reserved_).                */
+ *     kernel the full batch runs (the BANET_FLAG_FORCE_* / _NO_QUAD_GATHER bits of banet_level_t.flags).                */
 int banet_gather_selection(const banet_level_t* lv);
 /*   banet_syrk_selection: which depth-block contraction (SYRK) kernel banet_lm_level_f32 runs for this level AND batch size --
  *     0 = ba_syrk_kernel (LDS-tiled fp32 MFMA), 1 = ba_syrk_direct_kernel (fp32 MFMA, A/B), 2 = ba_syrk_bf16x6_kernel (fp32 operands

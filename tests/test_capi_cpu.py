@@ -10,6 +10,8 @@ import sys
 import pytest
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+# the host-side plans below are tabulated for a 256-CU part (MI355X); num_cus() would otherwise follow whatever GPU the host has
+os.environ.setdefault("BANET_NUM_CUS", "256")
 HEADER = os.path.join(ROOT, "include", "banet_hip.h")
 
 
@@ -324,11 +326,12 @@ def test_strip_gather_register_contract():
     assert "0 violations" in r.stdout
 
 
-def _level(capi, B, H, W, K, pairs, reserved=0):
+def _level(capi, B, H, W, K, pairs, reserved=0, policy=0):
     lv = capi.Level()
+    lv.policy = policy
     lv.B, lv.N, lv.C, lv.K, lv.H, lv.W = B, H * W, 128, K, H, W
     lv.variant, lv.dense, lv.scale, lv.pairs, lv.normalize_rays = capi.BUNDLE, 1, 1.0, pairs, 1
-    lv.reserved_ = reserved
+    lv.flags = reserved
     return lv
 
 
@@ -358,3 +361,26 @@ def test_kernel_selection_table_of_the_baseline_configs(capi):
     assert sel(32, h, w, 128, 1, reserved=1 << 30)[0] == 1 and sel(32, 480, 640, 128, 1, reserved=-2147483648)[1] == 2
     assert sel(32, h, w, 128, 1, reserved=(1 << 18) | 1024)[0] == 3
     assert sel(6, 240, 320, 128, 1)[0] == 1 and sel(6, 240, 320, 128, 1, reserved=1 << 25)[0] == 4      # (28800 items: beyond its limit -> tiles)
+
+
+def test_batch_invariant_policy_selects_by_level_only(capi):
+    """banet_level_t.policy = BANET_POLICY_BATCH_INVARIANT: the gather kernel and the SYRK form of a level are the ones a batch of
+    BANET_CANONICAL_BATCH = 32 windows runs, whatever the launch's own batch -- so a window's arithmetic does not depend on its shard
+    size (the bit-identity itself is a -m gpu test).  The default policy does depend on it (cfg-5: 64 windows on one GPU vs 8 per GPU)."""
+    L = capi.lib()
+    sel = lambda *a, **k: (L.banet_gather_selection(ctypes.byref(_level(capi, *a, **k))),       # noqa: E731
+                           L.banet_syrk_selection(ctypes.byref(_level(capi, *a, **k))))
+    pyr = [(30, 40), (60, 80), (120, 160), (240, 320), (480, 640)]
+    for pairs in (1, 4):
+        want = [sel(32, h, w, 128, pairs) for h, w in pyr]
+        for B in (1, 2, 8, 13, 32, 64, 256):
+            assert [sel(B, h, w, 128, pairs, policy=capi.POLICY_BATCH_INVARIANT) for h, w in pyr] == want, (pairs, B)
+    # the dependence the policy removes: cfg-5's 320x240 level, K = 256, 7 target frames
+    assert sel(64, 240, 320, 256, 7)[1] == 4 and sel(8, 240, 320, 256, 7)[1] == 3
+    assert sel(64, 240, 320, 256, 7, policy=1) == sel(8, 240, 320, 256, 7, policy=1)
+    # the field that used to be `pad_` still rejects garbage
+    lv = _level(capi, 8, 30, 40, 128, 1, policy=7)
+    assert L.banet_lm_level_workspace_bytes(ctypes.byref(lv)) == 0 or L.banet_gather_selection(ctypes.byref(lv)) >= 0
+    # the old field name is an alias of the new one (tools/ still use it)
+    lv.reserved_ = 1 << 18
+    assert lv.flags == 1 << 18

@@ -42,8 +42,9 @@ def relerr(got, want):
     return float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-30))
 
 
-def _window_level_check(B, H, W, C, K, pairs, seed, tol_step=1e-4):
-    """one full-resolution level of B multi-frame windows: assembly and one LM update vs the float64 twin"""
+def _window_level_check(B, H, W, C, K, pairs, seed, tol_step=1e-4, flags=0, expect_sel=None):
+    """one full-resolution level of B multi-frame windows: assembly and one LM update vs the float64 twin.
+    flags: banet_level_t.flags for the level (forces a kernel selection); expect_sel: the (gather, SYRK) selection asserted"""
     from banet_amd import dense as bdense, ops, synth as bsynth
     from banet_amd.bundlenet import he_normal_lambda_weights
     torch.manual_seed(seed)
@@ -52,6 +53,9 @@ def _window_level_check(B, H, W, C, K, pairs, seed, tol_step=1e-4):
     mlps = [he_normal_lambda_weights(C, 100)]
     ba = bdense.DenseBA(intr, levels, mlps, "bundle", 1000.0)
     assert ba.pairs == pairs and ba.problems[0].P == 6 * pairs + K
+    ba.problems[0].c.flags = flags
+    if expect_sel is not None:
+        assert (ops.gather_selection(ba.problems[0]), ops.syrk_selection(ba.problems[0])) == tuple(expect_sel)
     g = torch.Generator().manual_seed(seed + 1)
     R = torch.stack([torch.stack([bsynth._rodrigues((torch.rand(3, generator=g) * 2 - 1) * 0.003) for _ in range(pairs)])
                      for _ in range(B)]).to(DEV)
@@ -85,8 +89,9 @@ def _window_level_check(B, H, W, C, K, pairs, seed, tol_step=1e-4):
 
 
 def test_cfg3_full_size_level_matches_float64_twin():
-    """configs[2]: 5-frame windows, 640x480, C = K = 128 -- the finest level at full size, two windows so that the
-    production selection is the one bench.py's cfg-3 record runs (patch gather with the pair loop inside a tile)."""
+    """configs[2]: 5-frame windows, 640x480, C = K = 128 -- the finest level at full size on the kernels a TWO-window launch
+    selects by itself (patch gather with the pair loop inside a tile, exact bf16 SYRK).  The batch-32 production selection
+    (frame-parallel strip gather + fp16 two-piece SYRK) at full size: tests/test_gpu_round5.py."""
     ba = _window_level_check(2, 480, 640, 128, 128, 4, 4711)
     assert ba.problems[0].N == 640 * 480
 
