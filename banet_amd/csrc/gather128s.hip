@@ -24,8 +24,14 @@
 //   * pixel rows whose footprint does not fit the window (local scale > ~1.12, a depth discontinuity) read their taps
 //     directly; pixels on the image rim take the generic slow routine (as in the other C = 128 kernels).
 // Same arithmetic per pixel as ba_gather128_kernel; the channel sums are added slice by slice (different rounding order).
+#include <cstdlib>
+
 #include "quad_common.hpp"
 #include "strip_plan.hpp"
+
+#ifndef BANET_STRIP_OPT_DEFAULT
+#define BANET_STRIP_OPT_DEFAULT 0
+#endif
 
 namespace banet {
 
@@ -71,6 +77,25 @@ __device__ __forceinline__ void glds16(const float* gbase, unsigned voff_bytes, 
                : "=&s"(keep)
                : "v"(voff_bytes), "s"(gbase), "s"(lds_dst)
                : "memory");
+}
+// One window row = three LDS-DMA instructions with ONE M0 write: the instruction offset is added to the LDS address AND to the
+// global address, so instruction k (LDS dst + 1024 k, global row + 4096 k: the next 8 texels of 512 B) takes inst_offset 1024 k and
+// a lane offset of its own, voff + 3072 k.  The third instruction runs under `mask3` (only the texel columns a row reads).
+// (development variant OPT bit 1; the product path issues three glds16, 5 scalar instructions each)
+__device__ __forceinline__ void glds_row(const float* gbase, unsigned v0, unsigned v1, unsigned v2, unsigned lds_dst,
+                                         unsigned long long mask3) {
+  unsigned keep;
+  unsigned long long keepx;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %2, %5" BANET_WIN_NT_ "\n\t"
+      "global_load_lds_dwordx4 %3, %5 offset:1024" BANET_WIN_NT_ "\n\t"
+      "s_mov_b64 %1, exec\n\ts_mov_b64 exec, %7\n\t"
+      "global_load_lds_dwordx4 %4, %5 offset:2048" BANET_WIN_NT_ "\n\t"
+      "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep), "=&s"(keepx)
+      : "v"(v0), "v"(v1), "v"(v2), "s"(gbase), "s"(lds_dst), "s"(mask3)
+      : "memory");
 }
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -158,8 +183,11 @@ extern __shared__ __attribute__((aligned(16))) float sDynS[];
 constexpr int kSWaveLdsFloats = kWinFloats + kC128s;     // per wave: the rolling window + row statistics / sum|d|
 inline size_t strip_fp_lds_bytes(int pairs, int nch) { return ((size_t)pairs * kSWaveLdsFloats + (size_t)nch * 64 + 4) * sizeof(float); }
 
-template <int KV4, int NCH, bool FP>
+// OPT (development A/B, BANET_STRIP_OPT): bit 0 = both 16-byte pieces' window reads of a step issued before the first piece's
+// channel maths (the second LDS round trip hidden behind it); bit 1 = one M0 write per window row (glds_row)
+template <int KV4, int NCH, bool FP, int OPT = 0>
 __global__ __launch_bounds__(FP ? 512 : kSBlock, 2) __attribute__((amdgpu_num_vgpr(kStripVgprs / 2))) void ba_gather128s_kernel(const GatherArgs a) {
+  constexpr bool kPipe = (OPT & 1) != 0, kM0Row = (OPT & 2) != 0;
   constexpr int SEGH = 4 * NCH;          // pixel rows per segment
   constexpr int NH = (NCH + 3) / 4;      // groups of four chunks
   constexpr int CPG = NCH < 4 ? NCH : 4; // chunks per group (NCH = 2: 8-row segments for mid-size launches, one half-filled group)
@@ -216,6 +244,9 @@ __global__ __launch_bounds__(FP ? 512 : kSBlock, 2) __attribute__((amdgpu_num_vg
 
   for (int it = 0;; ++it) {
     int wi;
+#if defined(BANET_TIMING) && BANET_TIMING == 3
+    BANET_TICK(tb0);
+#endif
     if constexpr (FP) {     // wave 0 pops for the workgroup
       if (w == 0 && lane == 0) sItem[it & 1] = raw_next;
       __syncthreads();
@@ -232,6 +263,10 @@ __global__ __launch_bounds__(FP ? 512 : kSBlock, 2) __attribute__((amdgpu_num_vg
     BANET_TICK(ts0);
 #ifdef BANET_TIMING
     float ts_wait = 0.f;
+    [[maybe_unused]] float ts_issue = 0.f, ts_ldsA = 0.f, ts_mathA = 0.f, ts_ldsB = 0.f, ts_mathB = 0.f, ts_bar = 0.f;
+#if BANET_TIMING == 3
+    ts_bar = (float)(ts0 - tb0);     // the item barrier (FP) + the queue pop
+#endif
 #endif
     // ---- 1. depth of every pixel of the segment: D = D0 + b . W, chunk by chunk (once per window) ----------------------
     fvec4 Dv[NH];
@@ -249,7 +284,11 @@ __global__ __launch_bounds__(FP ? 512 : kSBlock, 2) __attribute__((amdgpu_num_vg
           const int ld = half * 32 + brev5s(RB * hb + i);
           const int jx = sx * kStripW + (ld >> 2), jy = sy * SEGH + 4 * c + (ld & 3);
           const bool vj = (jx < W) && (jy < H);
+#if defined(BANET_ABLATE_STRIP) && BANET_ABLATE_STRIP >= 2
+          const float* row = bas_b + (size_t)(vj ? (jy & 3) * W + (jx & 63) : 0) * K;
+#else
           const float* row = bas_b + (size_t)(vj ? jy * W + jx : 0) * K;
+#endif
 #pragma unroll
           for (int kc = 0; kc < KV4; ++kc) {
             const int k = kc * 128 + li * 4;
@@ -293,7 +332,14 @@ __global__ __launch_bounds__(FP ? 512 : kSBlock, 2) __attribute__((amdgpu_num_vg
           }
           sDep[c * 64 + lane] = D + pend[5];
         }
+#if defined(BANET_TIMING) && BANET_TIMING == 3
+        BANET_TICK(tb2);
+#endif
         __syncthreads();
+#if defined(BANET_TIMING) && BANET_TIMING == 3
+        BANET_TICK(tb3);
+        ts_bar += (float)(tb3 - tb2);
+#endif
 #pragma unroll
         for (int hh = 0; hh < NH; ++hh)
 #pragma unroll
@@ -385,6 +431,7 @@ __global__ __launch_bounds__(FP ? 512 : kSBlock, 2) __attribute__((amdgpu_num_vg
         }
       }
       // the plan (strip_plan.hpp): lane r < 32 owns pixel row r for the static part, the replay loop is scalar
+      [[maybe_unused]] unsigned long long mask3 = 0;   // lanes of the third LDS-DMA instruction of a row (kM0Row)
       int xl, ncol3, plan_ctl, plan_yf;       // the plan: StripStep.ctl / .yfirst of pixel row r on lane r (read with v_readlane)
       {
         StripRowStat st = sStat[lane & (SEGH - 1)];
@@ -409,6 +456,7 @@ __global__ __launch_bounds__(FP ? 512 : kSBlock, 2) __attribute__((amdgpu_num_vg
         // capacity, a unit-scale segment reads 19 or 20 of them -- the rest is not fetched.  At least one texel: the plan
         // counts kRowOps = 3 operations per row, and an instruction whose lanes are all off is branched around.
         ncol3 = 8 * max(rfl(xe) + 1 - 16, 1);
+        mask3 = ncol3 >= 64 ? ~0ull : ((1ull << ncol3) - 1ull);
         strip_plan_dynamic(env, SEGH, rfl(ye));
         if (lv.flags & (1 << 20)) {   // parity tests: every pixel row takes the direct (window-less) path
           if (step_mode(env.ctlv) == kStepWindow) env.ctlv = kStepDirect;
@@ -428,13 +476,25 @@ __global__ __launch_bounds__(FP ? 512 : kSBlock, 2) __attribute__((amdgpu_num_vg
         float absA[4] = {0.f, 0.f, 0.f, 0.f}, absB[4] = {0.f, 0.f, 0.f, 0.f};   // |d| of this lane's two channel pieces
         const float* tgt_s = tgt_b + 32 * s;
         // byte offset of pixel row r of this segment's source rows, slice s (the lane's pixel and piece are added per lane)
+#if defined(BANET_ABLATE_STRIP) && BANET_ABLATE_STRIP >= 2
+        auto src_soff = [&](int r) { return (unsigned)(((((sy * SEGH + r) & 3) * W + (sx & 3) * kStripW) * C + 32 * s) * 4); };
+#else
         auto src_soff = [&](int r) { return (unsigned)((((sy * SEGH + r) * W + sx * kStripW) * C + 32 * s) * 4); };
+#endif
         auto issue_row = [&](int Y, int slot) __attribute__((always_inline)) {     // texel row Y, columns xl .. xl + 20 -> ring slot Y mod 7
+#ifdef BANET_ABLATE_STRIP   // development: the same instruction stream on a cache-resident footprint (is the kernel paced by memory?)
+          const float* gb = tgt_s + ((size_t)(Y & 3) * W + (xl & 15)) * C;
+#else
           const float* gb = tgt_s + ((size_t)Y * W + xl) * C;
+#endif
           const unsigned dst = win_base + (unsigned)slot * (unsigned)kWinPitchB;
-          glds16(gb, dma_off, dst);
-          glds16(gb + 8 * C, dma_off, dst + 1024u);
-          if (lane < ncol3) glds16(gb + 16 * C, dma_off, dst + 2048u);
+          if constexpr (kM0Row) {
+            glds_row(gb, dma_off, dma_off + 3072u, dma_off + 6144u, dst, mask3);
+          } else {
+            glds16(gb, dma_off, dst);
+            glds16(gb + 8 * C, dma_off, dst + 1024u);
+            if (lane < ncol3) glds16(gb + 16 * C, dma_off, dst + 2048u);
+          }
         };
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the counted section starts with nothing in flight
         {
@@ -464,6 +524,9 @@ __global__ __launch_bounds__(FP ? 512 : kSBlock, 2) __attribute__((amdgpu_num_vg
             const int ctl = __builtin_amdgcn_readlane(plan_ctl, r);
             const int mode = step_mode(ctl);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the previous step's window reads are done (WAR)
+#if defined(BANET_TIMING) && BANET_TIMING >= 4
+            BANET_TICK(tq0);
+#endif
             if (step_src_next(ctl)) {
               src_issue<(k + 2) & 3, 0>(srcA_off, rs_src, src_soff(r + kSrcAhead));
               src_issue<(k + 2) & 3, 1>(srcB_off, rs_src, src_soff(r + kSrcAhead));
@@ -504,6 +567,30 @@ __global__ __launch_bounds__(FP ? 512 : kSBlock, 2) __attribute__((amdgpu_num_vg
               const float* l1 = l + m1i * kWinPitchF;
               const float* l2 = l + m2i * kWinPitchF;
               const float* l3 = l + m3i * kWinPitchF;
+#if defined(BANET_TIMING) && BANET_TIMING >= 4
+              BANET_TICK(tl0);                       // window mode, after the counted wait: address set-up + reads of piece A start here
+              [[maybe_unused]] unsigned long long tlm = tl0;
+              ts_issue += (float)(tl0 - tq0);        // step start -> here: source issue, parameter broadcast, row issue, counted wait
+#endif
+              if constexpr (kPipe) {
+                // both pieces' 12 window reads are in flight before the first piece's channel maths: the second LDS round trip
+                // (12 x 1 KB wave reads through a port shared by 8 waves) is hidden behind ~100 packed instructions
+                float4 tA[12], tB[12];
+                auto rd = [&](float4 (&t)[12], int po) __attribute__((always_inline)) {
+                  t[0] = *reinterpret_cast<const float4*>(l1 + po), t[1] = *reinterpret_cast<const float4*>(l1 + po + 32);
+                  t[2] = *reinterpret_cast<const float4*>(l1 + po + 64), t[3] = *reinterpret_cast<const float4*>(l1 + po + 96);
+                  t[4] = *reinterpret_cast<const float4*>(l2 + po), t[5] = *reinterpret_cast<const float4*>(l2 + po + 32);
+                  t[6] = *reinterpret_cast<const float4*>(l2 + po + 64), t[7] = *reinterpret_cast<const float4*>(l2 + po + 96);
+                  t[8] = *reinterpret_cast<const float4*>(l0 + po + 32), t[9] = *reinterpret_cast<const float4*>(l0 + po + 64);
+                  t[10] = *reinterpret_cast<const float4*>(l3 + po + 32), t[11] = *reinterpret_cast<const float4*>(l3 + po + 64);
+                };
+                rd(tA, 4 * jA);
+                rd(tB, 4 * jB);
+                __builtin_amdgcn_sched_barrier(0);
+                tap_math_s(fA, tA[0], tA[1], tA[2], tA[3], tA[4], tA[5], tA[6], tA[7], tA[8], tA[9], tA[10], tA[11], w00, w01, w10, w11, mk, qq, absA);
+                __builtin_amdgcn_sched_barrier(0);
+                tap_math_s(fB, tB[0], tB[1], tB[2], tB[3], tB[4], tB[5], tB[6], tB[7], tB[8], tB[9], tB[10], tB[11], w00, w01, w10, w11, mk, qq, absB);
+              } else {
 #pragma unroll
               for (int hp = 0; hp < 2; ++hp) {      // the lane's two 16-byte pieces of every tap
                 const int po = 4 * (hp ? jB : jA);
@@ -514,10 +601,22 @@ __global__ __launch_bounds__(FP ? 512 : kSBlock, 2) __attribute__((amdgpu_num_vg
                              b2 = *reinterpret_cast<const float4*>(l2 + po + 64), b3 = *reinterpret_cast<const float4*>(l2 + po + 96);
                 const float4 m1 = *reinterpret_cast<const float4*>(l0 + po + 32), m2 = *reinterpret_cast<const float4*>(l0 + po + 64);
                 const float4 p1 = *reinterpret_cast<const float4*>(l3 + po + 32), p2 = *reinterpret_cast<const float4*>(l3 + po + 64);
+#if defined(BANET_TIMING) && BANET_TIMING >= 4
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                BANET_TICK(tl1);
+                if (hp) ts_ldsB += (float)(tl1 - tlm); else ts_ldsA += (float)(tl1 - tl0);
+#endif
                 if (hp)
                   tap_math_s(f1, a0, a1, a2, a3, b0, b1, b2, b3, m1, m2, p1, p2, w00, w01, w10, w11, mk, qq, absB);
                 else
                   tap_math_s(f1, a0, a1, a2, a3, b0, b1, b2, b3, m1, m2, p1, p2, w00, w01, w10, w11, mk, qq, absA);
+#if defined(BANET_TIMING) && BANET_TIMING >= 4
+                asm volatile("" ::"v"(qq[0]), "v"(qq[4]) : "memory");
+                BANET_TICK(tl2);
+                if (hp) ts_mathB += (float)(tl2 - tl1); else ts_mathA += (float)(tl2 - tl1);
+                tlm = tl2;
+#endif
+              }
               }
             } else {   // kStepDirect: the footprint of this pixel row does not fit the window -- taps straight from memory
               const int x0 = fast ? (p0 & 0xfff) : 1, y0 = fast ? (p0 >> 12) & 0xfff : 1;
@@ -691,17 +790,45 @@ __global__ __launch_bounds__(FP ? 512 : kSBlock, 2) __attribute__((amdgpu_num_vg
 #if BANET_TIMING == 1
           part[28] = ts_wait;                  // parked in the counted waits (window rows / source features not landed)
           part[29] = (float)(ts3 - ts2);       // the four slice passes
+#elif BANET_TIMING == 3
+          part[28] = ts_bar;                   // FP: the two workgroup barriers of this segment (waiting for the other frames' waves)
+          part[29] = (float)(ts2 - ts0) - (ts_bar - (float)(ts0 - tb0));   // depth dot + geometry + plan without the barrier
+#elif BANET_TIMING == 4
+          part[28] = ts_issue;                 // per step: start -> after the counted wait (source issue, broadcast, row issue, wait)
+          part[29] = ts_ldsA + ts_ldsB;        // window reads: issue -> returned, both pieces
+#elif BANET_TIMING == 5
+          part[28] = ts_mathA + ts_mathB;      // channel maths of both pieces
+          part[29] = (float)(ts3 - ts2) - (ts_issue + ts_ldsA + ts_ldsB + ts_mathA + ts_mathB);   // rest of the slice passes (reductions, loop)
 #else
           part[28] = (float)(ts1 - ts0);       // depth dot
           part[29] = (float)(ts2 - ts1);       // geometry + plan
 #endif
+#if BANET_TIMING >= 4
+          part[30] = (float)(ts3 - ts2);       // the four slice passes
+#else
           part[30] = (float)(ts9 - ts3);       // rim, algebra, records, partial row
+#endif
+#if BANET_TIMING == 3
+          part[31] = (float)(ts9 - tb0);       // whole segment incl. the item barrier
+#else
           part[31] = (float)(ts9 - ts0);       // whole segment
+#endif
         }
       }
 #endif
     }  // pairs
   }  // items
+}
+
+// development A/B (builds with -DBANET_STRIP_OPT_VARIANTS only; measured neutral, profiles/r05_run2_*): BANET_STRIP_OPT selects the
+// OPT variant of the K <= 128, 16-row-segment kernels (read once)
+static int strip_opt() {
+  static const int v = [] {
+    const char* e = std::getenv("BANET_STRIP_OPT");
+    const int x = e ? std::atoi(e) : BANET_STRIP_OPT_DEFAULT;
+    return x >= 0 && x <= 3 ? x : 0;
+  }();
+  return v;
 }
 
 int launch_gather128s(const GatherArgs& a, int K, hipStream_t s) {
@@ -719,11 +846,25 @@ int launch_gather128s(const GatherArgs& a, int K, hipStream_t s) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                                    \
     hipLaunchKernelGGL((ba_gather128s_kernel<KV4, 4, true>), grid, block, shm, s, a);                                     \
   } while (0)
+#define BANET_LAUNCH_FPO(OPT)                                                                                             \
+  do {                                                                                                                    \
+    if (shm > 64 * 1024)                                                                                                  \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_gather128s_kernel<1, 4, true, OPT>),                    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                                    \
+    hipLaunchKernelGGL((ba_gather128s_kernel<1, 4, true, OPT>), grid, block, shm, s, a);                                  \
+  } while (0)
+    [[maybe_unused]] const int opt = strip_opt();
     if (K == 0) BANET_LAUNCH_FP(0);
+#ifdef BANET_STRIP_OPT_VARIANTS
+    else if ((K & 3) == 0 && K <= 128 && opt == 1) BANET_LAUNCH_FPO(1);
+    else if ((K & 3) == 0 && K <= 128 && opt == 2) BANET_LAUNCH_FPO(2);
+    else if ((K & 3) == 0 && K <= 128 && opt == 3) BANET_LAUNCH_FPO(3);
+#endif
     else if ((K & 3) == 0 && K <= 128) BANET_LAUNCH_FP(1);
     else if ((K & 3) == 0 && K <= 256) BANET_LAUNCH_FP(2);
     else return BANET_ERR_UNSUPPORTED;
 #undef BANET_LAUNCH_FP
+#undef BANET_LAUNCH_FPO
     return BANET_OK;
   }
 #define BANET_LAUNCH_S(KV4)                                                                     \
@@ -732,7 +873,13 @@ int launch_gather128s(const GatherArgs& a, int K, hipStream_t s) {
     else if (low) hipLaunchKernelGGL((ba_gather128s_kernel<KV4, 2, false>), grid, block, 0, s, a); \
     else hipLaunchKernelGGL((ba_gather128s_kernel<KV4, 4, false>), grid, block, 0, s, a);       \
   } while (0)
+  [[maybe_unused]] const int opt = strip_opt();
   if (K == 0) BANET_LAUNCH_S(0);
+#ifdef BANET_STRIP_OPT_VARIANTS
+  else if ((K & 3) == 0 && K <= 128 && !tall && !low && opt == 1) hipLaunchKernelGGL((ba_gather128s_kernel<1, 4, false, 1>), grid, block, 0, s, a);
+  else if ((K & 3) == 0 && K <= 128 && !tall && !low && opt == 2) hipLaunchKernelGGL((ba_gather128s_kernel<1, 4, false, 2>), grid, block, 0, s, a);
+  else if ((K & 3) == 0 && K <= 128 && !tall && !low && opt == 3) hipLaunchKernelGGL((ba_gather128s_kernel<1, 4, false, 3>), grid, block, 0, s, a);
+#endif
   else if ((K & 3) == 0 && K <= 128) BANET_LAUNCH_S(1);
   else if ((K & 3) == 0 && K <= 256) BANET_LAUNCH_S(2);
   else return BANET_ERR_UNSUPPORTED;

@@ -198,7 +198,7 @@ __device__ __noinline__ Q5 border_pixel_q5(int x0, int y0, float w00, float w01,
 #endif
 int launch_gather128(const GatherArgs& a, int K, hipStream_t s);
 int launch_gather128p(const GatherArgs& a, int K, hipStream_t s);   // gather128p.hip: wave-private LDS patches
-int launch_gather128s(const GatherArgs& a, int K, hipStream_t s);
-int launch_gather128q(const GatherArgs& a, int K, hipStream_t s);   // gather128q.hip: 4x4-pixel items, one step per item (latency-bound launches)   // gather128s.hip: strip segments, rolling LDS window
+int launch_gather128s(const GatherArgs& a, int K, hipStream_t s);   // gather128s.hip: strip segments, rolling LDS window
+int launch_gather128q(const GatherArgs& a, int K, hipStream_t s);   // gather128q.hip: 4x4-pixel items, one step per item (latency-bound launches)
 
 }  // namespace banet

@@ -39,6 +39,32 @@ __device__ __forceinline__ void tap_math_s(const float4& f1, const float4& a0, c
                                            const float4& p2, float w00, float w01, float w10, float w11, float mk,
                                            float (&q)[5], float (&absd)[4]) {
   const float h00 = 0.5f * w00, h01 = 0.5f * w01, h10 = 0.5f * w10, h11 = 0.5f * w11;
+#ifdef BANET_TAP_SCALAR   // development A/B (build with -fno-slp-vectorize): the same arithmetic, same order, one channel per instruction
+  {
+    const float F1[4] = {f1.x, f1.y, f1.z, f1.w}, A0[4] = {a0.x, a0.y, a0.z, a0.w}, A1[4] = {a1.x, a1.y, a1.z, a1.w},
+                A2[4] = {a2.x, a2.y, a2.z, a2.w}, A3[4] = {a3.x, a3.y, a3.z, a3.w}, B0[4] = {b0.x, b0.y, b0.z, b0.w},
+                B1[4] = {b1.x, b1.y, b1.z, b1.w}, B2[4] = {b2.x, b2.y, b2.z, b2.w}, B3[4] = {b3.x, b3.y, b3.z, b3.w},
+                M1[4] = {m1.x, m1.y, m1.z, m1.w}, M2[4] = {m2.x, m2.y, m2.z, m2.w}, P1[4] = {p1.x, p1.y, p1.z, p1.w},
+                P2[4] = {p2.x, p2.y, p2.z, p2.w};
+    float s11[4], s12[4], s22[4], sg1[4], sg2[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float f = ((A1[c] * w00 + A2[c] * w01) + B1[c] * w10) + B2[c] * w11;
+      const float gx = (((A2[c] - A0[c]) * h00 + (A3[c] - A1[c]) * h01) + (B2[c] - B0[c]) * h10) + (B3[c] - B1[c]) * h11;
+      const float gy = (((B1[c] - M1[c]) * h00 + (B2[c] - M2[c]) * h01) + (P1[c] - A1[c]) * h10) + (P2[c] - A2[c]) * h11;
+      const float d = f - F1[c] * mk;
+      s11[c] = gx * gx, s12[c] = gx * gy, s22[c] = gy * gy, sg1[c] = gx * d, sg2[c] = gy * d;
+      absd[c] += fabsf(d);
+    }
+    // the packed form's order: lanes {x, z} and {y, w} accumulate separately, then x + y
+    q[0] += (s11[0] + s11[2]) + (s11[1] + s11[3]);
+    q[1] += (s12[0] + s12[2]) + (s12[1] + s12[3]);
+    q[2] += (s22[0] + s22[2]) + (s22[1] + s22[3]);
+    q[3] += (sg1[0] + sg1[2]) + (sg1[1] + sg1[3]);
+    q[4] += (sg2[0] + sg2[2]) + (sg2[1] + sg2[3]);
+    return;
+  }
+#endif
   v2fs qm11 = {0.f, 0.f}, qm12 = {0.f, 0.f}, qm22 = {0.f, 0.f}, qg1 = {0.f, 0.f}, qg2 = {0.f, 0.f};
 #define BANET_V2S(v, k) (v2fs){(k) ? (v).z : (v).x, (k) ? (v).w : (v).y}
 #pragma unroll

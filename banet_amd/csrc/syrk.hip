@@ -665,7 +665,10 @@ __global__ __launch_bounds__(kBlock, 1) void ba_syrk_bf16x6_kernel(const SyrkArg
         split8_bf16x3(vv, op[4 * h + e]);
         if constexpr (T0 == 1) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) cmx[4 * h + e] = fmaxf(cmx[4 * h + e], fabsf(pb[i][h][e]));   // (rows past N repeat row 0)
+          for (int i = 0; i < 8; ++i) {   // (rows past N repeat row 0)  NaN-sticky like ba_colmax_kernel (fmaxf would drop a NaN and the
+            const float av = fabsf(pb[i][h][e]);   // not-finite fallback of the fp16 form would then depend on who computed the maxima)
+            cmx[4 * h + e] = (av > cmx[4 * h + e] || av != av) ? av : cmx[4 * h + e];
+          }
         }
       }
     issue(st + 1);                                          // the raw registers are free again
@@ -708,10 +711,10 @@ __global__ __launch_bounds__(kBlock, 1) void ba_syrk_bf16x6_kernel(const SyrkArg
     unsigned* cm = reinterpret_cast<unsigned*>(const_cast<float*>(a.colmax)) + (size_t)b * K;     // (non-negative floats order like
 #pragma unroll                                                                                   //  unsigned integers; zeroed before)
     for (int c = 0; c < 4 * KH; ++c) {
-      float v = cmx[c];
-      v = fmaxf(v, __shfl_xor(v, 16, 64));
-      v = fmaxf(v, __shfl_xor(v, 32, 64));
-      if (kq == 0 && s1 > s0) atomicMax(&cm[64 * (c >> 2) + 4 * m + (c & 3)], __float_as_uint(v));
+      unsigned v = __float_as_uint(cmx[c]);      // as bit patterns: |x| orders like an unsigned integer and a NaN stays the maximum
+      v = max(v, (unsigned)__shfl_xor((int)v, 16, 64));
+      v = max(v, (unsigned)__shfl_xor((int)v, 32, 64));
+      if (kq == 0 && s1 > s0) atomicMax(&cm[64 * (c >> 2) + 4 * m + (c & 3)], v);
     }
   }
   // ---- epilogue (as ba_syrk_direct_kernel) ------------------------------------------------------
@@ -1064,6 +1067,9 @@ int launch_syrk(const float* basis, const float* rec, int B, int N, int K, int p
   if (pl.direct == 3) {
     const float* colmax_w = nullptr;
     float* recmax_w = nullptr;
+    // The wide jobs differ from ba_syrk_bf16x6_kernel in ONE respect of the f16_stats contract (kernels.hpp): they have no variant that
+    // harvests the column maxima in-kernel, so f16_stats = 2 ("first iteration of a level") runs ba_colmax_kernel as a pass of its own
+    // and the fp16 form already on that iteration; 0 does the same for a one-iteration call, 1 = maxima in place.
     if (pl.f16 && f16_stats >= 0) {      // the job kernels' fp16 two-piece form: column maxima by their own pass at the level's first call
       unsigned* cm = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(partials) + pl.off_colmax);
       recmax_w = reinterpret_cast<float*>(reinterpret_cast<char*>(partials) + pl.off_recmax);

@@ -179,7 +179,16 @@ class _SmallStepGraph:
 
 
 _small_cache = {}          # shape key -> _SmallStepGraph (static buffers + a private graph memory pool each): bounded, see _small_step
-_SMALL_CACHE_MAX = int(os.environ.get("BANET_SMALL_STEP_CACHE", "32"))   # >= levels x configurations in flight (5 levels x 2 configs = 10)
+def _cache_limit():
+    """BANET_SMALL_STEP_CACHE: at least 1 (0 / negative / non-integer values fall back to the default instead of breaking the eviction loop)"""
+    try:
+        return max(1, int(os.environ.get("BANET_SMALL_STEP_CACHE", "32")))
+    except ValueError:
+        return 32
+
+
+_SMALL_CACHE_MAX = _cache_limit()   # >= levels x configurations in flight (5 levels x 2 configs = 10)
+_evict_warned = False
 
 
 def clear_small_step_cache():
@@ -202,8 +211,12 @@ def _small_step(tensors, N, l2_base, pairs=1, camera=False):
         while len(_small_cache) >= _SMALL_CACHE_MAX:          # least recently used first (dicts keep insertion order)
             old = next(iter(_small_cache))
             _small_cache.pop(old)
-            warnings.warn("banet_amd.dense_train: small-step graph cache full (%d entries): evicting %s; the next use of that shape "
-                          "re-captures its graph (raise BANET_SMALL_STEP_CACHE)" % (_SMALL_CACHE_MAX, old[0][0]), RuntimeWarning)
+            global _evict_warned
+            if not _evict_warned:                              # once per process: multi-resolution training would repeat it every step
+                _evict_warned = True
+                warnings.warn("banet_amd.dense_train: small-step graph cache full (%d entries): evicting %s; the next use of that "
+                              "shape re-captures its graph (raise BANET_SMALL_STEP_CACHE; further evictions are silent)"
+                              % (_SMALL_CACHE_MAX, old[0][0]), RuntimeWarning)
     _small_cache[key] = st
     return st(tensors)
 

@@ -313,6 +313,38 @@ def test_bench_compact_line_stays_under_4_kb(tmp_path, capsys, monkeypatch):
     assert len(bench.compact_record(full)) < 4096
 
 
+def test_bench_compact_line_of_an_8_rank_run(tmp_path, capsys, monkeypatch):
+    """The N-rank line the driver's scaling run parses (bench.py --gpus 8 under torch.distributed.run): < 4 KB, carries
+    config.world_size / backend / parallelism, and -- round 5 -- the parity numbers per group (everything the damping conditions vs
+    the undamped last coefficient with its float32 yardstick) and the SYRK's arithmetic form per level.  Stubbed from a real
+    record (profiles/r04_run12_bench_detail.json) with the round-5 fields filled in the way bench.py fills them."""
+    import json
+    sys.path.insert(0, ROOT) if ROOT not in sys.path else None
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_run12_bench_detail.json")))
+    full["n_gpus"] = 8
+    full["config"].update(world_size=8, backend="nccl", parallelism="dp8: 32 windows per GPU, contiguous shards, one all-gather per solve",
+                          windows_total=256)
+    full["parity"].update(max_pose_depth=3.9e-5, max_last=8.1e-5, max_last_ref32=2.4e-2)
+    full["roofline"]["syrk_form"] = "40x30:b16x3 80x60:b16x3 160x120:b16x3 320x240:f16x2 640x480:f16x2"
+    for rec in full["sweep"].values():
+        if "parity" in rec:
+            rec["parity"].update(max_pose_depth=1.8e-6, max_last=2.579e-3, max_last_ref32=1.728e-3)
+    monkeypatch.setenv("BANET_BENCH_DETAIL_DIR", str(tmp_path))
+    bench.emit(full)
+    last = capsys.readouterr().out.strip().split("\n")[-1]
+    assert len(last) < 4096, len(last)
+    rec = json.loads(last)
+    assert rec["n_gpus"] == 8 and rec["config"]["world_size"] == 8 and rec["config"]["backend"] == "nccl"
+    assert "dp8" in rec["config"]["parallelism"] and rec["scaling"] == "weak"
+    assert rec["parity"]["max_pose_depth"] == 3.9e-5 and rec["parity"]["max_last"] == 8.1e-5 and rec["parity"]["ok"] is True
+    assert rec["roofline"]["syrk_form"].endswith("640x480:f16x2")
+    for name, e in rec["sweep"].items():
+        if "parity" in e:                          # [lambda / pose / damped depth, last coefficient, its float32 yardstick]
+            assert e["parity"] == [1.8e-6, 2.579e-3, 1.728e-3], name
+            assert e["parity"][0] <= 1e-4 and e["parity"][1] <= max(1e-4, 2 * e["parity"][2])
+
+
 def test_strip_gather_register_contract():
     """ba_gather128s_kernel reserves v224..v255 behind the compiler's back (amdgpu_num_vgpr + inline asm naming them): the
     compiler-emitted instructions of every instantiation must not touch them and the default variants must not spill

@@ -42,9 +42,12 @@ def relerr(got, want):
     return float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-30))
 
 
-def _window_level_check(B, H, W, C, K, pairs, seed, tol_step=1e-4, flags=0, expect_sel=None):
+def _window_level_check(B, H, W, C, K, pairs, seed, tol_step=1e-4, flags=0, expect_sel=None, last_yardstick=False):
     """one full-resolution level of B multi-frame windows: assembly and one LM update vs the float64 twin.
-    flags: banet_level_t.flags for the level (forces a kernel selection); expect_sel: the (gather, SYRK) selection asserted"""
+    flags: banet_level_t.flags for the level (forces a kernel selection); expect_sel: the (gather, SYRK) selection asserted;
+    last_yardstick: the undamped last depth coefficient (bundlenet.py:266: `[diag[:-1] + 1e-5, 0] * lambda`) is the quotient of two
+    cancelling sums once the other coefficients have converged -- gate it like bench.py does, at max(tol_step, 2 x what the SAME
+    statements lose in float32 at this state) instead of tol_step alone (the yardstick is printed)"""
     from banet_amd import dense as bdense, ops, synth as bsynth
     from banet_amd.bundlenet import he_normal_lambda_weights
     torch.manual_seed(seed)
@@ -79,8 +82,16 @@ def _window_level_check(B, H, W, C, K, pairs, seed, tol_step=1e-4, flags=0, expe
         o = 6 * pairs
         e_lam = relerr(n(st.lambda_out[b:b + 1]), n(d["lam"]))
         e_pose, e_depth, e_last = relerr(dl[:o], sol[:o]), relerr(dl[o:-1], sol[o:-1]), relerr(dl[-1:], sol[-1:])
+        tol_last = tol_step
+        if last_yardstick:
+            *_, d32 = torch_port.window_iteration(intr[sl], lv.scale, lv.src[sl], lv.tgt[sl], lv.depth[sl], lv.basis[sl], R[sl], T[sl],
+                                                  Wc[sl], [(n(w), n(bb)) for w, bb in mlps[0]], 1000.0, dtype=torch.float32)
+            ref32_last = relerr(n(d32["solution"][0])[-1:], sol[-1:])
+            tol_last = max(tol_step, 2.0 * ref32_last)
+            del d32
+            out.append(("float32 twin's own error on the last coefficient", ref32_last))
         out.append((eA, eb, e_lam, e_pose, e_depth, e_last))
-        assert e_lam < 1e-4 and e_pose < tol_step and e_depth < tol_step and e_last < tol_step, (b, out[-1])
+        assert e_lam < 1e-4 and e_pose < tol_step and e_depth < tol_step and e_last < tol_last, (b, out[-2:])
         assert relerr(n(st.R[b]), n(R2[0])) < 1e-5 and relerr(n(st.T[b]), n(T2[0])) < 1e-4 and relerr(n(st.Wc[b]), n(W2[0])) < 1e-4
         del d, R2, T2, W2
         torch.cuda.empty_cache()

@@ -9,7 +9,7 @@ This compiles gather128s.hip to gfx950 assembly and asserts, for every ba_gather
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NO_SPILL = ("ILi0ELi4ELb0E", "ILi1ELi4ELb0E", "ILi0ELi2ELb0E", "ILi1ELi2ELb0E", "ILi0ELi4ELb1E")     # <KV4, NCH, FP> manglings
+NO_SPILL = ("ILi0ELi4ELb0ELi0E", "ILi1ELi4ELb0ELi0E", "ILi0ELi2ELb0ELi0E", "ILi1ELi2ELb0ELi0E", "ILi0ELi4ELb1ELi0E")     # <KV4, NCH, FP, OPT = 0> manglings
 
 
 def main():
