@@ -227,10 +227,12 @@ class BundleNet:
         # backward); False = the reference's registered gradient verbatim (inexact: matrix_solve's
         # gradient w.r.t. AtA is not symmetric, utils.cu:648-657 assumes it is)
         self.exact_gradients = True
-        # training graph: "lean" = C-wide statements as one HIP op with a HIP adjoint, normal equations by block (no
-        # samp / diff / grad / J tensors; always exact gradients); "reference" = the reference's statements one by one
-        # with the EquationConstruction op and its registered gradient
-        self.training_graph = "lean"
+        # training graph: "fused" (round 5, the default) = the whole iteration as ONE autograd node on the fused kernels -- forward
+        # = the inference path (gather + SYRK + solve), backward = the small step by implicit differentiation + the fused adjoint
+        # of the assembly on the sparse layout (dense_train._SparseIteration); "lean" = C-wide statements as one HIP op with a HIP
+        # adjoint, normal equations by block in torch (no samp / diff / grad / J tensors); both always exact gradients;
+        # "reference" = the reference's statements one by one with the EquationConstruction op and its registered gradient
+        self.training_graph = "fused"
 
     # -- small helpers kept for API parity --------------------------------------------
     def grad_fixed(self, input, name=None):
@@ -299,7 +301,21 @@ class BundleNet:
         return tuple(t for pair in lw for t in pair if torch.is_tensor(t)) if lw else ()
 
     def _training_iteration(self, *args):
-        if self.training_graph == "lean" and self.exact_gradients:
+        if self.training_graph == "fused" and self.exact_gradients:
+            conv1, conv2, fx, fy, ox, oy, p, D, B, R, T, W, l2, level = args
+            from . import dense_train
+            data_grad = any(torch.is_tensor(x) and x.requires_grad for x in (fx, fy, ox, oy, p))     # (data in the reference: no gradient path)
+            if not data_grad and dense_train.sparse_iteration_supported(conv1, conv2, B):
+                lw = self.lambda_weights[str(level)]
+                layers = [(w if torch.is_tensor(w) else torch.as_tensor(w), b if torch.is_tensor(b) else torch.as_tensor(b)) for w, b in lw]
+                layers = [(w.to(conv1.device), b.to(conv1.device)) for w, b in layers]
+                bundle = B is not None
+                l2v = (1.0 if l2 is None else float(l2)) if bundle else 1.0            # CameraIteration ignores the argument (:122-191)
+                R2, T2, W2 = dense_train.sparse_iteration("bundle" if bundle else "bundle_camera", self._mlp(level, conv1.device), l2v,
+                                                          conv1, conv2, D, B, R, T, W, fx, fy, ox, oy, p, layers)
+                return R2, T2, W2
+            return self._iteration_autograd_lean(*args)
+        if self.training_graph in ("lean", "fused") and self.exact_gradients:
             return self._iteration_autograd_lean(*args)
         return self._iteration_autograd(*args)
 

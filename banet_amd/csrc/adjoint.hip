@@ -391,13 +391,17 @@ __device__ __forceinline__ float wsum(float v) {
   return (a0 + a1) + (a2 + a3);
 }
 
-template <int CJ, int KJ>   // C <= 64 CJ, K <= 64 KJ (K > 128: 2 waves per SIMD -- the per-coefficient state would spill at 3)
+// SP (round 5): SPARSE points in the reference's own layout -- what bundlenet.py:332-399 trains on: conv1 [B,N,C] sampled at N points,
+// rays p [B,3,N] and per-point level intrinsics supplied (bundlenet.py:115-119), the target map precomputed as [f|gx|gy]
+// [B,H,W,3C] (bundlenet.py:92-100) and sampled with plain bilinear taps, clamped one by one like the forward's generic kernel
+// (gather.hip, GRAD = true).  Same per-pixel algebra; dmap3 is then the gradient of that 3C map itself.
+template <int CJ, int KJ, bool SP = false>   // C <= 64 CJ, K <= 64 KJ (K > 128: 2 waves per SIMD -- the per-coefficient state would spill at 3)
 __global__ __launch_bounds__(kBlock, (KJ >= 3 ? 2 : 3)) void adj_pixel_kernel(const AdjArgs a) {
   const banet_level_t& lv = a.lv;
   const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x & 63, w = wave_id();
   const int N = lv.N, C = lv.C, K = lv.K, H = lv.H, W = lv.W, P = 6 + K;
   const float* __restrict__ src_b = lv.src + (size_t)b * N * C;
-  const float* __restrict__ tgt_b = lv.tgt + (size_t)b * N * C;
+  const float* __restrict__ tgt_b = lv.tgt + (size_t)b * H * W * (SP ? 3 * C : C);
   const float* __restrict__ bas_b = lv.basis + (size_t)b * N * K;
   const float* __restrict__ S = a.S + (size_t)b * P * P;
   const float* __restrict__ gb = a.gb + (size_t)b * P;
@@ -412,8 +416,9 @@ __global__ __launch_bounds__(kBlock, (KJ >= 3 ? 2 : 3)) void adj_pixel_kernel(co
   for (int i = 0; i < 9; ++i) Rm[i] = a.R[b * 9 + i];
 #pragma unroll
   for (int i = 0; i < 3; ++i) Tv[i] = a.T[b * 3 + i];
-  const float fx0 = lv.intr[b * 4 + 0], fy0 = lv.intr[b * 4 + 1], ox0 = lv.intr[b * 4 + 2], oy0 = lv.intr[b * 4 + 3];
-  const float fx = fx0 / lv.scale, fy = fy0 / lv.scale, ox = ox0 / lv.scale, oy = oy0 / lv.scale;
+  float fx0 = 1.f, fy0 = 1.f, ox0 = 0.f, oy0 = 0.f;
+  if constexpr (!SP) fx0 = lv.intr[b * 4 + 0], fy0 = lv.intr[b * 4 + 1], ox0 = lv.intr[b * 4 + 2], oy0 = lv.intr[b * 4 + 3];
+  float fx = fx0 / lv.scale, fy = fy0 / lv.scale, ox = ox0 / lv.scale, oy = oy0 / lv.scale;     // SP: per point, below
   float wc[KJ], scd[KJ][6], gbd[KJ], dwc[KJ];
   bool kok[KJ], cok[CJ];
 #pragma unroll
@@ -443,13 +448,20 @@ __global__ __launch_bounds__(kBlock, (KJ >= 3 ? 2 : 3)) void adj_pixel_kernel(co
   const int n_lo = (g * kNumWaves + w) * chunk, n_hi = min(N, n_lo + chunk);
   for (int n = n_lo; n < n_hi; ++n) {
     // ---- depth and warp (bundlenet.py:206-224), every lane the same values
-    const int qy = n / W, qx = n - qy * W;
-    float p0 = ((float)qx * lv.scale - ox0) / fx0, p1 = ((float)qy * lv.scale - oy0) / fy0, p2 = 1.f;
-    if (lv.normalize_rays) {
-      const float inv = 1.f / sqrtf(fmaxf(p0 * p0 + p1 * p1 + p2 * p2, 1e-12f));
-      p0 *= inv;
-      p1 *= inv;
-      p2 *= inv;
+    float p0, p1, p2;
+    if constexpr (SP) {
+      const size_t o = (size_t)b * 3 * N, qn = (size_t)b * N + n;
+      p0 = lv.rays[o + n], p1 = lv.rays[o + N + n], p2 = lv.rays[o + 2 * (size_t)N + n];
+      fx = lv.fx[qn], fy = lv.fy[qn], ox = lv.ox[qn], oy = lv.oy[qn];
+    } else {
+      const int qy = n / W, qx = n - qy * W;
+      p0 = ((float)qx * lv.scale - ox0) / fx0, p1 = ((float)qy * lv.scale - oy0) / fy0, p2 = 1.f;
+      if (lv.normalize_rays) {
+        const float inv = 1.f / sqrtf(fmaxf(p0 * p0 + p1 * p1 + p2 * p2, 1e-12f));
+        p0 *= inv;
+        p1 *= inv;
+        p2 *= inv;
+      }
     }
     float bv[KJ], z2v[KJ], f1v[CJ], bsum = 0.f;
 #pragma unroll
@@ -494,7 +506,18 @@ __global__ __launch_bounds__(kBlock, (KJ >= 3 ? 2 : 3)) void adj_pixel_kernel(co
     const float ax = px - xf, ay = py - yf;
     // ---- the 4x4 neighbourhood (minus corners) of the target map, clamped to the image: 12 coalesced row loads per
     // channel chunk; [f|gx|gy] at the 4 bilinear taps from it (grad_fixed on the fly, REFLECT rim -> 0, outside -> 0)
-    float tex[CJ][4][4];
+    float tex[CJ][4][4];       // SP: tex[j][t][e] = channel e (f, gx, gy) of the 3C map at bilinear tap t, taps clamped one by one
+    if constexpr (SP) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int yy = min(max(y0 + (t >> 1), 0), H - 1), xx = min(max(x0 + (t & 1), 0), W - 1);
+        const float* __restrict__ row = tgt_b + (size_t)(yy * W + xx) * 3 * C;
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+#pragma unroll
+          for (int j = 0; j < CJ; ++j) tex[j][t][e] = row[e * C + (cok[j] ? lane + 64 * j : 0)];
+      }
+    } else {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -505,6 +528,7 @@ __global__ __launch_bounds__(kBlock, (KJ >= 3 ? 2 : 3)) void adj_pixel_kernel(co
 #pragma unroll
         for (int j = 0; j < CJ; ++j) tex[j][r][cc] = row[cok[j] ? lane + 64 * j : 0];
       }
+    }
     float Sf[CJ], Sgx[CJ], Sgy[CJ], Ax[CJ][3], Ay[CJ][3], dif[CJ];
 #pragma unroll
     for (int j = 0; j < CJ; ++j) {
@@ -523,9 +547,9 @@ __global__ __launch_bounds__(kBlock, (KJ >= 3 ? 2 : 3)) void adj_pixel_kernel(co
       const float wt = wx * wy, sx = (ix ? 1.f : -1.f) * wy, sy = (iy ? 1.f : -1.f) * wx;
 #pragma unroll
       for (int j = 0; j < CJ; ++j) {
-        const float F = fin * tex[j][1 + iy][1 + ix];
-        const float GX = hx * (tex[j][1 + iy][2 + ix] - tex[j][1 + iy][ix]);
-        const float GY = hy * (tex[j][2 + iy][1 + ix] - tex[j][iy][1 + ix]);
+        const float F = SP ? tex[j][t][0] : fin * tex[j][1 + iy][1 + ix];
+        const float GX = SP ? tex[j][t][1] : hx * (tex[j][1 + iy][2 + ix] - tex[j][1 + iy][ix]);
+        const float GY = SP ? tex[j][t][2] : hy * (tex[j][2 + iy][1 + ix] - tex[j][iy][1 + ix]);
         Sf[j] = fmaf(wt, F, Sf[j]);
         Sgx[j] = fmaf(wt, GX, Sgx[j]);
         Sgy[j] = fmaf(wt, GY, Sgy[j]);
@@ -1493,16 +1517,18 @@ struct AdjPlan {
 bool adj_supported(const banet_level_t* lv) {
   const bool var_ok = (lv->variant == BANET_BUNDLE && lv->K >= 1 && lv->K <= 64 * kAdjMaxKJ) ||
                       (lv->variant == BANET_BUNDLE_CAMERA && lv->K == 0);     // pose only: bundlenet.py:122-191, depth fixed
-  return var_ok && lv->dense == 1 && lv->tgt_has_grad == 0 && lv->pairs <= 1 && lv->C >= 1 && lv->C <= 64 * kAdjMaxCJ &&
-         lv->N == lv->H * lv->W;
+  const bool dense_ok = lv->dense == 1 && lv->tgt_has_grad == 0 && lv->N == lv->H * lv->W;
+  // round 5: sparse points in the reference's layout (conv1 [B,N,C], rays + per-point intrinsics, [f|gx|gy] target map)
+  const bool sparse_ok = lv->dense == 0 && lv->tgt_has_grad == 1 && lv->rays && lv->fx && lv->fy && lv->ox && lv->oy && lv->H >= 2 && lv->W >= 2;
+  return var_ok && (dense_ok || sparse_ok) && lv->pairs <= 1 && lv->C >= 1 && lv->C <= 64 * kAdjMaxCJ && lv->N >= 1;
 }
 
 void adj_plan(const banet_level_t* lv, AdjPlan* pl) {
-  const size_t B = lv->B, N = lv->N, C = lv->C, K = lv->K, P = 6 + K;
+  const size_t B = lv->B, N = lv->N, C = lv->C, K = lv->K, P = 6 + K, HW = (size_t)lv->H * lv->W;   // (dense: HW == N)
   const int per = (int)((2048 + B - 1) / B);                         // ~8 waves per CU over the whole chip
   pl->G = (int)std::max<size_t>(1, std::min<size_t>((N + 63) / 64, (size_t)(per + kNumWaves - 1) / kNumWaves));
   pl->Ga = (int)std::max<size_t>(1, std::min<size_t>((N + 63) / 64, (size_t)((512 + B - 1) / B)));
-  pl->Gm = (int)std::max<size_t>(1, std::min<size_t>((N + 3) / 4, (size_t)((4096 + B - 1) / B)));
+  pl->Gm = (int)std::max<size_t>(1, std::min<size_t>((HW + 3) / 4, (size_t)((4096 + B - 1) / B)));
   size_t o = 0;
   auto take = [&](size_t bytes) {
     const size_t at = o;
@@ -1514,12 +1540,12 @@ void adj_plan(const banet_level_t* lv, AdjPlan* pl) {
   pl->off_arec = take(B * N * 8 * 4);
   pl->off_arow = take(B * N * 3 * C * 4);
   pl->off_frac = take(B * N * 4 * 4);
-  pl->off_cnt = take(B * N * 4);
-  pl->off_start = take(B * N * 8);
-  pl->off_cursor = take(B * N * 4);
+  pl->off_cnt = take(B * HW * 4);
+  pl->off_start = take(B * HW * 8);
+  pl->off_cursor = take(B * HW * 4);
   pl->off_list = take(B * N * 4);
   pl->off_part = take(B * (size_t)pl->G * kNumWaves * (kAdjHdr + K) * 4);
-  pl->off_chunks = take(B * ((N + 1023) / 1024) * 4);
+  pl->off_chunks = take(B * ((HW + 1023) / 1024) * 4);
   pl->bytes = o;
 }
 
@@ -1617,7 +1643,26 @@ int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T
       break;
     default: return BANET_ERR_UNSUPPORTED;
   }
-  if ((lv->C & 3) == 0 && (K & 3) == 0 && lv->C <= 128 && K <= 128 && !(lv->flags & (1 << 27))) {   // bit 27: one pixel per wave (A/B)
+  if (!lv->dense) {   // sparse points, [f|gx|gy] target map: one point per wave
+    const int CJ = (lv->C + 63) / 64, KJ = std::max(1, (K + 63) / 64);
+    const dim3 grid(pl.G, B), block(kBlock);
+#define BANET_ADJ_POINT(cj, kj) \
+  if (CJ == cj && KJ == kj) hipLaunchKernelGGL((adj_pixel_kernel<cj, kj, true>), grid, block, 0, s, a)
+    BANET_ADJ_POINT(1, 1);
+    BANET_ADJ_POINT(2, 1);
+    BANET_ADJ_POINT(3, 1);
+    BANET_ADJ_POINT(4, 1);
+    BANET_ADJ_POINT(1, 2);
+    BANET_ADJ_POINT(2, 2);
+    BANET_ADJ_POINT(3, 2);
+    BANET_ADJ_POINT(4, 2);
+    BANET_ADJ_POINT(1, 3);
+    BANET_ADJ_POINT(2, 3);
+    BANET_ADJ_POINT(1, 4);
+    BANET_ADJ_POINT(2, 4);
+#undef BANET_ADJ_POINT
+    if (CJ > 2 && KJ > 2) return BANET_ERR_UNSUPPORTED;   // (C > 128 with K > 128: not compiled for the sparse layout)
+  } else if ((lv->C & 3) == 0 && (K & 3) == 0 && lv->C <= 128 && K <= 128 && !(lv->flags & (1 << 27))) {   // bit 27: one pixel per wave (A/B)
     hipLaunchKernelGGL((adj_pixel2_kernel<1>), dim3(pl.G, B), dim3(kBlock), 0, s, a);   // (C = 256: 264 B of spills -> the one-pixel kernel)
   } else {
     const int CJ = (lv->C + 63) / 64, KJ = std::max(1, (K + 63) / 64);

@@ -390,7 +390,8 @@ int banet_dense_adjoint_ex_f32(const banet_level_t* lv, const float* R, const fl
                                float* dpose, int flags, void* ws, size_t ws_bytes, banet_stream_t stream) {
   if (!lv || !R || !T || !gAtA || !gAtb || !gabs || !dsrc || !dmap3 || !ddepth || !dpose || !ws) return BANET_ERR_INVALID_ARG;
   if (lv->K > 0 && (!Wc || !dbasis || !lv->basis)) return BANET_ERR_INVALID_ARG;     // K = 0 (pose only): no coefficient / basis tensors
-  if (lv->B <= 0 || lv->N <= 0 || !lv->src || !lv->tgt || !lv->depth || !lv->intr) return BANET_ERR_INVALID_ARG;
+  if (lv->B <= 0 || lv->N <= 0 || !lv->src || !lv->tgt || !lv->depth) return BANET_ERR_INVALID_ARG;
+  if (lv->dense ? !lv->intr : (!lv->rays || !lv->fx || !lv->fy || !lv->ox || !lv->oy)) return BANET_ERR_INVALID_ARG;
   if (flags & ~(BANET_ADJOINT_OVERWRITE | BANET_ADJOINT_OVERWRITE_MAP)) return BANET_ERR_INVALID_ARG;
   const size_t need = dense_adjoint_workspace_bytes(lv);
   if (need == 0) return BANET_ERR_UNSUPPORTED;

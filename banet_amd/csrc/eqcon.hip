@@ -328,7 +328,7 @@ static int eq_nb(int P) {
   if (nb <= 5) return 5;
   if (nb <= 9) return 9;
   if (nb <= 17) return 17;
-  if (nb <= 19) return 19;   // 272 < P <= 304 (cfg-5's 8-frame windows: P = 298): the LDS-tiled kernel below, no SYRK-engine job set
+  if (nb <= 19) return 19;   // 272 < P <= 304 (cfg-5's 8-frame windows: P = 298): eqcon_syrk.hip's 17-block pass + three jobs for blocks 17, 18
   return -1;
 }
 
@@ -344,7 +344,7 @@ int plan_eq(int B, int N, int C, int P, EqPlan* pl) {
   // P <= 144: the SYRK formulation (eqcon_syrk.hip), one workgroup per CU, >= 1 step of 16 pixels per wave
   // (environment BANET_EQ_LDS_KERNEL=1 keeps the LDS-operand kernel: development A/B only)
   static const bool force_lds = getenv("BANET_EQ_LDS_KERNEL") != nullptr && atoi(getenv("BANET_EQ_LDS_KERNEL")) != 0;
-  pl->fast = (pl->nb <= 17 && !force_lds) ? 1 : 0;
+  pl->fast = (pl->nb <= 19 && !force_lds) ? 1 : 0;
   if (pl->fast) {
     G = (256 + B - 1) / B;
     const int steps = (N + 15) / 16;

@@ -535,6 +535,21 @@ int launch_eq_syrk(const float* J, const float* G, const float* d, int B, int N,
       hipLaunchKernelGGL((eq_syrk_kernel<4, 8, false>), grid, block, 0, s, a);
       break;
     }
+    case 19: {   // 272 < P <= 304 (round 5; cfg-5's 8-frame windows: P = 298): the 17 x 17 block part in ONE pass over J by the four
+                 // wave-jobs above (all its columns are < 272 <= P), then the two extra column blocks 17, 18 as three small jobs of the
+                 // generic job kernel: sym(17..18) with their record tiles, rect(0..8 x 17..18), rect(9..16 x 17..18) -- they read
+                 // 2 + 11 + 10 of the 19 column blocks again (1.2 more passes over J); every entry of the partial has one owner
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&eq_syrk4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kEq4LdsBytes);
+      hipLaunchKernelGGL(eq_syrk4_kernel, grid, block, kEq4LdsBytes, s, a);
+      a.rb0 = a.cb0 = 17;
+      hipLaunchKernelGGL((eq_syrk_kernel<2, 2, true>), grid, block, 0, s, a);
+      a.rb0 = 0;
+      hipLaunchKernelGGL((eq_syrk_kernel<9, 2, false>), grid, block, 0, s, a);
+      a.rb0 = 9;
+      hipLaunchKernelGGL((eq_syrk_kernel<8, 2, false>), grid, block, 0, s, a);
+      break;
+    }
     default: return BANET_ERR_UNSUPPORTED;
   }
   return hipGetLastError() == hipSuccess ? BANET_OK : BANET_ERR_LAUNCH;

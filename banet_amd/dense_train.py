@@ -374,3 +374,79 @@ def solve_differentiable(ba, levels, lambda_weights, iters_per_level, R=None, T=
         ba.mlps[li] = ops.MlpWeights([(flat[2 * i].detach(), flat[2 * i + 1].detach()) for i in range(5)], dev)
         R, T, Wc = _LevelSolve.apply(ba, li, int(n_it), lv.src, lv.tgt, lv.depth, lv.basis, R, T, Wc, *flat)
     return R, T, Wc
+
+
+# ---- the sparse-point training iteration (round 5): what the reference actually trains on --------------------------------------
+class _SparseIteration(torch.autograd.Function):
+    """ONE BundleIteration / CameraIteration on N sampled points in the reference's own layout (bundlenet.py:122-278 as called from
+    bundlenet.py:332-399: conv1 [B,N,C], the [f|gx|gy] target map [B,H,W,3C], rays p [B,3,N] and per-point level intrinsics) as a
+    single autograd node on the fused kernels:
+      forward   banet_ba_assemble_f32 (gather + SYRK + reduce) and banet_ba_solve_update_f32 -- the inference path, 4-5 launches;
+      backward  the small step (lambda MLP, damping, solve by implicit differentiation, SE(3) / W update: _small_step, as the dense
+                path's) and banet_dense_adjoint_f32 on the sparse level (adjoint.hip, adj_pixel_kernel<.., SP = true>): gradients
+                of conv1, the [f|gx|gy] map, D, the basis, R, T, W and the lambda weights.  No samp / diff / grad / J tensors, no
+                float atomics (the map adjoint is gathered per texel in a fixed order): bit-reproducible.
+    fx / fy / ox / oy / p are data (bundlenet.py:112-120 computes them from the sampled points): no gradient."""
+
+    @staticmethod
+    def forward(ctx, variant, mlp, l2_base, conv1, conv2, D, Bs, R, T, W, fx, fy, ox, oy, p, *flat_layers):
+        nb, H, Wd, C3 = conv2.shape
+        C = conv1.shape[2]
+        K = 0 if Bs is None else Bs.shape[-1]
+        prob = ops.LevelProblem(variant, conv1.detach(), conv2.detach(), D.detach(), H, Wd, C, basis=None if Bs is None else Bs.detach(),
+                                rays=p.detach(), fx=fx.detach(), fy=fy.detach(), ox=ox.detach(), oy=oy.detach(), dense=False,
+                                tgt_has_grad=True)
+        st = ops.LmState(R.detach().clone(), T.detach().clone(), None if K == 0 else W.detach().reshape(nb, K, 1).clone(), P=6 + K)
+        AtA, Atb, absres, nvalid = ops.ba_assemble(prob, st.R, st.T, st.Wc)
+        R0, T0 = st.R.clone(), st.T.clone()
+        W0 = st.Wc.clone() if K else torch.zeros(nb, 0, 1, device=conv1.device)
+        ops.ba_solve_update(prob, mlp, l2_base, AtA, Atb, absres, nvalid, st)
+        ctx.prob, ctx.l2, ctx.camera = prob, float(l2_base), K == 0
+        ctx.saved = (R0, T0, W0, AtA, Atb, absres)
+        ctx.flat = flat_layers
+        ctx.shapes = (conv1.shape, conv2.shape, D.shape, None if Bs is None else Bs.shape, R.shape, T.shape, None if W is None else W.shape)
+        ctx.last = dict(AtA=AtA, Atb=Atb, lam=st.lambda_out.clone(), delta=st.delta.clone())
+        Wn = st.Wc.clone().reshape(W.shape) if K else None
+        return st.R.clone().reshape(R.shape), st.T.clone().reshape(T.shape), Wn
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gR, gT, gW):
+        prob = ctx.prob
+        B, N, C, K = prob.B, prob.N, prob.C, prob.K
+        H, Wd = prob.c.H, prob.c.W
+        dev = prob.device
+        R0, T0, W0, AtA, Atb, absres = ctx.saved
+        gR = torch.zeros(B, 1, 3, 3, device=dev) if gR is None else gR.reshape(B, 1, 3, 3)
+        gT = torch.zeros(B, 1, 3, 1, device=dev) if gT is None else gT.reshape(B, 1, 3, 1)
+        gW = torch.zeros(B, K, 1, device=dev) if (gW is None or K == 0) else gW.reshape(B, K, 1)
+        flat = ctx.flat
+        grads = _small_step([AtA, Atb, absres, R0.reshape(B, 1, 3, 3), T0.reshape(B, 1, 3, 1), W0, gR.contiguous(), gT.contiguous(),
+                             gW.contiguous()] + [t.detach() for t in flat], N, ctx.l2, 1, ctx.camera)
+        gAtA, gAtb, gabs, dR, dT, dW = grads[:6]
+        dsrc = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+        dmap3 = torch.empty((B, H, Wd, 3 * C), dtype=torch.float32, device=dev)
+        ddepth = torch.empty((B, N), dtype=torch.float32, device=dev)
+        dbasis = torch.empty((B, N, K), dtype=torch.float32, device=dev)
+        dpose, _ = dense_adjoint(prob, R0, T0, W0, gAtA, gAtb, gabs, dsrc, dmap3, ddepth, dbasis, None, overwrite=True)
+        dR = dR.reshape(B, 3, 3) + dpose[:, 0:9].reshape(B, 3, 3)
+        dT = dT.reshape(B, 3, 1) + dpose[:, 9:12].reshape(B, 3, 1)
+        s1, s2, sD, sB, sR, sT, sW = ctx.shapes
+        dWn = None if K == 0 else (dW.reshape(B, K, 1) + dpose[:, 12:].reshape(B, K, 1)).reshape(sW)
+        return (None, None, None, dsrc.reshape(s1), dmap3.reshape(s2), ddepth.reshape(sD), None if sB is None else dbasis.reshape(sB),
+                dR.reshape(sR), dT.reshape(sT), dWn, None, None, None, None, None) + tuple(grads[6:])
+
+
+def sparse_iteration_supported(conv1, conv2, Bs):
+    """shapes the fused sparse backward is compiled for (adjoint.hip): C <= 256, K <= 256, not C > 128 together with K > 128"""
+    C = conv1.shape[-1]
+    K = 0 if Bs is None else Bs.shape[-1]
+    return conv1.is_cuda and 1 <= C <= 256 and K <= 256 and not (C > 128 and K > 128) and conv2.shape[-1] == 3 * C
+
+
+def sparse_iteration(variant, mlp, l2_base, conv1, conv2, D, Bs, R, T, W, fx, fy, ox, oy, p, layers):
+    """-> (R', T', W' or None, diagnostics): see _SparseIteration.  layers: five (filters [Cin,Cout], biases [Cout]) pairs (tensors)."""
+    flat = []
+    for w, b in layers:
+        flat += [w.reshape(w.shape[-2], w.shape[-1]), b.reshape(-1)]
+    return _SparseIteration.apply(variant, mlp, l2_base, conv1, conv2, D, Bs, R, T, W, fx, fy, ox, oy, p, *flat)

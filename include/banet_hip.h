@@ -315,7 +315,10 @@ int banet_sample_stats_grad_det_f32(const float* conv1, const float* conv2, cons
  *     direct dependence of the update step on R, T, Wc).  What TF autodiff + EquationConstructionGrad (bundlenet.py:79-82,
  *     utils.cu:465-694) compute for bundlenet.py:206-263, per pixel, without J / G / d in memory.  Bit-reproducible:
  *     the target-map adjoint is gathered per texel in a fixed order (integer atomics only build the cell lists).
- *     Supported: dense = 1, tgt_has_grad = 0, pairs <= 1, C <= 256, and BANET_BUNDLE with 1 <= K <= 256 or the pose-only
+ *     Supported: dense = 1 with tgt_has_grad = 0 -- or (round 5) the reference's own sparse layout, dense = 0 with tgt_has_grad = 1:
+ *     src = conv1 [B,N,C] at N sampled points, rays / fx / fy / ox / oy per point, tgt = the [f|gx|gy] map [B,H,W,3C]
+ *     (bundlenet.py:332-399, what the reference trains on); dmap3 is then the gradient of that map itself --, pairs <= 1,
+ *     C <= 256 (sparse: not C > 128 together with K > 128), and BANET_BUNDLE with 1 <= K <= 256 or the pose-only
  *     BANET_BUNDLE_CAMERA (bundlenet.py:122-191: K = 0, P = 6; basis / Wc / dbasis are not touched and may be NULL); else
  *     workspace_bytes = 0 and BANET_ERR_UNSUPPORTED.  A multi-frame window (pairs > 1) is the sum of its frames' two-frame
  *     terms: call once per target frame with the frame's sub-blocks of gAtA / gAtb (banet_amd/dense_train.py does).

@@ -810,7 +810,7 @@ def _sparse_case(seed, B=2, H=24, W=32, C=6, K=5, N=300):
                 mlp=orc.he_normal_mlp_weights(C, 7))
 
 
-@pytest.mark.parametrize("graph", ["lean", "reference"])
+@pytest.mark.parametrize("graph", ["fused", "lean", "reference"])
 def test_training_graph_matches_fused_forward_and_finite_difference_gradients(graph):
     from banet_amd.bundlenet import BundleNet
     c = _sparse_case(17)
@@ -854,7 +854,7 @@ def test_lean_training_graph_equals_the_reference_style_graph():
     names = ["conv1", "conv2", "fx", "fy", "ox", "oy", "p", "D", "Bs", "R", "T", "W"]
     rng = np.random.RandomState(11)
     res = {}
-    for graph in ("lean", "reference"):
+    for graph in ("lean", "reference", "fused"):
         lw = [(t(w).requires_grad_(True), t(b).requires_grad_(True)) for w, b in c["mlp"]]
         net = BundleNet(lambda_weights={"2": lw})
         net.training_graph = graph
@@ -870,10 +870,11 @@ def test_lean_training_graph_equals_the_reference_style_graph():
         Rc, Tc = net.CameraIteration(*cam, 1.0, "2")
         gc = torch.autograd.grad((Rc * cR).sum() + (Tc * cT).sum(), [leaves[k] for k in ("conv1", "conv2", "D", "T")])
         res[graph] = ([n(Ra), n(Ta), n(Wa), n(Rc), n(Tc)], [n(x) for x in g] + [n(x) for x in gc])
-    for a, b in zip(res["lean"][0], res["reference"][0]):
-        assert relerr(a, b) < 1e-4, relerr(a, b)                     # the parity tolerance on updates
-    for i, (a, b) in enumerate(zip(res["lean"][1], res["reference"][1])):
-        assert relerr(a, b) < 2e-3, (i, relerr(a, b))
+    for other in ("reference", "fused"):   # fused (round 5): the whole iteration as one autograd node on the fused kernels (dense_train._SparseIteration)
+        for a, b in zip(res["lean"][0], res[other][0]):
+            assert relerr(a, b) < 1e-4, (other, relerr(a, b))               # the parity tolerance on updates
+        for i, (a, b) in enumerate(zip(res["lean"][1], res[other][1])):
+            assert relerr(a, b) < 2e-3, (other, i, relerr(a, b))
 
 
 @pytest.mark.parametrize("B,N,C,H,W", [(2, 300, 128, 24, 32), (1, 77, 5, 9, 11), (2, 64, 200, 12, 16)])

@@ -5,7 +5,11 @@
   1280x960 x 7 target frames, K = 256 (configs[4]) -- until round 4 these ran at full size only inside bench.py's sweep record;
 * banet_level_t.policy = BANET_POLICY_BATCH_INVARIANT: the same window solved in batches of 1 / 8 / 32 is bit-identical (kernels,
   SYRK form and summation split decided from the level alone); under the default policy the batches may select different kernels
-  and agree to 1e-5.
+  and agree to rounding (DESIGN.md section 6);
+* the sparse-point training iteration as ONE autograd node on the fused kernels (BundleNet.training_graph = "fused": forward = the
+  inference path, backward = implicit differentiation of the small step + banet_dense_adjoint_f32 on the reference's sparse layout)
+  against the lean torch graph at the reference's training shape (N = 4096 points, C = K = 128); the finite-difference check
+  against the float64 oracle is tests/test_gpu_parity.py::test_training_graph_matches_fused_forward_and_finite_difference_gradients.
 """
 import numpy as np
 import pytest
@@ -117,3 +121,124 @@ def test_batch_invariant_policy_is_bit_identical_across_batch_sizes(pairs):
         assert np.abs(a.astype(np.float64) - ref).max() <= tol * max(np.abs(ref).max(), 1e-30)
     for a, b in zip(d32[1:4], runs[32][1:4]):                 # at the canonical batch both policies are the same launch
         np.testing.assert_array_equal(a, b)
+
+
+def _sparse_iteration64(conv1, conv2, D, Bs, R, T, Wc, lw, bundle, l2, fx, fy, ox, oy, p):
+    """bundlenet.py:122-278 on sparse points in float64, every statement a differentiable torch expression (the lean graph's
+    statements with the C-wide part -- resampler, mask, d, G^T G, G^T d, sum |d| -- written out): the yardstick for both float32
+    training graphs."""
+    from banet_amd.bundlenet import AngleaAxisRotation, CameraJacobianMatrix, DepthJacobianMatrix, VMatrix, _resampler_autograd
+    C, N = conv1.shape[-1], conv1.shape[1]
+    fx8, fy8, ox8, oy8, p8 = fx.double(), fy.double(), ox.double(), oy.double(), p.double()
+    Dd = D + torch.matmul(Bs, Wc) if bundle else D
+    Rp = torch.matmul(R, p8)
+    rx, ry, rz = Rp[:, 0], Rp[:, 1], Rp[:, 2]
+    RPT = Rp * Dd.transpose(1, 2) + T
+    X, Y, Z = RPT[:, 0], RPT[:, 1], RPT[:, 2]
+    x, y = X / Z, Y / Z
+    px, py = fx8 * x + ox8, fy8 * y + oy8
+    samp = _resampler_autograd(conv2, torch.stack([px, py], dim=-1))
+    Hh, Ww = conv2.shape[1], conv2.shape[2]
+    m = (~((px < 0) | (px > float(Ww - 1)) | (py < 0) | (py > float(Hh - 1)))).to(torch.float64)
+    d = (conv1 - samp[..., :C]) * m[..., None]
+    gx, gy = samp[..., C:2 * C] * m[..., None], samp[..., 2 * C:] * m[..., None]
+    M11, M12, M22, g1, g2 = (gx * gx).sum(-1), (gx * gy).sum(-1), (gy * gy).sum(-1), (gx * d).sum(-1), (gy * d).sum(-1)
+    avg = (d.abs().sum(dim=1) / float(N)).unsqueeze(1)
+    h = avg
+    for i, (w, b) in enumerate(lw):
+        z = torch.matmul(h, w) + b
+        h = torch.tanh(z) if i == 4 else torch.nn.functional.selu(z)
+    lam = torch.linalg.vector_norm(avg, dim=-1, keepdim=True) ** (2.0 + h)
+    if bundle:
+        lam = l2 * lam
+    Jc = CameraJacobianMatrix(x, y, Z, fx8, fy8)
+    MJ0 = M11.unsqueeze(-1) * Jc[:, :, 0] + M12.unsqueeze(-1) * Jc[:, :, 1]
+    MJ1 = M12.unsqueeze(-1) * Jc[:, :, 0] + M22.unsqueeze(-1) * Jc[:, :, 1]
+    Hcc = torch.matmul(Jc[:, :, 0].transpose(1, 2), MJ0) + torch.matmul(Jc[:, :, 1].transpose(1, 2), MJ1)
+    bc = (Jc[:, :, 0] * g1.unsqueeze(-1) + Jc[:, :, 1] * g2.unsqueeze(-1)).sum(dim=1)
+    nb = conv1.shape[0]
+    if bundle:
+        jd = DepthJacobianMatrix(rx.unsqueeze(1), ry.unsqueeze(1), rz.unsqueeze(1), x, y, Z, fx8, fy8)
+        u = MJ0 * jd[..., 0:1] + MJ1 * jd[..., 1:2]
+        s_ = M11 * jd[..., 0] ** 2 + 2.0 * M12 * jd[..., 0] * jd[..., 1] + M22 * jd[..., 1] ** 2
+        r = jd[..., 0] * g1 + jd[..., 1] * g2
+        Hcd = torch.matmul(u.transpose(1, 2), Bs)
+        Hdd = torch.matmul(Bs.transpose(1, 2), Bs * s_.unsqueeze(-1))
+        bd = torch.matmul(Bs.transpose(1, 2), r.unsqueeze(-1)).squeeze(-1)
+        AtA = torch.cat([torch.cat([Hcc, Hcd], dim=2), torch.cat([Hcd.transpose(1, 2), Hdd], dim=2)], dim=1)
+        Atb = torch.cat([bc, bd], dim=1).unsqueeze(-1)
+        diag = torch.diagonal(AtA, dim1=1, dim2=2)
+        damp = torch.cat([diag[:, :-1] + 1e-5, torch.zeros(nb, 1, device=diag.device, dtype=diag.dtype)], dim=-1)
+    else:
+        AtA, Atb = Hcc, bc.unsqueeze(-1)
+        damp = torch.diagonal(AtA, dim1=1, dim2=2) + 1e-5
+    sol = torch.linalg.solve(AtA + torch.diag_embed(damp * lam.squeeze(-1)), Atb)
+    wx, wy, wz = sol[:, 0], sol[:, 1], sol[:, 2]
+    dr = AngleaAxisRotation(wx, wy, wz)
+    dv = VMatrix(wx.reshape(-1), wy.reshape(-1), wz.reshape(-1))
+    return torch.matmul(dr, R), torch.matmul(dv, sol[:, 3:6]) + torch.matmul(dr, T), (Wc + sol[:, 6:]) if bundle else None
+
+
+@pytest.mark.parametrize("B,N,C,K,H,W", [(2, 4096, 128, 128, 96, 128),      # the reference's training shape class (bundlenet.py:332-399)
+                                         (1, 777, 70, 33, 40, 56),          # ragged C / K (masked lanes)
+                                         (2, 1500, 32, 200, 48, 64)])       # K > 128: the wide seed blocks
+def test_fused_sparse_training_iteration_equals_the_lean_graph(B, N, C, K, H, W):
+    """BundleNet.BundleIteration / CameraIteration with gradients: training_graph "fused" (one autograd node on the fused kernels,
+    dense_train._SparseIteration) vs "lean" (ops.sample_stats + the normal equations by block in torch, FD-checked against the
+    float64 oracle in test_gpu_parity.py), both against the same statements in float64 (pure torch): same updates (1e-4), and the
+    gradients w.r.t. conv1, the [f|gx|gy] map, D, the basis, R, T, W and the ten lambda-weight tensors within 2e-3 of each
+    gradient's largest entry (or twice the lean graph's own float32 error, whichever is larger); the fused gradients are
+    bit-reproducible run to run (no float atomics)."""
+    from banet_amd import ops
+    from banet_amd.bundlenet import BundleNet, he_normal_lambda_weights
+    g = torch.Generator().manual_seed(1000 + N)
+    img = torch.randn(B, H, W, C, generator=g).to(DEV)
+    conv2 = ops.target_map(img)
+    pts = torch.stack([torch.rand(B, N, generator=g) * (W - 1.5) + 0.25, torch.rand(B, N, generator=g) * (H - 1.5) + 0.25], dim=-1).to(DEV)
+    conv1 = ops.resample(img, pts) + 0.05 * torch.randn(B, N, C, generator=g).to(DEV)
+    fx = torch.full((B, N), 0.8 * W, device=DEV)
+    fy = fx.clone()
+    ox = torch.full((B, N), W / 2.0, device=DEV)
+    oy = torch.full((B, N), H / 2.0, device=DEV)
+    ray = torch.stack([(pts[..., 0] - ox) / fx, (pts[..., 1] - oy) / fy, torch.ones(B, N, device=DEV)], dim=1)
+    p = ray / ray.norm(dim=1, keepdim=True)
+    D = (2.5 + torch.rand(B, N, 1, generator=g)).to(DEV)
+    Bs = (torch.randn(B, N, K, generator=g) / K ** 0.5).to(DEV)
+    R = torch.eye(3, device=DEV).repeat(B, 1, 1)
+    T = (0.02 * torch.randn(B, 3, 1, generator=g)).to(DEV)          # (projections move by ~1 px: some points leave the image)
+    Wc = (0.01 * torch.randn(B, K, 1, generator=g)).to(DEV)
+    cR, cT, cW = [torch.randn(x.shape, generator=g).to(DEV) for x in (R, T, Wc)]
+    res = {}
+    for graph in ("f64", "lean", "fused", "fused"):
+        dt = torch.float64 if graph == "f64" else torch.float32
+        lw = [(w.to(DEV).to(dt).requires_grad_(True), b.to(DEV).to(dt).requires_grad_(True)) for w, b in he_normal_lambda_weights(C, 7)]
+        leaves = [x.clone().to(dt).requires_grad_(True) for x in (conv1, conv2, D, Bs, R, T, Wc)]
+        if graph == "f64":
+            R2, T2, W2 = _sparse_iteration64(*leaves, lw, True, 1000.0, fx, fy, ox, oy, p)
+            Rc, Tc, _ = _sparse_iteration64(*leaves, lw, False, 1.0, fx, fy, ox, oy, p)
+        else:
+            net = BundleNet(lambda_weights={"0": lw})
+            net.training_graph = graph
+            R2, T2, W2 = net.BundleIteration(leaves[0], leaves[1], fx, fy, ox, oy, p, leaves[2], leaves[3], leaves[4], leaves[5], leaves[6], 1000.0, "0")
+            Rc, Tc = net.CameraIteration(leaves[0], leaves[1], fx, fy, ox, oy, p, leaves[2], leaves[4], leaves[5], 1.0, "0")
+        loss = (R2 * cR.to(dt)).sum() + (T2 * cT.to(dt)).sum() + (W2 * cW.to(dt)).sum()
+        grads = torch.autograd.grad(loss, leaves + [x for wb in lw for x in wb], retain_graph=graph == "f64")
+        gc = torch.autograd.grad((Rc * cR.to(dt)).sum() + (Tc * cT.to(dt)).sum(),
+                                 [leaves[0], leaves[1], leaves[2], leaves[4], leaves[5]] + [x for wb in lw for x in wb])
+        out = ([n(x) for x in (R2, T2, W2, Rc, Tc)], [n(x) for x in grads] + [n(x) for x in gc])
+        if graph == "fused" and "fused" in res:
+            for a, b in zip(out[1], res["fused"][1]):
+                np.testing.assert_array_equal(a, b)                  # bit-reproducible
+        res[graph] = out
+
+    def rel(a, b):
+        return float(np.abs(a.astype(np.float64) - b).max() / max(np.abs(b).max(), 1e-300))
+    for a, b, c in zip(res["fused"][0], res["lean"][0], res["f64"][0]):
+        assert rel(a, c) < 1e-4 and rel(a, b) < 1e-4, (rel(a, c), rel(a, b))
+    # gradients: both float32 graphs against the float64 statements.  The fused node must be within 2e-3 of each gradient's
+    # largest entry -- or, where float32 itself cannot do better (the pose-only iteration's feature / depth gradients are ~1e-6
+    # next to pose gradients of ~1: differences of cancelling sums; the lean graph is 4e-1 off there too, tools/diag_sparse_train.py),
+    # no worse than twice the lean graph's own error.
+    for i, (a, b, c) in enumerate(zip(res["fused"][1], res["lean"][1], res["f64"][1])):
+        assert a.shape == c.shape and np.isfinite(a).all()
+        assert rel(a, c) < max(2e-3, 2.0 * rel(b, c)), (i, rel(a, c), rel(b, c))

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """One differentiable BundleIteration (forward + backward w.r.t. features, basis, depth, pose, lambda-MLP weights):
-the lean training graph (ops.sample_stats + block-wise normal equations) vs the reference-style graph (the reference's
-statements with the EquationConstruction op): time per step and peak device memory."""
+the fused node (round 5: the inference kernels forward, implicit differentiation + banet_dense_adjoint_f32 on the sparse layout
+backward) vs the lean training graph (ops.sample_stats + block-wise normal equations) vs the reference-style graph (the reference's
+statements with the EquationConstruction op): time per step and peak device memory.  PN=4096 PH=384 PW=512: the reference's
+training shape (bundlenet.py:332-399)."""
 import os, sys, time
 import numpy as np
 import torch
@@ -25,7 +27,7 @@ Bs = torch.randn(B, N, K, device=dev) / K ** 0.5
 R = torch.eye(3, device=dev).repeat(B, 1, 1)
 T = 0.01 * torch.randn(B, 3, 1, device=dev)
 Wc = torch.zeros(B, K, 1, device=dev)
-for graph in ("lean", "reference"):
+for graph in ("fused", "lean", "reference"):
     lw = [(w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)) for w, b in he_normal_lambda_weights(C, 7)]
     net = BundleNet(lambda_weights={"0": lw})
     net.training_graph = graph
