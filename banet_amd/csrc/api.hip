@@ -142,7 +142,7 @@ int banet_equation_construction_grad_f32(const float* J, const float* G, const f
                                          void* ws, size_t ws_bytes, banet_stream_t stream) {
   if (!J || !G || !d || !g0 || !g1 || !gJ || !gG || !gd) return BANET_ERR_INVALID_ARG;
   if (B <= 0 || N <= 0 || C <= 0 || P <= 0) return BANET_ERR_INVALID_ARG;
-  // with a workspace (P <= 272): the matrix-pipe kernels of eqcon_grad.hip; without: the first-generation kernel
+  // with a workspace (P <= 304): the matrix-pipe kernels of eqcon_grad.hip; without: the first-generation kernel
   const size_t need = eq_grad_fast_ws_bytes(B, N, P);
   if (need > 0 && ws != nullptr && ws_bytes >= need && aligned256(ws))
     return launch_eq_grad_fast(J, G, d, g0, g1, gJ, gG, gd, B, N, C, P, ws, static_cast<hipStream_t>(stream));

@@ -1,4 +1,4 @@
-// EquationConstructionGrad for P <= 272 on the bf16 matrix pipe (the literal op of utils.cu:420-428,465-694):
+// EquationConstructionGrad for P <= 304 on the bf16 matrix pipe (the literal op of utils.cu:420-428,465-694):
 //   dJ = 2 M U + g g1^T,  dG = 2 G Q + d v^T,  dd = G v    with  U = J g0 (2 x P per pixel),  Q = U J^T (2x2),  v = J g1 (2),
 //   M = G^T G, g = G^T d.
 // U is the only large product: the [2N x P] . [P x P] GEMM.  Three kernels:
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kBlock) void eq_grad_gd_kernel(const float* __restr
 }
 
 size_t eq_grad_fast_ws_bytes(int B, int N, int P) {
-  if (P > 272) return 0;
+  if (P > 304) return 0;
   return 2 * align_up((size_t)B * N * 8 * sizeof(float), 256);
 }
 
@@ -256,6 +256,12 @@ int launch_eq_grad_fast(const float* J, const float* G, const float* d, const fl
         launch_u<17, 5>(a, B, s);     // columns >= P are masked
       else
         launch_u<17, 2>(a, B, s);
+    }
+  } else if (nb <= 19) {   // 272 < P <= 304 (round 5; cfg-5's P = 298): 10 k-steps x 5 blocks x 3 KB = 150 KB of split g0 per pass, four passes
+    for (int ob = 0; ob < nb; ob += 5) {      // output columns 0-4, 5-9, 10-14, 15-18 (blocks / columns >= P are masked)
+      a.ob0 = ob;
+      a.accumulate = ob > 0;
+      launch_u<19, 5>(a, B, s);
     }
   } else
     return BANET_ERR_UNSUPPORTED;

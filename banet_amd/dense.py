@@ -23,9 +23,13 @@ class DenseLevel:
 
 
 class DenseBA:
-    def __init__(self, intr, levels, lambda_weights, variant="bundle", l2_base=1000.0):
+    def __init__(self, intr, levels, lambda_weights, variant="bundle", l2_base=1000.0, batch_invariant=False):
         """intr [B,4] full-resolution (fx,fy,ox,oy); levels: list of DenseLevel coarse->fine;
-        lambda_weights: list (one per level) of 5 (filters, biases) pairs."""
+        lambda_weights: list (one per level) of 5 (filters, biases) pairs.
+        batch_invariant: banet_level_t.policy = BANET_POLICY_BATCH_INVARIANT on every level -- kernels, SYRK form and summation
+        split chosen from the level alone, so a window's bits do not depend on the batch / shard it is solved in (callers that
+        shard one batch unevenly over GPUs and compare results bit for bit; slower below ~8 windows per launch).  Default: the
+        launch decides (fastest; results agree to rounding across batchings)."""
         self.variant = variant
         self.levels, self.lambda_weights = list(levels), list(lambda_weights)
         self.l2_base = float(l2_base) if variant == "bundle" else 1.0
@@ -40,6 +44,9 @@ class DenseBA:
                                                   basis=basis, intr=self.intr, scale=lv.scale, dense=True,
                                                   tgt_has_grad=False, normalize_rays=not legacy, pairs=lv.pairs))
             self.mlps.append(None if variant == "legacy_fixed" else ops.MlpWeights(lw, dev))
+        if batch_invariant:
+            for p in self.problems:
+                p.c.policy = ops.capi.POLICY_BATCH_INVARIANT
         self.K = self.problems[0].K
         self.pairs = self.problems[0].pairs
         nb = max(ops.lm_level_workspace_bytes(p) for p in self.problems)

@@ -5,6 +5,12 @@ solves its contiguous shard of the batch.  The only exchange is one all-gather p
 the small per-window result record [R(9) | T(3) | W(K) | iters(L)] -- the "cross-window pose
 reduction" a sequence-level consumer needs (cf. legacy/seq_example.py:170-173).  On MI355X
 that is RCCL over xGMI (`backend="nccl"`); the CPU tests run the same code over gloo.
+
+Shard size and bits: by default the library picks kernels, the SYRK's arithmetic form and the number of partial rows from the whole
+launch (batch included), so a window solved in a shard of 8 and in a shard of 32 agrees to rounding (pose 1e-5, depth coefficients
+1e-4 after a multi-level solve; measured 2.4e-5) but not bit for bit.  Equal shards select equal kernels (two ranks == one process,
+tested); callers that need bit-identical results across UNEQUAL shards build their DenseBA with batch_invariant=True
+(banet_level_t.policy = BANET_POLICY_BATCH_INVARIANT; tests/test_gpu_round5.py).
 """
 import torch
 import torch.distributed as dist

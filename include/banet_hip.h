@@ -51,7 +51,7 @@ const char* banet_error_string(int code);
  *       left  AtA [B,P,P] = sum_n J_n^T (G_n^T G_n) J_n
  *       right Atb [B,P,1] = sum_n J_n^T  G_n^T d_n
  *     Never materialises the per-pixel PxP products (utils.cu:356-365 does: 22 GB/item at
- *     640x480, P=134).  Supported: 1 <= P <= 304, any C >= 1, any N >= 1 (P <= 272: the matrix-pipe kernels; 272 < P <= 304, cfg-5's P = 298: the LDS-tiled first kernel).
+ *     640x480, P=134).  Supported: 1 <= P <= 304, any C >= 1, any N >= 1 (all on the matrix-pipe kernels; 272 < P <= 304, cfg-5's P = 298: the 17-block pass + three jobs, round 5).
  * ------------------------------------------------------------------------------------- */
 size_t banet_equation_construction_workspace_bytes(int B, int N, int C, int P);
 int banet_equation_construction_f32(const float* jacobian, const float* gradient,
@@ -65,7 +65,7 @@ int banet_equation_construction_f32(const float* jacobian, const float* gradient
  *       A_n = G_n J_n ; dA_n = 2 A_n g0 + d_n g1^T   (alpha = 2.0 as utils.cu:651)
  *       jacobian_grad = G^T dA [B,N,2,P]; gradient_grad = dA J^T [B,N,C,2];
  *       difference_grad = A g1 [B,N,C,1]
- *     Workspace: optional.  With ws_bytes >= banet_equation_construction_grad_workspace_bytes (P <= 272, 256-byte
+ *     Workspace: optional.  With ws_bytes >= banet_equation_construction_grad_workspace_bytes (P <= 304, 256-byte
  *     aligned) the matrix-pipe kernels run; with ws = NULL (or for shapes whose size is 0) the first-generation
  *     kernel, same results to rounding.                                                   */
 size_t banet_equation_construction_grad_workspace_bytes(int B, int N, int C, int P);
