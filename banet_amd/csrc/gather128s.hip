@@ -274,7 +274,7 @@ __global__ __launch_bounds__(FP ? 512 : kSBlock, 2) __attribute__((amdgpu_num_vg
       // batches of RB basis rows (16 at K <= 128, 8 at K = 256: 64 registers per buffer): batch n + 1 is in flight while
       // batch n is reduced (two register buffers, sched_barrier keeps the issue order), so the depth dot exposes one memory
       // latency per segment instead of one per batch
-      constexpr int RB = KV4 == 1 ? 16 : 8, NB = 32 / RB;
+      constexpr int RB = FP ? (KV4 == 2 ? 4 : 8) : (KV4 == 1 ? 16 : 8), NB = 32 / RB;   // (FP: a wave does one chunk of four; 8-row batches keep the depth dot out of scratch)
       f32x4 bv[2][RB][KV4];
       auto issue_batch = [&](auto bufc, int c, int hb) __attribute__((always_inline)) {
         constexpr int BUF = decltype(bufc)::value;

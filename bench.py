@@ -770,10 +770,10 @@ def main():
                 entries = [("cfg1_160x120_K32_B1", 2,   1,  120, 160,  32,  3,   20,   3,   [1]),
                            ("B1_2frame",           2,   1,  H,   W,    K,   10,  20,   5,   None),    # (7 ms steps: enough of them for
                            ("B8_2frame",           2,   8,  H,   W,    K,   10,  10,   3,   None),    #  the clocks to settle)
-                           ("cfg3_5frame_B32",     5,   32, H,   W,    K,   10,  5,    1,   None)]
+                           ("cfg3_5frame_B32",     5,   32, H,   W,    K,   10,  8,    2,   None)]
                 if not args.no_sweep_large:      # 161 GB / 67 GB of inputs in the 288 GB of HBM
-                    entries += [("B256_2frame",    2,   256, H,  W,    K,   10,  3,    1,   None),
-                                ("cfg5_8frame_1280x960_K256_B8", 8, 8, 960, 1280, 256, 15, 3, 1, None)]
+                    entries += [("B256_2frame",    2,   256, H,  W,    K,   10,  5,    1,   None),    # (round 5: 5 timed steps, was 3:
+                                ("cfg5_8frame_1280x960_K256_B8", 8, 8, 960, 1280, 256, 15, 5, 1, None)]    # + 1.0 s + 1.2 s of run time)
                 for name, fr, bb, hh, ww, kk, it, stp, wu, sc in entries:
                     sweep[name] = sub_record(fr, bb, hh, ww, kk, it, stp, wu, 4321, dev, fence, args.reserved, sc, par, name)
                 out["sweep"] = sweep
