@@ -67,6 +67,7 @@ __global__ __launch_bounds__(kBlock, 2) void ba_gather128q_kernel(const GatherAr
   float* __restrict__ part_b = a.partials + (size_t)vb * nitems * (kGHdr + C);
   const float* Rm = a.R + vb * 9;
   const float* Tv = a.T + vb * 3;
+  const PoseIntr pq = load_pose_intr(lv, b, Rm, Tv);     // 16 scalars, once per kernel: quad_common.hpp
   const int q = lane & 3, p = lane >> 2;
   const int qx = p & 3, qy = p >> 2;
   const int rowC = W * C;
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(kBlock, 2) void ba_gather128q_kernel(const GatherAr
 
     // ---- 2. geometry (every lane of the quad computes its pixel's) -----------------------------------------------------------
     SGeo ge;
-    strip_geometry(lv, b, Rm, Tv, valid, px, py, D, ge);
+    strip_geometry(lv, pq, valid, px, py, D, ge);
     const bool fast = (ge.flags & 2) != 0;
     const float mk = fast ? 1.f : 0.f;
     const float w00 = mk * ((1.f - ge.dx) * (1.f - ge.dy)), w01 = mk * (ge.dx * (1.f - ge.dy)), w10 = mk * ((1.f - ge.dx) * ge.dy),

@@ -393,6 +393,7 @@ __global__ __launch_bounds__(FP ? 512 : kSBlock, 2) __attribute__((amdgpu_num_vg
       float* __restrict__ part = a.partials + ((size_t)vb * nitems + wi) * (kGHdr + C);
       const float* Rm = a.R + vb * 9;
       const float* Tv = a.T + vb * 3;
+      const PoseIntr pq = load_pose_intr(lv, b, Rm, Tv);     // 16 scalars, once per (window, target frame): quad_common.hpp
 
       // ---- 2. geometry (lane = pixel): tap parameters of the whole segment + the row statistics the plan needs ----------
       ivec4 P0v[NH];       // x0 | y0 << 12 | ((y0 - 1) mod 7) << 24 | fast << 27
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(FP ? 512 : kSBlock, 2) __attribute__((amdgpu_num_vg
         const int py = py0 + 4 * c;
         const bool valid = (px < W) && (py < H);
         SGeo ge;
-        strip_geometry(lv, b, Rm, Tv, valid, px, py, Dv[hh][c4], ge);
+        strip_geometry(lv, pq, valid, px, py, Dv[hh][c4], ge);
         const bool fast = (ge.flags & 2) != 0;
         const int m7 = fast ? (ge.y0 - 1) % kWinRows : 0;
         P0v[hh][c4] = (fast ? (ge.x0 | (ge.y0 << 12)) : 0) | (m7 << 24) | (fast ? (1 << 27) : 0);
@@ -694,7 +695,7 @@ __global__ __launch_bounds__(FP ? 512 : kSBlock, 2) __attribute__((amdgpu_num_vg
         const bool valid = (px < W) && (py < H);
         const int pt = valid ? py * W + px : 0;
         SGeo ge;
-        strip_geometry(lv, b, Rm, Tv, valid, px, py, Dv[hh][c4], ge);
+        strip_geometry(lv, pq, valid, px, py, Dv[hh][c4], ge);
         Q5 qv;
         qv.m11 = Q0[hh][c4];
         qv.m12 = Q1[hh][c4];

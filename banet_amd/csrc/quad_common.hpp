@@ -117,13 +117,34 @@ struct SGeo {
 
 // the pixel's projection, tap fractions and Jacobian rows from (pixel, D, R, T): statement for statement the geometry
 // phase of ba_gather128_kernel (gather128.hip)
-__device__ __forceinline__ void strip_geometry(const banet_level_t& lv, int b, const float* __restrict__ Rm,
-                                               const float* __restrict__ Tv, bool valid, int px, int py, float D, SGeo& o) {
+// The pose and the window's full-resolution intrinsics as 16 wave-uniform scalars, read ONCE per (window, target frame) by the caller.
+// Read inside strip_geometry they were vector loads (the compiler cannot prove that the kernel's own stores do not alias R / T / intr,
+// so it neither hoists them nor uses scalar loads): five loads and three s_waitcnt vmcnt(0) round trips per chunk and phase, 24 per
+// segment, each of which also drains whatever the wave has in flight (round 5).
+struct PoseIntr {
+  float R[9], T[3], fx0, fy0, ox0, oy0;
+};
+__device__ __forceinline__ PoseIntr load_pose_intr(const banet_level_t& lv, int b, const float* __restrict__ Rm, const float* __restrict__ Tv) {
+  auto u = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };   // -> SGPRs
+  PoseIntr q;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) q.R[i] = u(Rm[i]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) q.T[i] = u(Tv[i]);
+  q.fx0 = u(lv.intr[b * 4 + 0]);
+  q.fy0 = u(lv.intr[b * 4 + 1]);
+  q.ox0 = u(lv.intr[b * 4 + 2]);
+  q.oy0 = u(lv.intr[b * 4 + 3]);
+  return q;
+}
+__device__ __forceinline__ void strip_geometry(const banet_level_t& lv, const PoseIntr& pq, bool valid, int px, int py, float D, SGeo& o) {
   const int W = lv.W, H = lv.H;
+  const float* Rm = pq.R;
+  const float* Tv = pq.T;
   o.dx = o.dy = o.jd0 = o.jd1 = 0.f;
   float p0 = 0.f, p1 = 0.f, p2 = 1.f, fx = 1.f, fy = 1.f, ox = 0.f, oy = 0.f;
   if (valid) {
-    const float fx0 = lv.intr[b * 4 + 0], fy0 = lv.intr[b * 4 + 1], ox0 = lv.intr[b * 4 + 2], oy0 = lv.intr[b * 4 + 3];
+    const float fx0 = pq.fx0, fy0 = pq.fy0, ox0 = pq.ox0, oy0 = pq.oy0;
     p0 = ((float)px * lv.scale - ox0) / fx0;
     p1 = ((float)py * lv.scale - oy0) / fy0;
     p2 = 1.f;
