@@ -24,7 +24,7 @@ for lv in levels:
         setattr(lv, name, getattr(lv, name).requires_grad_(True))
 ba = bdense.DenseBA(intr, levels, mlps, "bundle", 1000.0)
 for prob in ba.problems:                       # PBITS: banet_level_t.reserved_ bits for every level (A/B switches, e.g. 67108864 =
-    prob.c.reserved_ = int(os.environ.get("PBITS", "0"))   # bit 26 = the fp32-MFMA form of the backward's GEMM-shaped piece)
+    prob.c.flags = int(os.environ.get("PBITS", "0"))   # bit 26 = the fp32-MFMA form of the backward's GEMM-shaped piece)
 T0 = (gt["T"] * 0.7).reshape(B * (FRAMES - 1), 3, 1).to(dev)
 iters = [IT] * len(SCALES)
 leaves = [getattr(lv, n) for lv in levels for n in ("src", "tgt", "depth", "basis")] + [x for lw in mlps for wb in lw for x in wb]
