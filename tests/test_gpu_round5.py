@@ -181,7 +181,10 @@ def _sparse_iteration64(conv1, conv2, D, Bs, R, T, Wc, lw, bundle, l2, fx, fy, o
 
 @pytest.mark.parametrize("B,N,C,K,H,W", [(2, 4096, 128, 128, 96, 128),      # the reference's training shape class (bundlenet.py:332-399)
                                          (1, 777, 70, 33, 40, 56),          # ragged C / K (masked lanes)
-                                         (2, 1500, 32, 200, 48, 64)])       # K > 128: the wide seed blocks
+                                         (2, 1500, 32, 200, 48, 64),        # K > 128: the wide seed blocks
+                                         (3, 513, 16, 8, 20, 24),           # small everything, three windows
+                                         (1, 2048, 128, 64, 60, 80),        # K = 64
+                                         (2, 300, 256, 32, 24, 32)])        # C = 256 (four channel chunks per lane)
 def test_fused_sparse_training_iteration_equals_the_lean_graph(B, N, C, K, H, W):
     """BundleNet.BundleIteration / CameraIteration with gradients: training_graph "fused" (one autograd node on the fused kernels,
     dense_train._SparseIteration) vs "lean" (ops.sample_stats + the normal equations by block in torch, FD-checked against the
