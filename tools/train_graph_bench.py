@@ -27,7 +27,7 @@ Bs = torch.randn(B, N, K, device=dev) / K ** 0.5
 R = torch.eye(3, device=dev).repeat(B, 1, 1)
 T = 0.01 * torch.randn(B, 3, 1, device=dev)
 Wc = torch.zeros(B, K, 1, device=dev)
-for graph in ("fused", "lean", "reference"):
+for graph in tuple(os.environ.get("PGRAPHS", "fused,lean,reference").split(",")):
     lw = [(w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)) for w, b in he_normal_lambda_weights(C, 7)]
     net = BundleNet(lambda_weights={"0": lw})
     net.training_graph = graph
