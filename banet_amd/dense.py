@@ -7,6 +7,8 @@ the whole coarse->fine LM schedule is enqueued on the current stream without a h
 Iteration bodies: `bundle` = bundlenet.py:193-278 (pose + depth basis), `bundle_camera` =
 bundlenet.py:122-191, `legacy_lm` / `legacy_fixed` = legacy/ba.py:226-345 / :148-214.
 """
+import os
+
 import torch
 
 from . import ops
@@ -54,6 +56,39 @@ class DenseBA:
             raise ops.capi.BanetError("DenseBA: unsupported level shape")
         self.ws = ops.capi.workspace(nb, dev)
         self.B = self.problems[0].B
+        # The coarsest level (<= 1200 pixels) of a large batch as two half batches on two HIP streams (host-side orchestration only;
+        # opt-in: BANET_SPLIT_COARSE=1).  Measured at 32 windows (profiles/r05_run13_*): 40x30 1.37 -> 1.08 ms per 10 iterations, but
+        # 80x60 +7 % and 160x120 +13 % when split too -- net zero over a solve, +0.5 % with the coarsest level alone: not the default.
+        self.split_coarse = os.environ.get("BANET_SPLIT_COARSE", "0") == "1"
+        self._parts, self._side = {}, None
+        self._variant_args = dict(variant=variant, legacy=legacy)
+
+    def _level_parts(self, li, st):
+        """two half-batch views of level li (problems over slices of the level tensors, workspaces) + views of the state"""
+        if li not in self._parts:
+            lv, B = self.levels[li], self.B
+            cuts = [(0, B // 2), (B // 2, B)]
+            parts = []
+            for lo, hi in cuts:
+                H, W, C = lv.H, lv.W, lv.C
+                basis = lv.basis[lo:hi].reshape(hi - lo, H * W, -1) if self.variant == "bundle" else None
+                prob = ops.LevelProblem(self.variant, lv.src[lo:hi], lv.tgt[lo:hi], lv.depth[lo:hi].reshape(hi - lo, H * W), H, W, C,
+                                        basis=basis, intr=self.intr[lo:hi], scale=lv.scale, dense=True, tgt_has_grad=False,
+                                        normalize_rays=not self._variant_args["legacy"], pairs=lv.pairs)
+                prob.c.flags, prob.c.policy = self.problems[li].c.flags, self.problems[li].c.policy
+                parts.append((lo, hi, prob, ops.capi.workspace(ops.lm_level_workspace_bytes(prob), self.intr.device)))
+            self._parts[li] = parts
+        out = []
+        for lo, hi, prob, ws in self._parts[li]:
+            sub = ops.capi.State()
+            sub.R, sub.T = st.R[lo:hi].data_ptr(), st.T[lo:hi].data_ptr()
+            sub.Wc = st.Wc[lo:hi].data_ptr() if st.Wc is not None else None
+            sub.iters, sub.ratio = st.iters[lo:hi].data_ptr(), st.ratio[lo:hi].data_ptr()
+            sub.lambda_out, sub.delta = st.lambda_out[lo:hi].data_ptr(), st.delta[lo:hi].data_ptr()
+            holder = type("SubState", (), {})()
+            holder.c = sub
+            out.append((prob, ws, holder))
+        return out
 
     def new_state(self, R=None, T=None, Wc=None):
         dev = self.intr.device
@@ -78,7 +113,21 @@ class DenseBA:
             if level_events is not None:
                 e0 = torch.cuda.Event(enable_timing=True)
                 e0.record()
-            ops.lm_level(prob, mlp, self.l2_base, its, early_termination, st, ws=self.ws, params=params)
+            li = len(counts)
+            if self.split_coarse and self.B >= 16 and prob.N <= 1200 and li < len(self.levels):
+                # two half batches, the second on a side stream; joined before the next level (the state tensors are shared)
+                dev = self.intr.device
+                cur = torch.cuda.current_stream(dev)
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=dev)
+                (p0, w0, s0), (p1, w1, s1) = self._level_parts(li, st)
+                self._side.wait_stream(cur)
+                ops.lm_level(p0, mlp, self.l2_base, its, early_termination, s0, ws=w0, params=params)
+                with torch.cuda.stream(self._side):
+                    ops.lm_level(p1, mlp, self.l2_base, its, early_termination, s1, ws=w1, params=params)
+                cur.wait_stream(self._side)
+            else:
+                ops.lm_level(prob, mlp, self.l2_base, its, early_termination, st, ws=self.ws, params=params)
             if level_events is not None:
                 e1 = torch.cuda.Event(enable_timing=True)
                 e1.record()
