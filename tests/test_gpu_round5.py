@@ -245,3 +245,27 @@ def test_fused_sparse_training_iteration_equals_the_lean_graph(B, N, C, K, H, W)
     for i, (a, b, c) in enumerate(zip(res["fused"][1], res["lean"][1], res["f64"][1])):
         assert a.shape == c.shape and np.isfinite(a).all()
         assert rel(a, c) < max(2e-3, 2.0 * rel(b, c)), (i, rel(a, c), rel(b, c))
+
+
+def test_split_coarse_levels_equal_one_batch_under_the_invariant_policy():
+    """DenseBA.split_coarse (opt-in): the coarsest level (<= 1200 pixels) of a batch of >= 16 windows runs as two half batches on two
+    HIP streams that share the state tensors.  Under BANET_POLICY_BATCH_INVARIANT a window's bits do not depend on its launch, so the
+    split solve must equal the one-batch solve bit for bit -- which also checks the stream fork / join and the state views."""
+    from banet_amd import dense as bdense, synth as bsynth
+    from banet_amd.bundlenet import he_normal_lambda_weights
+    B, H, W, C, K = 16, 60, 80, 128, 128
+    intr, levels, gt = bsynth.make_dense_windows(B, H, W, C, K, [2, 1], 9100, DEV, trans_mag=0.05)
+    mlps = [he_normal_lambda_weights(C, 17 + i) for i in range(2)]
+    T0 = (gt["T"] * 0.7).reshape(B, 3, 1).to(DEV)
+    out = []
+    for split in (False, True, True):
+        ba = bdense.DenseBA(intr, levels, mlps, "bundle", 1000.0, batch_invariant=True)
+        ba.split_coarse = split
+        st, counts = ba.solve([4, 3], ba.new_state(T=T0.clone()))
+        torch.cuda.synchronize()
+        assert (not split) or 0 in ba._parts                      # the 40x30 level really ran as two halves
+        out.append([n(st.R), n(st.T), n(st.Wc), n(st.delta), n(st.lambda_out)] + [n(c) for c in counts])
+    assert all(np.isfinite(x).all() for x in out[0])
+    for other in out[1:]:
+        for a, b in zip(out[0], other):
+            np.testing.assert_array_equal(a, b)
