@@ -501,9 +501,9 @@ def test_patch_gather_kernel_matches_oracle(H, W, K, big, pairs):
     ba = bdense.DenseBA(t(intr), _torch_levels(levels), mlps, "bundle" if K else "bundle_camera", 1000.0)
     outs = {}
     for bits in (512, 64, 512 | 4096):                           # patch kernel forced / direct kernel / patch kernel with the
-        ba.problems[0].c.reserved_ = bits                         # target frames looped over inside a tile (large levels)
+        ba.problems[0].c.flags = bits                         # target frames looped over inside a tile (large levels)
         outs[bits] = [n(x) for x in ops.ba_assemble(ba.problems[0], t(R), t(T), t(Wc) if K else None)]
-    ba.problems[0].c.reserved_ = 0
+    ba.problems[0].c.flags = 0
     for x, y in zip(outs[512], outs[64]):
         assert relerr(x, y) < 2e-6, relerr(x, y)
     for x, y in zip(outs[512 | 4096], outs[512]):                 # same arithmetic per pair: identical bits

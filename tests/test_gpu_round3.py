@@ -161,10 +161,10 @@ def test_opt_in_three_product_syrk_is_a_separate_less_exact_path():
     Wc = torch.zeros(B, K, 1, device=DEV)
     base = [x.clone() for x in ops.ba_assemble(p, R, T, Wc)]
     again = [x.clone() for x in ops.ba_assemble(p, R, T, Wc)]
-    p.c.reserved_ = ops.SYRK_THREE_PRODUCTS
+    p.c.flags = ops.SYRK_THREE_PRODUCTS
     fast = [x.clone() for x in ops.ba_assemble(p, R, T, Wc)]
     st_fast = ba.step_from(0, R, T, Wc)
-    p.c.reserved_ = 0
+    p.c.flags = 0
     st_base = ba.step_from(0, R, T, Wc)
     assert all(torch.equal(a, b) for a, b in zip(base, again))
     assert not torch.equal(base[0], fast[0])                         # a different kernel ran
@@ -253,13 +253,13 @@ def test_strip_gather_kernel_matches_oracle(H, W, K, big, pairs):
     outs = {}
     variants = (STRIP, DIRECT, STRIP_ALL_DIRECT, STRIP | SEG32, STRIP | SEG8) + ((STRIP | PAIR_LOOP,) if pairs > 1 else ())
     for bits in variants:
-        ba.problems[0].c.reserved_ = bits
+        ba.problems[0].c.flags = bits
         assert ops.gather_selection(ba.problems[0]) == (1 if bits == DIRECT else 3)
         outs[bits] = [n(x) for x in ops.ba_assemble(ba.problems[0], t(R), t(T), t(Wc) if K else None)]
         again = [n(x) for x in ops.ba_assemble(ba.problems[0], t(R), t(T), t(Wc) if K else None)]
         for x, y in zip(outs[bits], again):                       # bit-reproducible run to run
             np.testing.assert_array_equal(x, y)
-    ba.problems[0].c.reserved_ = 0
+    ba.problems[0].c.flags = 0
     for name, x, y in zip(("AtA", "Atb", "absres", "nvalid"), outs[STRIP], outs[DIRECT]):
         assert relerr(x, y) < 3e-6, (name, relerr(x, y))
     for name, x, y in zip(("AtA", "Atb", "absres", "nvalid"), outs[STRIP_ALL_DIRECT], outs[STRIP]):
@@ -352,11 +352,11 @@ def test_cg_solve_and_ldlt_fallback_match_the_oracle_lu(l2_base, pairs):
     AtA, Atb, absres, nvalid = ops.ba_assemble(ba.problems[0], t(R), t(T), t(Wc))
     sols = {}
     for bits in (0, 1 << 23):
-        ba.problems[0].c.reserved_ = bits
+        ba.problems[0].c.flags = bits
         st = ba.new_state(t(R.reshape(B * pairs, 3, 3)), t(T.reshape(B * pairs, 3, 1)), t(Wc))
         ops.ba_solve_update(ba.problems[0], ba.mlps[0], l2_base, AtA, Atb, absres, nvalid, st)
         sols[bits] = (n(st.delta).astype(np.float64), float(n(st.lambda_out)[0]))
-    ba.problems[0].c.reserved_ = 0
+    ba.problems[0].c.flags = 0
     o = 6 * pairs
     for b in range(B):
         lam = float(n(st.lambda_out)[b])
@@ -391,7 +391,7 @@ def test_strip_gather_under_the_legacy_early_terminated_lm():
     for bits in (STRIP, DIRECT):
         ba = bdense.DenseBA(t(intr), _torch_levels(levels), mlps, "legacy_lm")
         for p in ba.problems:
-            p.c.reserved_ = bits
+            p.c.flags = bits
         st, cnt = ba.solve(iters, early_termination=True)
         got[bits] = ([[int(v) for v in c] for c in cnt], n(st.R), n(st.T))
     assert got[STRIP][0] == counts, (got[STRIP][0], counts)

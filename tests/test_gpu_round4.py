@@ -53,7 +53,7 @@ def test_mask_output_of_every_gather_kernel(H, W, K, pairs, big):
     ba = bdense.DenseBA(t(intr), tl, mlps, "bundle" if K else "bundle_camera", 1000.0)
     masks = {}
     for bits in (GENERIC, DIRECT, PATCH, STRIP, QUAD) + ((STRIP_PAIR_LOOP,) if pairs > 1 else ()):
-        ba.problems[0].c.reserved_ = bits
+        ba.problems[0].c.flags = bits
         plain = ops.ba_assemble(ba.problems[0], t(R), t(T), t(Wc) if K else None)
         withm = ops.ba_assemble(ba.problems[0], t(R), t(T), t(Wc) if K else None, return_mask=True)
         for x, y in zip(plain, withm[:4]):                         # writing the mask changes no sum
@@ -62,7 +62,7 @@ def test_mask_output_of_every_gather_kernel(H, W, K, pairs, big):
         assert m.shape == (B, pairs, H * W) and m.max() <= 1       # every pixel written (the buffer starts at 255)
         np.testing.assert_array_equal(m.reshape(B, -1).sum(1).astype(np.float32), n(withm[3]))
         masks[bits] = m
-    ba.problems[0].c.reserved_ = 0
+    ba.problems[0].c.flags = 0
     for bits, m in masks.items():
         np.testing.assert_array_equal(m, masks[DIRECT])             # the same float32 geometry in every kernel
     # against the float64 oracle's mask: identical except for pixels on the border (none expected at these seeds: <= 1 tolerated)
@@ -108,13 +108,13 @@ def test_quad_gather_kernel_matches_oracle(H, W, K, big, pairs):
     ba = bdense.DenseBA(t(intr), tl, mlps, "bundle" if K else "bundle_camera", 1000.0)
     outs = {}
     for bits in (QUAD, DIRECT):
-        ba.problems[0].c.reserved_ = bits
+        ba.problems[0].c.flags = bits
         assert ops.gather_selection(ba.problems[0]) == (1 if bits == DIRECT else 4)
         outs[bits] = [n(x) for x in ops.ba_assemble(ba.problems[0], t(R), t(T), t(Wc) if K else None, return_mask=True)]
         again = [n(x) for x in ops.ba_assemble(ba.problems[0], t(R), t(T), t(Wc) if K else None, return_mask=True)]
         for x, y in zip(outs[bits], again):                       # bit-reproducible run to run
             np.testing.assert_array_equal(x, y)
-    ba.problems[0].c.reserved_ = 0
+    ba.problems[0].c.flags = 0
 
     def relerr(got, want):
         want, got = np.asarray(want, np.float64), np.asarray(got, np.float64)
@@ -205,10 +205,10 @@ def test_syrk_f16_two_piece_with_basis_columns_spanning_many_octaves(K, H, W, pa
     T = (gt["T"] * 0.7).reshape(B, pairs, 3, 1).to(DEV) if pairs > 1 else (gt["T"] * 0.7).reshape(B, 3, 1).to(DEV)
     Wc = torch.zeros(B, K, 1, device=DEV)
     exact = [x.clone() for x in ops.ba_assemble(p, R, T, Wc)]
-    p.c.reserved_ = SYRK_F16
+    p.c.flags = SYRK_F16
     f16 = [x.clone() for x in ops.ba_assemble(p, R, T, Wc)]
     again = [x.clone() for x in ops.ba_assemble(p, R, T, Wc)]
-    p.c.reserved_ = 0
+    p.c.flags = 0
     assert all(torch.equal(a, b) for a, b in zip(f16, again))                  # bit-reproducible
     assert not torch.equal(exact[0], f16[0])                                   # another kernel ran
     o = 6 * pairs
@@ -248,9 +248,9 @@ def test_syrk_f16_flush_and_fallback_cases():
     R = torch.eye(3, device=DEV).repeat(B, 1, 1)
     T = (gt["T"] * 0.7).reshape(B, 3, 1).to(DEV)
     Wc = torch.zeros(B, K, 1, device=DEV)
-    p.c.reserved_ = SYRK_F16
+    p.c.flags = SYRK_F16
     f16 = [x.clone() for x in ops.ba_assemble(p, R, T, Wc)]
-    p.c.reserved_ = 0
+    p.c.flags = 0
     for b in range(B):
         sl = slice(b, b + 1)
         r = torch_port.dense_assemble(intr[sl], lva.scale, lva.src[sl], lva.tgt[sl], lva.depth[sl], lva.basis[sl], R[sl], T[sl], Wc[sl], True, True)
@@ -263,9 +263,9 @@ def test_syrk_f16_flush_and_fallback_cases():
     bb = bdense.DenseBA(intr, [lvb], [orc.he_normal_mlp_weights(C, 5)], "bundle", 1000.0)
     pb = bb.problems[0]
     exact = [x.clone() for x in ops.ba_assemble(pb, R, T, Wc)]
-    pb.c.reserved_ = SYRK_F16
+    pb.c.flags = SYRK_F16
     mixed = [x.clone() for x in ops.ba_assemble(pb, R, T, Wc)]
-    pb.c.reserved_ = 0
+    pb.c.flags = 0
     assert torch.equal(mixed[0][1].nan_to_num(1.0, 2.0, 3.0), exact[0][1].nan_to_num(1.0, 2.0, 3.0))     # window 1: the exact form's bits
     assert not torch.equal(mixed[0][0], exact[0][0]) and torch.isfinite(mixed[0][0]).all()                # window 0: the fp16 form
 
@@ -284,13 +284,13 @@ def test_lm_loop_with_the_f16_syrk_matches_the_exact_form_and_the_twin():
     res = {}
     for bits in (SYRK_F16, -2147483648):
         for prob in ba.problems:
-            prob.c.reserved_ = bits
+            prob.c.flags = bits
         st, counts = ba.solve([10, 10], ba.new_state(T=T0.clone()))
         res[bits] = (st.R.clone(), st.T.clone(), st.Wc.clone(), [c.clone() for c in counts])
         s1 = ba.step_from(1, torch.eye(3, device=DEV).repeat(B, 1, 1), T0.clone(), torch.zeros(B, K, 1, device=DEV))
         res[bits] += (s1.delta.clone(), s1.lambda_out.clone())
     for prob in ba.problems:
-        prob.c.reserved_ = 0
+        prob.c.flags = 0
     a, e = res[SYRK_F16], res[-2147483648]
 
     def rel(x, y):

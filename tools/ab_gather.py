@@ -19,7 +19,7 @@ for (B, H, W, K, rot, tr, pairs) in [(2, 48, 64, 128, 0.012, 0.06, 1), (2, 37, 5
     Wc = torch.zeros(B, max(K, 1), 1, device=dev)[:, :K]
     outs = {}
     for bits in (64, 0, 128):
-        p.c.reserved_ = bits
+        p.c.flags = bits
         outs[bits] = [x.clone() for x in ops.ba_assemble(p, R, T, Wc if K else None)]
         again = ops.ba_assemble(p, R, T, Wc if K else None)
         assert all(torch.equal(x, y) for x, y in zip(outs[bits], again)), "not deterministic"

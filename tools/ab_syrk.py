@@ -16,7 +16,7 @@ for (B, H, W, K, pairs) in [(2, 48, 64, 128, 1), (2, 37, 53, 64, 1), (2, 40, 56,
     Wc = torch.zeros(B, K, 1, device=dev)
     outs = {}
     for bits in (0, 256):
-        p.c.reserved_ = bits
+        p.c.flags = bits
         outs[bits] = [x.clone() for x in ops.ba_assemble(p, R, T, Wc)]
         again = ops.ba_assemble(p, R, T, Wc)
         assert all(torch.equal(x, y) for x, y in zip(outs[bits], again)), "not deterministic"

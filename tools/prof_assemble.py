@@ -31,7 +31,7 @@ res = {bits: [] for bits, _ in cfgs}
 ROUNDS = int(os.environ.get("PROUNDS", "3"))
 for rnd in range(ROUNDS):                      # round-robin over the configurations: warm-up / clock drift hits all alike
     for bits, name in cfgs:
-        p.c.reserved_ = bits
+        p.c.flags = bits
         for _ in range(2):
             ops.ba_assemble(p, R, T, Wc if K else None)
         torch.cuda.synchronize()
@@ -52,7 +52,7 @@ for bits, name in cfgs:
         W, H, K, B, PP, name, ms * 1e3, ms * 1e3 / B, byts / ms / 1e6, ROUNDS, ker))
 ref = None
 for bits, name in cfgs:      # the variants must agree to rounding
-    p.c.reserved_ = bits
+    p.c.flags = bits
     out = [t.clone() for t in ops.ba_assemble(p, R, T, Wc if K else None)]
     torch.cuda.synchronize()
     if ref is None:

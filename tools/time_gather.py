@@ -17,7 +17,7 @@ intr, levels, gt = bsynth.make_dense_windows(B, H, W, C, K, [1], 5, dev, trans_m
 ba = bdense.DenseBA(intr, levels, [he_normal_lambda_weights(C, 1)], "bundle" if K else "bundle_camera", 1000.0)
 p = ba.problems[0]
 PATCH = os.environ.get("PPATCH", "1") == "1"   # 1: the patch kernel (ba_gather128p_kernel), 0: the direct ba_gather128_kernel
-p.c.reserved_ = 0 if PATCH else 64
+p.c.flags = 0 if PATCH else 64
 L = capi.lib()
 R = torch.eye(3, device=dev).repeat(B, 1, 1)
 T = (gt["T"] * 0.7).reshape(B, 3, 1).to(dev)

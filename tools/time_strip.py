@@ -18,7 +18,7 @@ dev = torch.device("cuda:0")
 intr, levels, gt = bsynth.make_dense_windows(B, H, W, C, K, [1], 5, dev, trans_mag=0.06, pairs=PP)
 ba = bdense.DenseBA(intr, levels, [he_normal_lambda_weights(C, 1)], "bundle" if K else "bundle_camera", 1000.0)
 p = ba.problems[0]
-p.c.reserved_ = ops.FORCE_STRIP_GATHER
+p.c.flags = ops.FORCE_STRIP_GATHER
 assert ops.gather_selection(p) == 3
 L = capi.lib()
 R = torch.eye(3, device=dev).repeat(B, 1, 1) if PP == 1 else torch.eye(3, device=dev).repeat(B, PP, 1, 1)

@@ -12,7 +12,7 @@ intr, levels, gt = bsynth.make_dense_windows(B, H, W, C, K, [1], 5, dev, trans_m
 ba = bdense.DenseBA(intr, levels, [he_normal_lambda_weights(C, 1)], "bundle", 1000.0)
 p = ba.problems[0]
 BF = os.environ.get("PBF", "1") == "1"   # 1: the default bf16x6 kernel, 0: the fp32-MFMA ba_syrk_direct_kernel
-p.c.reserved_ = 0 if BF else 256
+p.c.flags = 0 if BF else 256
 L = capi.lib()
 R = torch.eye(3, device=dev).repeat(B, 1, 1)
 T = (gt["T"] * 0.7).reshape(B, 3, 1).to(dev)
