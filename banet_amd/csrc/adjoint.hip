@@ -1519,7 +1519,8 @@ bool adj_supported(const banet_level_t* lv) {
                       (lv->variant == BANET_BUNDLE_CAMERA && lv->K == 0);     // pose only: bundlenet.py:122-191, depth fixed
   const bool dense_ok = lv->dense == 1 && lv->tgt_has_grad == 0 && lv->N == lv->H * lv->W;
   // round 5: sparse points in the reference's layout (conv1 [B,N,C], rays + per-point intrinsics, [f|gx|gy] target map)
-  const bool sparse_ok = lv->dense == 0 && lv->tgt_has_grad == 1 && lv->rays && lv->fx && lv->fy && lv->ox && lv->oy && lv->H >= 2 && lv->W >= 2;
+  const bool sparse_ok = lv->dense == 0 && lv->tgt_has_grad == 1 && lv->rays && lv->fx && lv->fy && lv->ox && lv->oy && lv->H >= 2 && lv->W >= 2 &&
+                         !(lv->C > 128 && lv->K > 128);     // (the point kernel is not compiled for > 2 channel chunks with > 2 coefficient chunks)
   return var_ok && (dense_ok || sparse_ok) && lv->pairs <= 1 && lv->C >= 1 && lv->C <= 64 * kAdjMaxCJ && lv->N >= 1;
 }
 
@@ -1661,7 +1662,6 @@ int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T
     BANET_ADJ_POINT(1, 4);
     BANET_ADJ_POINT(2, 4);
 #undef BANET_ADJ_POINT
-    if (CJ > 2 && KJ > 2) return BANET_ERR_UNSUPPORTED;   // (C > 128 with K > 128: not compiled for the sparse layout)
   } else if ((lv->C & 3) == 0 && (K & 3) == 0 && lv->C <= 128 && K <= 128 && !(lv->flags & (1 << 27))) {   // bit 27: one pixel per wave (A/B)
     hipLaunchKernelGGL((adj_pixel2_kernel<1>), dim3(pl.G, B), dim3(kBlock), 0, s, a);   // (C = 256: 264 B of spills -> the one-pixel kernel)
   } else {

@@ -416,3 +416,32 @@ def test_batch_invariant_policy_selects_by_level_only(capi):
     # the old field name is an alias of the new one (tools/ still use it)
     lv.reserved_ = 1 << 18
     assert lv.flags == 1 << 18
+
+
+def test_adjoint_accepts_the_sparse_reference_layout(capi):
+    """banet_dense_adjoint_workspace_bytes (host-side plan, no launch): the backward of the assembly is compiled for the dense layout
+    AND -- round 5 -- for the reference's own sparse layout (conv1 [B,N,C] at N sampled points, rays + per-point intrinsics, the
+    [f|gx|gy] target map: bundlenet.py:332-399); the cell arrays of the per-texel gather are sized by H * W, not by N."""
+    L = capi.lib()
+    one = (ctypes.c_float * 4)()
+    ptr = ctypes.cast(one, ctypes.c_void_p).value      # any non-null pointer: the plan only checks presence
+
+    def ws(dense, tgt_has_grad, N, H, W, C=128, K=128, with_rays=True, variant=None):
+        lv = capi.Level()
+        lv.B, lv.N, lv.C, lv.K, lv.H, lv.W = 2, N, C, K, H, W
+        lv.variant = capi.BUNDLE if variant is None else variant
+        lv.dense, lv.tgt_has_grad, lv.scale, lv.pairs, lv.normalize_rays = dense, tgt_has_grad, 1.0, 1, 1
+        lv.src = lv.tgt = lv.depth = lv.basis = lv.intr = ptr
+        if with_rays:
+            lv.rays = lv.fx = lv.fy = lv.ox = lv.oy = ptr
+        return L.banet_dense_adjoint_workspace_bytes(ctypes.byref(lv))
+
+    dense = ws(1, 0, 48 * 64, 48, 64)
+    sparse_small_map = ws(0, 1, 4096, 48, 64)
+    sparse_big_map = ws(0, 1, 4096, 384, 512)
+    assert dense > 0 and sparse_small_map > 0 and sparse_big_map > sparse_small_map      # H * W enters the size
+    assert ws(0, 1, 4096, 384, 512, with_rays=False) == 0          # sparse points need rays and per-point intrinsics
+    assert ws(0, 0, 4096, 384, 512) == 0 and ws(1, 1, 48 * 64, 48, 64) == 0      # the two mixed layouts are not compiled
+    assert ws(0, 1, 4096, 384, 512, C=200, K=200) == 0             # sparse: not C > 128 together with K > 128 ...
+    assert ws(0, 1, 4096, 384, 512, C=200, K=64) > 0 and ws(0, 1, 4096, 384, 512, C=64, K=200) > 0
+    assert ws(0, 1, 4096, 384, 512, K=0, variant=capi.BUNDLE_CAMERA) > 0       # pose-only iteration
