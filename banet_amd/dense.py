@@ -80,6 +80,7 @@ class DenseBA:
             self._parts[li] = parts
         out = []
         for lo, hi, prob, ws in self._parts[li]:
+            prob.c.flags, prob.c.policy = self.problems[li].c.flags, self.problems[li].c.policy    # (follow later changes of the level's)
             sub = ops.capi.State()
             sub.R, sub.T = st.R[lo:hi].data_ptr(), st.T[lo:hi].data_ptr()
             sub.Wc = st.Wc[lo:hi].data_ptr() if st.Wc is not None else None
