@@ -90,6 +90,7 @@ EXPORTS = {
     "banet_sample_stats_grad_det_f32": (ctypes.c_int, [_FP] * 4 + [ctypes.c_int] * 5 + [_FP] * 5 + [_FP, ctypes.c_size_t, _FP]),
     "banet_spd_solve_f32": (ctypes.c_int, [_FP] * 3 + [ctypes.c_int] * 2 + [_FP]),
     "banet_dense_adjoint_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Level)]),
+    "banet_dense_adjoint_workspace_bytes_ex": (ctypes.c_size_t, [ctypes.POINTER(Level), ctypes.c_int]),
     "banet_dense_adjoint_f32": (ctypes.c_int, [ctypes.POINTER(Level)] + [_FP] * 11 + [_FP, ctypes.c_size_t, _FP]),
     "banet_dense_adjoint_ex_f32": (ctypes.c_int, [ctypes.POINTER(Level)] + [_FP] * 11 + [ctypes.c_int, _FP, ctypes.c_size_t, _FP]),
     "banet_target_map_adjoint_f32": (ctypes.c_int, [_FP] * 2 + [ctypes.c_int] * 4 + [_FP]),

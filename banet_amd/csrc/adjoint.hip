@@ -38,6 +38,7 @@ constexpr int kAdjMaxCJ = 4;    // C <= 256
 constexpr int kAdjMaxKJ = 4;    // K <= 256 (K <= 128: adj_basis_kernel keeps the whole K x (K+16) seed block in LDS; above: column chunks)
 constexpr int kAdjHdr = 16;     // partial row: dR (9), dT (3), pad, then dWc (K)
 constexpr int kScanThreads = 1024;
+constexpr int kFrac = 8;        // per-pixel record of the map adjoint: key (int; -1 = outside), ax, ay, dg1, dg2, dM11, dM12, dM22
 
 struct AdjArgs {
   banet_level_t lv;
@@ -49,8 +50,8 @@ struct AdjArgs {
   const float* gabs;  // [B][C]
   float* z2;          // [B][N][K]
   float* arec;        // [B][N][8]   q0..q5, zeta, e
-  float* arow;        // [B][N][3C]
-  float* frac;        // [B][N][4]   key (int), ax, ay, -
+  float* arow;        // [B][N][3C]  (nullptr in fold mode: the rows are never materialised)
+  float* frac;        // [B][N][kFrac]   key (int), ax, ay, dg1, dg2, dM11, dM12, dM22
   int* cnt;           // [B][HW]
   int* start;         // [B][HW][2]  (start, count)
   int* cursor;        // [B][HW]
@@ -64,6 +65,10 @@ struct AdjArgs {
   float* dpose;
   int overwrite;      // 1: dsrc / ddepth / dbasis are WRITTEN (every entry, zeros where nothing contributes) instead of accumulated
   int overwrite_map;  // 1: the same for dmap3
+  // fold mode (round 6, adj_tile_kernel): dmap3 is the target map's gradient itself, [B][H][W][C]
+  float* lrec;        // [B][N][kFrac]  the records in cell-list order, key replaced by the pixel index
+  int* list2;         // [B][N]         scratch of the big-cell sort
+  int* bigq;          // [1 + B*N/32]   queue of the cells with more than kSortSerial entries (bigq[0] = their number)
 };
 
 __global__ void adj_sym_kernel(const float* __restrict__ g, float* __restrict__ S, int P, size_t total) {
@@ -487,7 +492,7 @@ __global__ __launch_bounds__(kBlock, (KJ >= 3 ? 2 : 3)) void adj_pixel_kernel(co
     const float x = X / Z, y = Y / Z;
     const float px = fx * x + ox, py = fy * y + oy;
     const bool m = (px >= 0.f) && (px <= (float)(W - 1)) && (py >= 0.f) && (py <= (float)(H - 1));
-    float* __restrict__ fr = a.frac + ((size_t)b * N + n) * 4;
+    float* __restrict__ fr = a.frac + ((size_t)b * N + n) * kFrac;
     if (!m) {   // wave-uniform: no contribution to anything (M = g = 0)
       if (lane == 0) fr[0] = __int_as_float(-1);
       if (a.overwrite) {   // nothing was zero-filled: this pixel's rows are written here
@@ -643,9 +648,11 @@ __global__ __launch_bounds__(kBlock, (KJ >= 3 ? 2 : 3)) void adj_pixel_kernel(co
         const float dgx = 2.f * (dM11 * gx + dM12 * gy) + dg1 * d;
         const float dgy = 2.f * (dM12 * gx + dM22 * gy) + dg2 * d;
         dsrc_n[c] = a.overwrite ? dd : dsrc_n[c] + dd;
-        arow_n[c] = -dd;
-        arow_n[C + c] = dgx;
-        arow_n[2 * C + c] = dgy;
+        if (a.arow) {
+          arow_n[c] = -dd;
+          arow_n[C + c] = dgx;
+          arow_n[2 * C + c] = dgy;
+        }
         dpx += -dd * Ax[j][0] + dgx * Ax[j][1] + dgy * Ax[j][2];
         dpy += -dd * Ay[j][0] + dgx * Ay[j][1] + dgy * Ay[j][2];
       }
@@ -698,6 +705,11 @@ __global__ __launch_bounds__(kBlock, (KJ >= 3 ? 2 : 3)) void adj_pixel_kernel(co
       fr[0] = __int_as_float(key);
       fr[1] = ax;
       fr[2] = ay;
+      fr[3] = dg1;
+      fr[4] = dg2;
+      fr[5] = dM11;
+      fr[6] = dM12;
+      fr[7] = dM22;
       atomicAdd(&a.cnt[(size_t)b * H * W + key], 1);
     }
   }
@@ -964,9 +976,11 @@ __global__ __launch_bounds__(kBlock, 2) void adj_pixel2_kernel(const AdjArgs a) 
         if (m) {
           f32x4* ds = reinterpret_cast<f32x4*>(dsrc_n + 128 * j);
           *ds = a.overwrite ? dd : *ds + dd;
-          *reinterpret_cast<f32x4*>(arow_n + 128 * j) = -dd;
-          *reinterpret_cast<f32x4*>(arow_n + C + 128 * j) = dgx;
-          *reinterpret_cast<f32x4*>(arow_n + 2 * C + 128 * j) = dgy;
+          if (a.arow) {
+            *reinterpret_cast<f32x4*>(arow_n + 128 * j) = -dd;
+            *reinterpret_cast<f32x4*>(arow_n + C + 128 * j) = dgx;
+            *reinterpret_cast<f32x4*>(arow_n + 2 * C + 128 * j) = dgy;
+          }
         }
       }
     }
@@ -1015,14 +1029,13 @@ __global__ __launch_bounds__(kBlock, 2) void adj_pixel2_kernel(const AdjArgs a) 
       *reinterpret_cast<f32x4*>(a.dbasis + q * K + k0) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (hl == 0 && live) {
-      float* __restrict__ fr = a.frac + q * 4;
+      float* __restrict__ fr = a.frac + q * kFrac;
       if (a.overwrite && !m) a.ddepth[q] = 0.f;
       if (m) {
         a.ddepth[q] = a.overwrite ? dD : a.ddepth[q] + dD;
         const int key = y0 * W + x0;
-        fr[0] = __int_as_float(key);
-        fr[1] = ax;
-        fr[2] = ay;
+        *reinterpret_cast<f32x4*>(fr) = f32x4{__int_as_float(key), ax, ay, dg1};
+        *reinterpret_cast<f32x4*>(fr + 4) = f32x4{dg2, dM11, dM12, dM22};
         atomicAdd(&a.cnt[(size_t)b * H * W + key], 1);
       } else {
         fr[0] = __int_as_float(-1);
@@ -1152,10 +1165,369 @@ static void launch_cell_scan(const int* cnt, int* start, int* cursor, int* chunk
 __global__ void adj_fill_kernel(const float* __restrict__ frac, int* __restrict__ cursor, int* __restrict__ list, int N, int HW) {
   const int b = blockIdx.y, n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
-  const int key = __float_as_int(frac[((size_t)b * N + n) * 4]);
+  const int key = __float_as_int(frac[((size_t)b * N + n) * kFrac]);
   if (key < 0) return;
   const int slot = atomicAdd(&cursor[(size_t)b * HW + key], 1);   // the consumer orders each cell's entries itself
   list[(size_t)b * N + slot] = n;
+}
+
+// ---- round 6: the target map's gradient per 8x8 texel tile, without the 3C rows in memory -------------------------------
+// Until round 5 every pixel wrote its 3C adjoint row of the sampled [f|gx|gy] vector (1.5 KB), adj_map2_kernel gathered four of
+// them per texel into the [f|gx|gy] map adjoint dmap3 (another 1.5 KB per texel, read-modify-write over the iterations) and
+// target_map_adjoint4_kernel folded grad_fixed^T once per level: 8+ KB of traffic per pixel and iteration, 30 GB of buffers at 32
+// windows of 640x480.  Here ONE wave owns a tile of TW x TH target texels exclusively: it walks the cell lists of the tile and of
+// the ring around it ((TW + 3) x (TH + 3) cells: every pixel whose 12-texel footprint -- four bilinear taps plus their
+// central-difference neighbours -- touches the tile), recomputes the pixel's channel adjoints (-dd, dgx, dgy) from its source row,
+// the 12 target texels of its cell and the eight per-pixel scalars adj_pixel*_kernel left in its record, and accumulates
+// grad_fixed^T of them (bundlenet.py:92-100, REFLECT rim -> 0) straight into the tile's accumulators in LDS, in a fixed order
+// (cells row-major, ascending pixel index inside a cell): no float atomics between waves, bit-reproducible, and the only thing
+// written is the target map's gradient itself -- once per tile.
+constexpr int kSortSerial = 32;     // cells with up to this many pixels are ordered by one thread (insertion sort)
+
+// One thread per target cell: order the cell's pixel list (adj_fill_kernel's slots come from an atomic cursor) and write the
+// records in list order, key replaced by the pixel index.  Fuller cells (a collapsed warp) go to the big-cell queue.
+__global__ void adj_cellsort_kernel(const int2* __restrict__ cs, int* __restrict__ list, const float* __restrict__ frac,
+                                    float* __restrict__ lrec, int* __restrict__ bigq, int N, int HW, int bigq_cap) {
+  const int b = blockIdx.y, cell = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= HW) return;
+  const int2 v = cs[(size_t)b * HW + cell];
+  const int s0 = v.x, L = v.y;
+  if (L == 0) return;
+  int* __restrict__ li = list + (size_t)b * N + s0;
+  if (L > kSortSerial) {
+    const int slot = atomicAdd(&bigq[0], 1);
+    if (slot < bigq_cap) bigq[1 + slot] = b * HW + cell;     // (cap = every possible big cell: never exceeded)
+    return;
+  }
+  for (int i = 1; i < L; ++i) {
+    const int key = li[i];
+    int j = i - 1;
+    while (j >= 0 && li[j] > key) {
+      li[j + 1] = li[j];
+      --j;
+    }
+    li[j + 1] = key;
+  }
+  const float* __restrict__ fr = frac + (size_t)b * N * kFrac;
+  float* __restrict__ lr = lrec + ((size_t)b * N + s0) * kFrac;
+  for (int i = 0; i < L; ++i) {
+    const int n = li[i];
+    const f32x4 r0 = *reinterpret_cast<const f32x4*>(fr + (size_t)n * kFrac), r1 = *reinterpret_cast<const f32x4*>(fr + (size_t)n * kFrac + 4);
+    *reinterpret_cast<f32x4*>(lr + (size_t)i * kFrac) = f32x4{__int_as_float(n), r0[1], r0[2], r0[3]};
+    *reinterpret_cast<f32x4*>(lr + (size_t)i * kFrac + 4) = r1;
+  }
+}
+
+// One workgroup per queued cell: rank sort through list2 (pixel indices are distinct), then the records.  O(L^2 / 256) -- only a
+// degenerate warp (hundreds of pixels in one texel cell) gets here; adj_map_kernel's per-texel selection had the same order.
+__global__ __launch_bounds__(256) void adj_bigcell_kernel(const int2* __restrict__ cs, int* __restrict__ list, int* __restrict__ list2,
+                                                          const float* __restrict__ frac, float* __restrict__ lrec,
+                                                          const int* __restrict__ bigq, int N, int HW, int bigq_cap) {
+  const int nbig = min(bigq[0], bigq_cap);
+  for (int qi = blockIdx.x; qi < nbig; qi += gridDim.x) {
+    const int gc = bigq[1 + qi], b = gc / HW;
+    const int2 v = cs[gc];
+    const int s0 = v.x, L = v.y;
+    int* __restrict__ li = list + (size_t)b * N + s0;
+    int* __restrict__ lo = list2 + (size_t)b * N + s0;
+    for (int e = threadIdx.x; e < L; e += 256) {
+      const int me = li[e];
+      int rank = 0;
+      for (int j = 0; j < L; ++j) rank += li[j] < me ? 1 : 0;
+      lo[rank] = me;
+    }
+    __syncthreads();
+    const float* __restrict__ fr = frac + (size_t)b * N * kFrac;
+    float* __restrict__ lr = lrec + ((size_t)b * N + s0) * kFrac;
+    for (int e = threadIdx.x; e < L; e += 256) {
+      const int n = lo[e];
+      const f32x4 r0 = *reinterpret_cast<const f32x4*>(fr + (size_t)n * kFrac), r1 = *reinterpret_cast<const f32x4*>(fr + (size_t)n * kFrac + 4);
+      *reinterpret_cast<f32x4*>(lr + (size_t)e * kFrac) = f32x4{__int_as_float(n), r0[1], r0[2], r0[3]};
+      *reinterpret_cast<f32x4*>(lr + (size_t)e * kFrac + 4) = r1;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < L; e += 256) li[e] = lo[e];     // (the list itself in order too: diagnostics, the old per-texel path)
+    __syncthreads();
+  }
+}
+
+template <int V> struct VecOf;
+template <> struct VecOf<1> { typedef float T; };
+template <> struct VecOf<2> { typedef float T __attribute__((ext_vector_type(2))); };
+template <int V> __device__ __forceinline__ typename VecOf<V>::T vsplat(float x);
+template <> __device__ __forceinline__ float vsplat<1>(float x) { return x; }
+template <> __device__ __forceinline__ VecOf<2>::T vsplat<2>(float x) { return VecOf<2>::T{x, x}; }
+// LDS accumulate without a return value (ds_add_f32): the accumulators of a tile belong to one wave, whose LDS operations execute in order
+__device__ __forceinline__ void lds_add(float* p, float v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <int V> __device__ __forceinline__ float vget(const typename VecOf<V>::T& v, int e);
+template <> __device__ __forceinline__ float vget<1>(const float& v, int) { return v; }
+template <> __device__ __forceinline__ float vget<2>(const VecOf<2>::T& v, int e) { return v[e]; }
+
+// CJ x V x 64 >= C: lane owns the V consecutive channels V lane + 64 V j (+ e); V = 2 needs an even C.  One wave per workgroup;
+// LDS = TW TH CJ V 64 floats, accumulator of (texel t, chunk j, element e) of this lane at ((t CJ + j) V + e) 64 + lane (bank = lane).
+// Work items are numbered so that the eight XCDs (workgroup id mod 8) each walk a contiguous range of tiles: the target halo and the
+// source rows that neighbouring tiles share then meet in one L2.
+template <int CJ, int V, int TW, int TH>
+__global__ __launch_bounds__(64) void adj_tile_kernel(const AdjArgs a, int tiles_x, int ntiles, int total, int chunk) {
+  typedef typename VecOf<V>::T vec;
+  static_assert((TW + 3) * (TH + 3) <= 128, "the tile's cell table is two entries per lane");
+  extern __shared__ float sAcc[];
+  const int lane = threadIdx.x;
+  const int kk = blockIdx.x >> 3, work = (blockIdx.x & 7) * chunk + kk;
+  if (kk >= chunk || work >= total) return;
+  const int b = work / ntiles, tile = work - b * ntiles;
+  const int tyi = tile / tiles_x, tx0 = (tile - tyi * tiles_x) * TW, ty0 = tyi * TH;
+  const int N = a.lv.N, C = a.lv.C, H = a.lv.H, W = a.lv.W, HW = H * W;
+  const float* __restrict__ src_b = a.lv.src + (size_t)b * N * C;
+  const float* __restrict__ tgt_b = a.lv.tgt + (size_t)b * HW * C;
+  const float* __restrict__ lrec = a.lrec + (size_t)b * N * kFrac;
+  const int2* __restrict__ cs = reinterpret_cast<const int2*>(a.start) + (size_t)b * HW;
+  bool cok[CJ];
+  int coff[CJ];
+  vec ga[CJ];
+#pragma unroll
+  for (int j = 0; j < CJ; ++j) {
+    const int c = V * lane + 64 * V * j;
+    cok[j] = c < C;
+    coff[j] = cok[j] ? c : 0;
+    ga[j] = *reinterpret_cast<const vec*>(a.gabs + (size_t)b * C + coff[j]);
+    if (!cok[j]) ga[j] = vsplat<V>(0.f);
+  }
+  for (int i = lane; i < TW * TH * CJ * V * 64; i += 64) sAcc[i] = 0.f;
+
+  // the cells whose pixels can touch the tile: x0 in [tx0 - 2, tx0 + TW], y0 in [ty0 - 2, ty0 + TH], clipped to the image
+  const int cxa = max(tx0 - 2, 0), cxb = min(tx0 + TW, W - 1), ncx = cxb - cxa + 1;
+  const int cya = max(ty0 - 2, 0), cyb = min(ty0 + TH, H - 1), ncell = ncx * (cyb - cya + 1);
+  int cst[2], ccn[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int id = lane + 64 * e;
+    const bool ok = id < ncell;
+    const int r = id / ncx, c = id - r * ncx;
+    const int2 v = cs[ok ? (cya + r) * W + cxa + c : 0];
+    cst[e] = v.x;
+    ccn[e] = ok ? v.y : 0;
+  }
+  unsigned long long q0 = __ballot(ccn[0] > 0), q1 = __ballot(ccn[1] > 0);
+  auto next_cell = [&](bool pop) -> int {      // id of the next non-empty cell in row-major order, -1 = none
+    int id = -1;
+    if (q0) {
+      id = __builtin_ctzll(q0);
+      if (pop) q0 &= q0 - 1;
+    } else if (q1) {
+      id = 64 + __builtin_ctzll(q1);
+      if (pop) q1 &= q1 - 1;
+    }
+    return id;
+  };
+  auto cell_range = [&](int id, int& s, int& L) {
+    const int l = id & 63;
+    s = id < 64 ? __builtin_amdgcn_readlane(cst[0], l) : __builtin_amdgcn_readlane(cst[1], l);
+    L = id < 64 ? __builtin_amdgcn_readlane(ccn[0], l) : __builtin_amdgcn_readlane(ccn[1], l);
+  };
+  auto load_tex = [&](int id, vec (&tx)[4][4][CJ]) {
+    const int r0 = id / ncx, cx = cxa + id - r0 * ncx, cy = cya + r0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        if ((r == 0 || r == 3) && (cc == 0 || cc == 3)) continue;
+        const int yy = min(max(cy - 1 + r, 0), H - 1), xx = min(max(cx - 1 + cc, 0), W - 1);
+        const float* __restrict__ row = tgt_b + (size_t)(yy * W + xx) * C;
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) tx[r][cc][j] = *reinterpret_cast<const vec*>(row + coff[j]);
+      }
+  };
+  auto load_rec = [&](int i, f32x4& r0, f32x4& r1) {
+    r0 = *reinterpret_cast<const f32x4*>(lrec + (size_t)i * kFrac);
+    r1 = *reinterpret_cast<const f32x4*>(lrec + (size_t)i * kFrac + 4);
+  };
+  auto load_src = [&](int n, vec (&f)[CJ]) {
+#pragma unroll
+    for (int j = 0; j < CJ; ++j) f[j] = *reinterpret_cast<const vec*>(src_b + (size_t)n * C + coff[j]);
+  };
+
+  // the pixels in walking order: the list segments of a row of cells are contiguous (the list is sorted by cell), so the sequence
+  // is row by row [start of the row's first cell, end of its last); two records ahead are requested, one source row ahead
+  const int ncy = cyb - cya + 1;
+  auto row_range = [&](int r, int& rs, int& re) {
+    int s2, L2, Lx;
+    cell_range(r * ncx, rs, Lx);
+    cell_range(r * ncx + ncx - 1, s2, L2);
+    re = s2 + L2;
+  };
+  struct Seq {
+    int i, r, re;     // list index (-1: done), its row of cells, the row's end
+  };
+  auto seq_from = [&](int r0) -> Seq {
+    for (int r = r0; r < ncy; ++r) {
+      int rs, re;
+      row_range(r, rs, re);
+      if (rs < re) return Seq{rs, r, re};
+    }
+    return Seq{-1, ncy, 0};
+  };
+  auto seq_next = [&](const Seq& q) -> Seq {
+    if (q.i < 0) return q;
+    if (q.i + 1 < q.re) return Seq{q.i + 1, q.r, q.re};
+    return seq_from(q.r + 1);
+  };
+  Seq p0 = seq_from(0);
+  if (p0.i >= 0) {
+    vec tex[4][4][CJ], texn[4][4][CJ], f1[CJ], f1n[CJ];
+    f32x4 ra0, ra1, rb0 = {0.f, 0.f, 0.f, 0.f}, rb1 = rb0, rc0 = rb0, rc1 = rb0;     // records of this pixel, the next, the one after
+    int cur = next_cell(true), s, L;
+    cell_range(cur, s, L);
+    int e = s + L;
+    load_rec(p0.i, ra0, ra1);
+    Seq p1 = seq_next(p0);
+    if (p1.i >= 0) load_rec(p1.i, rb0, rb1);
+    load_tex(cur, tex);
+    load_src(__builtin_amdgcn_readfirstlane(__float_as_int(ra0[0])), f1);
+    int nxt = next_cell(true), sn = 0, Ln = 0;      // the following non-empty cell: its texels travel while this cell's pixels are worked on
+    if (nxt >= 0) {
+      cell_range(nxt, sn, Ln);
+      load_tex(nxt, texn);
+    }
+    while (true) {
+      const Seq p2 = seq_next(p1);
+      if (p2.i >= 0) load_rec(p2.i, rc0, rc1);
+      if (p1.i >= 0) load_src(__builtin_amdgcn_readfirstlane(__float_as_int(rb0[0])), f1n);
+      // ---- this pixel: cell (x0, y0), fractions, the per-pixel scalars of adj_pixel*_kernel
+      const int r0 = cur / ncx, x0 = cxa + cur - r0 * ncx, y0 = cya + r0;
+      const float ax = ra0[1], ay = ra0[2], dg1 = ra0[3], dg2 = ra1[0], dM11 = ra1[1], dM12 = ra1[2], dM22 = ra1[3];
+      vec Sf[CJ], Sgx[CJ], Sgy[CJ];
+#pragma unroll
+      for (int j = 0; j < CJ; ++j) Sf[j] = Sgx[j] = Sgy[j] = vsplat<V>(0.f);
+      float cf[4], cgx[4], cgy[4];      // tap weight x (in image, gx defined, gy defined): adj_pixel*_kernel's wt, fin, hx, hy
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int ix = t & 1, iy = t >> 1;
+        const int tx = x0 + ix, ty = y0 + iy;
+        const bool in = tx <= W - 1 && ty <= H - 1;
+        const float hx = (in && tx > 0 && tx < W - 1) ? 0.5f : 0.f, hy = (in && ty > 0 && ty < H - 1) ? 0.5f : 0.f;
+        const float fin = in ? 1.f : 0.f;
+        const float wx = ix ? ax : 1.f - ax, wy = iy ? ay : 1.f - ay;
+        const float wt = wx * wy;
+        cf[t] = wt * fin;
+        cgx[t] = wt * hx;
+        cgy[t] = wt * hy;
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) {
+          const vec F = fin * tex[1 + iy][1 + ix][j];
+          const vec GX = hx * (tex[1 + iy][2 + ix][j] - tex[1 + iy][ix][j]);
+          const vec GY = hy * (tex[2 + iy][1 + ix][j] - tex[iy][1 + ix][j]);
+          Sf[j] += wt * F;
+          Sgx[j] += wt * GX;
+          Sgy[j] += wt * GY;
+        }
+      }
+      vec af[CJ], agx[CJ], agy[CJ];     // the adjoint of the sampled (f, gx, gy): what the 3C row held
+#pragma unroll
+      for (int j = 0; j < CJ; ++j) {
+        if (!cok[j]) {
+          Sf[j] = Sgx[j] = Sgy[j] = vsplat<V>(0.f);
+          f1[j] = vsplat<V>(0.f);
+        }
+        const vec d = f1[j] - Sf[j];
+        vec sg;
+        if constexpr (V == 1) {
+          sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        } else {
+#pragma unroll
+          for (int q = 0; q < V; ++q) sg[q] = d[q] > 0.f ? 1.f : (d[q] < 0.f ? -1.f : 0.f);
+        }
+        af[j] = -(dg1 * Sgx[j] + dg2 * Sgy[j] + sg * ga[j]);
+        agx[j] = 2.f * (dM11 * Sgx[j] + dM12 * Sgy[j]) + dg1 * d;
+        agy[j] = 2.f * (dM12 * Sgx[j] + dM22 * Sgy[j]) + dg2 * d;
+      }
+      // ---- grad_fixed^T into the tile: texel (X, Y) of the 4x4-minus-corners footprint, if this wave owns it (wave-uniform test)
+      auto slot = [&](int X, int Y) -> float* {
+        const int ux = X - tx0, uy = Y - ty0;
+        return (ux >= 0 && ux < TW && uy >= 0 && uy < TH) ? sAcc + (size_t)((uy * TW + ux) * CJ) * V * 64 + lane : nullptr;
+      };
+      auto put1 = [&](int X, int Y, float k, const vec (&g)[CJ]) {          // += k g
+        if (float* dst = slot(X, Y)) {
+#pragma unroll
+          for (int j = 0; j < CJ; ++j) {
+            const vec v = k * g[j];
+#pragma unroll
+            for (int q = 0; q < V; ++q) lds_add(dst + (j * V + q) * 64, vget<V>(v, q));
+          }
+        }
+      };
+#pragma unroll
+      for (int iy = 0; iy < 2; ++iy) {
+        put1(x0 - 1, y0 + iy, -cgx[2 * iy], agx);          // gx of tap (0, iy) = hx (T[tx + 1] - T[tx - 1])
+        put1(x0 + 2, y0 + iy, cgx[2 * iy + 1], agx);
+      }
+#pragma unroll
+      for (int ix = 0; ix < 2; ++ix) {
+        put1(x0 + ix, y0 - 1, -cgy[ix], agy);
+        put1(x0 + ix, y0 + 2, cgy[2 + ix], agy);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int ix = t & 1, iy = t >> 1;
+        // the tap's own value, the x-neighbour tap's gx (this texel is its right / left neighbour), the y-neighbour tap's gy
+        if (float* dst = slot(x0 + ix, y0 + iy)) {
+          const float kx = ix ? cgx[2 * iy] : -cgx[2 * iy + 1], ky = iy ? cgy[ix] : -cgy[2 + ix];
+#pragma unroll
+          for (int j = 0; j < CJ; ++j) {
+            const vec v = cf[t] * af[j] + kx * agx[j] + ky * agy[j];
+#pragma unroll
+            for (int q = 0; q < V; ++q) lds_add(dst + (j * V + q) * 64, vget<V>(v, q));
+          }
+        }
+      }
+      // ---- advance
+      if (p1.i < 0) break;
+      ra0 = rb0;
+      ra1 = rb1;
+      rb0 = rc0;
+      rb1 = rc1;
+#pragma unroll
+      for (int j = 0; j < CJ; ++j) f1[j] = f1n[j];
+      if (p1.i >= e) {                  // into the next non-empty cell: its texels become current, the cell after it is requested
+        cur = nxt;
+        e = sn + Ln;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) tex[r][cc][j] = texn[r][cc][j];
+        nxt = next_cell(true);
+        if (nxt >= 0) {
+          cell_range(nxt, sn, Ln);
+          load_tex(nxt, texn);
+        }
+      }
+      p0 = p1;
+      p1 = p2;
+    }
+  }
+  // ---- the tile's texels: written once (overwrite_map) or added to the gradient of the earlier iterations
+  float* __restrict__ out_b = a.dmap3 + (size_t)b * HW * C;
+  for (int t = 0; t < TW * TH; ++t) {
+    const int X = tx0 + (t % TW), Y = ty0 + t / TW;
+    if (X >= W || Y >= H) continue;
+#pragma unroll
+    for (int j = 0; j < CJ; ++j) {
+      if (!cok[j]) continue;
+      vec v;
+      if constexpr (V == 1) {
+        v = sAcc[(size_t)(t * CJ + j) * 64 + lane];
+      } else {
+#pragma unroll
+        for (int q = 0; q < V; ++q) v[q] = sAcc[(size_t)((t * CJ + j) * V + q) * 64 + lane];
+      }
+      vec* o = reinterpret_cast<vec*>(out_b + (size_t)(Y * W + X) * C + coff[j]);
+      *o = a.overwrite_map ? v : *o + v;
+    }
+  }
 }
 
 __device__ __forceinline__ int wave_min_i(int v) {
@@ -1172,7 +1544,7 @@ __device__ __forceinline__ void adj_map_texel(const AdjArgs& a, int b, int t, in
   const int N = a.lv.N, C = a.lv.C, H = a.lv.H, W = a.lv.W, HW = H * W, C3 = 3 * C;
   const int2* __restrict__ cs = reinterpret_cast<const int2*>(a.start) + (size_t)b * HW;
   const int* __restrict__ list = a.list + (size_t)b * N;
-  const float* __restrict__ frac = a.frac + (size_t)b * N * 4;
+  const float* __restrict__ frac = a.frac + (size_t)b * N * kFrac;
   const float* __restrict__ arow = a.arow + (size_t)b * N * C3;
   bool cok[J3];
 #pragma unroll
@@ -1209,7 +1581,7 @@ __device__ __forceinline__ void adj_map_texel(const AdjArgs& a, int b, int t, in
       float wt[4];
 #pragma unroll
       for (int cell = 0; cell < 4; ++cell) {
-        const float fax = frac[(size_t)n1[cell] * 4 + 1], fay = frac[(size_t)n1[cell] * 4 + 2];
+        const float fax = frac[(size_t)n1[cell] * kFrac + 1], fay = frac[(size_t)n1[cell] * kFrac + 2];
         const float v = ((cell & 1) ? 1.f - fax : fax) * ((cell >> 1) ? 1.f - fay : fay);   // cell = texel - (1,1) ... texel
         wt[cell] = L[cell] ? v : 0.f;
         any = any || wt[cell] != 0.f;
@@ -1235,7 +1607,7 @@ __device__ __forceinline__ void adj_map_texel(const AdjArgs& a, int b, int t, in
           }
           const int n = wave_min_i(mn);
           last = n;
-          const float ax = frac[(size_t)n * 4 + 1], ay = frac[(size_t)n * 4 + 2];
+          const float ax = frac[(size_t)n * kFrac + 1], ay = frac[(size_t)n * kFrac + 2];
           const float wt = ((cell & 1) ? 1.f - ax : ax) * ((cell >> 1) ? 1.f - ay : ay);
           if (wt != 0.f) {
             any = true;
@@ -1270,7 +1642,7 @@ __global__ __launch_bounds__(kBlock) void adj_map2_kernel(const AdjArgs a) {
   const int N = a.lv.N, C = a.lv.C, H = a.lv.H, W = a.lv.W, HW = H * W, C3 = 3 * C;
   const int2* __restrict__ cs = reinterpret_cast<const int2*>(a.start) + (size_t)b * HW;
   const int* __restrict__ list = a.list + (size_t)b * N;
-  const float* __restrict__ frac = a.frac + (size_t)b * N * 4;
+  const float* __restrict__ frac = a.frac + (size_t)b * N * kFrac;
   const float* __restrict__ arow = a.arow + (size_t)b * N * C3;
   bool cok[J4];
 #pragma unroll
@@ -1311,7 +1683,7 @@ __global__ __launch_bounds__(kBlock) void adj_map2_kernel(const AdjArgs a) {
     bool any = false;
 #pragma unroll
     for (int cell = 0; cell < 4; ++cell) {
-      const float fax = frac[(size_t)n1[cell] * 4 + 1], fay = frac[(size_t)n1[cell] * 4 + 2];
+      const float fax = frac[(size_t)n1[cell] * kFrac + 1], fay = frac[(size_t)n1[cell] * kFrac + 2];
       const float v = ((cell & 1) ? 1.f - fax : fax) * ((cell >> 1) ? 1.f - fay : fay);
       wt[cell] = L[cell] ? v : 0.f;
       any = any || wt[cell] != 0.f;
@@ -1428,7 +1800,7 @@ __global__ __launch_bounds__(kBlock) void sstats_rows_kernel(const float* __rest
         const int c = lane + 64 * j;
         if (c < C) dconv1[q * C + c] = 0.f;
       }
-      if (lane == 0) frac[q * 4] = __int_as_float(-1);
+      if (lane == 0) frac[q * kFrac] = __int_as_float(-1);
     } else {
       const float xf = floorf(pxv), yf = floorf(pyv);
       const int x0 = (int)xf, y0 = (int)yf;
@@ -1478,9 +1850,9 @@ __global__ __launch_bounds__(kBlock) void sstats_rows_kernel(const float* __rest
       dpy = wave_sum(dpy);
       if (lane == 0) {
         const int key = y0 * W + x0;
-        frac[q * 4] = __int_as_float(key);
-        frac[q * 4 + 1] = ax;
-        frac[q * 4 + 2] = ay;
+        frac[q * kFrac] = __int_as_float(key);
+        frac[q * kFrac + 1] = ax;
+        frac[q * kFrac + 2] = ay;
         atomicAdd(&cnt[(size_t)b * H * W + key], 1);
       }
     }
@@ -1511,7 +1883,10 @@ static void launch_adj_map(const AdjArgs& a, int C, dim3 grid, dim3 block, hipSt
 
 struct AdjPlan {
   int G, Ga, Gm;
-  size_t off_S, off_z2, off_arec, off_arow, off_frac, off_cnt, off_start, off_cursor, off_list, off_part, off_chunks, bytes;
+  int fold;           // adj_tile_kernel instead of the 3C rows + per-texel gather (BANET_ADJOINT_FOLD_TARGET)
+  int bigq_cap;
+  size_t off_S, off_z2, off_arec, off_arow, off_frac, off_cnt, off_start, off_cursor, off_list, off_part, off_chunks, off_lrec, off_list2,
+      bytes;
 };
 
 bool adj_supported(const banet_level_t* lv) {
@@ -1524,12 +1899,17 @@ bool adj_supported(const banet_level_t* lv) {
   return var_ok && (dense_ok || sparse_ok) && lv->pairs <= 1 && lv->C >= 1 && lv->C <= 64 * kAdjMaxCJ && lv->N >= 1;
 }
 
-void adj_plan(const banet_level_t* lv, AdjPlan* pl) {
+// fold mode: the dense layout (the target map holds features, gradients are formed from it), any C the pixel kernels take
+bool adj_fold_supported(const banet_level_t* lv) { return adj_supported(lv) && lv->dense == 1 && lv->tgt_has_grad == 0; }
+
+void adj_plan(const banet_level_t* lv, int flags, AdjPlan* pl) {
   const size_t B = lv->B, N = lv->N, C = lv->C, K = lv->K, P = 6 + K, HW = (size_t)lv->H * lv->W;   // (dense: HW == N)
   const int per = (int)((2048 + B - 1) / B);                         // ~8 waves per CU over the whole chip
+  pl->fold = (flags & BANET_ADJOINT_FOLD_TARGET) ? 1 : 0;
   pl->G = (int)std::max<size_t>(1, std::min<size_t>((N + 63) / 64, (size_t)(per + kNumWaves - 1) / kNumWaves));
   pl->Ga = (int)std::max<size_t>(1, std::min<size_t>((N + 63) / 64, (size_t)((512 + B - 1) / B)));
   pl->Gm = (int)std::max<size_t>(1, std::min<size_t>((HW + 3) / 4, (size_t)((4096 + B - 1) / B)));
+  pl->bigq_cap = (int)(B * N / (kSortSerial + 1) + 1);               // every cell that could hold more than kSortSerial pixels
   size_t o = 0;
   auto take = [&](size_t bytes) {
     const size_t at = o;
@@ -1539,15 +1919,50 @@ void adj_plan(const banet_level_t* lv, AdjPlan* pl) {
   pl->off_S = take(B * P * P * 4);
   pl->off_z2 = take(B * N * K * 4);
   pl->off_arec = take(B * N * 8 * 4);
-  pl->off_arow = take(B * N * 3 * C * 4);
-  pl->off_frac = take(B * N * 4 * 4);
-  pl->off_cnt = take(B * HW * 4);
+  pl->off_arow = pl->fold ? 0 : take(B * N * 3 * C * 4);
+  pl->off_frac = take(B * N * kFrac * 4);
+  pl->off_cnt = take(B * HW * 4 + (pl->fold ? (size_t)(1 + pl->bigq_cap) * 4 : 0));   // fold: the big-cell queue follows, its counter zeroed with the counts
   pl->off_start = take(B * HW * 8);
   pl->off_cursor = take(B * HW * 4);
   pl->off_list = take(B * N * 4);
   pl->off_part = take(B * (size_t)pl->G * kNumWaves * (kAdjHdr + K) * 4);
   pl->off_chunks = take(B * ((HW + 1023) / 1024) * 4);
+  pl->off_lrec = pl->fold ? take(B * N * kFrac * 4) : 0;
+  pl->off_list2 = pl->fold ? take(B * N * 4) : 0;
   pl->bytes = o;
+}
+
+// ---- launch of the tile kernel: (channel chunks, vector width) by C; 8 x 8 texel tiles (BANET_ADJOINT_TILE_8X4: 8 x 4, A/B) ----
+template <int CJ, int V, int TW, int TH>
+void launch_adj_tile_t(const AdjArgs& a, hipStream_t s) {
+  const int tiles_x = (a.lv.W + TW - 1) / TW, ntiles = tiles_x * ((a.lv.H + TH - 1) / TH);
+  const int total = ntiles * a.lv.B, chunk = (total + 7) / 8;
+  const size_t shm = (size_t)TW * TH * CJ * V * 64 * sizeof(float);
+  if (shm > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&adj_tile_kernel<CJ, V, TW, TH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+  hipLaunchKernelGGL((adj_tile_kernel<CJ, V, TW, TH>), dim3(8 * chunk), dim3(64), shm, s, a, tiles_x, ntiles, total, chunk);
+}
+template <int CJ, int V>
+void launch_adj_tile_cv(const AdjArgs& a, bool small, hipStream_t s) {
+  if (small)
+    launch_adj_tile_t<CJ, V, 8, 4>(a, s);
+  else
+    launch_adj_tile_t<CJ, V, 8, 8>(a, s);
+}
+void launch_adj_tile(const AdjArgs& a, bool small, hipStream_t s) {
+  const int C = a.lv.C;
+  if ((C & 1) == 0) {
+    if (C <= 128)
+      launch_adj_tile_cv<1, 2>(a, small, s);
+    else
+      launch_adj_tile_cv<2, 2>(a, small, s);
+  } else if (C <= 64) {
+    launch_adj_tile_cv<1, 1>(a, small, s);
+  } else if (C <= 128) {
+    launch_adj_tile_cv<2, 1>(a, small, s);
+  } else {
+    launch_adj_tile_cv<4, 1>(a, small, s);
+  }
 }
 
 template <int NK>
@@ -1581,10 +1996,11 @@ void launch_adj_basis_wide(const AdjArgs& a, int Ga, hipStream_t s) {
 
 }  // namespace
 
-size_t dense_adjoint_workspace_bytes(const banet_level_t* lv) {
+size_t dense_adjoint_workspace_bytes(const banet_level_t* lv, int flags) {
   if (!adj_supported(lv)) return 0;
+  if ((flags & BANET_ADJOINT_FOLD_TARGET) && !adj_fold_supported(lv)) return 0;
   AdjPlan pl;
-  adj_plan(lv, &pl);
+  adj_plan(lv, flags, &pl);
   return pl.bytes;
 }
 
@@ -1592,8 +2008,9 @@ int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T
                          const float* gAtb, const float* gabs, float* dsrc, float* dmap3, float* ddepth, float* dbasis,
                          float* dpose, int flags, void* ws, hipStream_t s) {
   if (!adj_supported(lv)) return BANET_ERR_UNSUPPORTED;
+  if ((flags & BANET_ADJOINT_FOLD_TARGET) && !adj_fold_supported(lv)) return BANET_ERR_UNSUPPORTED;
   AdjPlan pl;
-  adj_plan(lv, &pl);
+  adj_plan(lv, flags, &pl);
   char* base = static_cast<char*>(ws);
   const int B = lv->B, N = lv->N, K = lv->K, P = 6 + K, HW = lv->H * lv->W;
   AdjArgs a;
@@ -1607,13 +2024,16 @@ int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T
   a.gabs = gabs;
   a.z2 = reinterpret_cast<float*>(base + pl.off_z2);
   a.arec = reinterpret_cast<float*>(base + pl.off_arec);
-  a.arow = reinterpret_cast<float*>(base + pl.off_arow);
+  a.arow = pl.fold ? nullptr : reinterpret_cast<float*>(base + pl.off_arow);
   a.frac = reinterpret_cast<float*>(base + pl.off_frac);
   a.cnt = reinterpret_cast<int*>(base + pl.off_cnt);
   a.start = reinterpret_cast<int*>(base + pl.off_start);
   a.cursor = reinterpret_cast<int*>(base + pl.off_cursor);
   a.list = reinterpret_cast<int*>(base + pl.off_list);
   a.part = reinterpret_cast<float*>(base + pl.off_part);
+  a.lrec = pl.fold ? reinterpret_cast<float*>(base + pl.off_lrec) : nullptr;
+  a.list2 = pl.fold ? reinterpret_cast<int*>(base + pl.off_list2) : nullptr;
+  a.bigq = pl.fold ? a.cnt + (size_t)B * HW : nullptr;
   a.G = pl.G;
   a.dsrc = dsrc;
   a.ddepth = ddepth;
@@ -1624,7 +2044,7 @@ int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T
   a.overwrite_map = (flags & BANET_ADJOINT_OVERWRITE_MAP) ? 1 : 0;
   const size_t tot = (size_t)B * P * P;
   hipLaunchKernelGGL(adj_sym_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, gAtA, S, P, tot);
-  if (hipMemsetAsync(a.cnt, 0, (size_t)B * HW * sizeof(int), s) != hipSuccess) return BANET_ERR_LAUNCH;
+  if (hipMemsetAsync(a.cnt, 0, ((size_t)B * HW + (pl.fold ? 1 : 0)) * sizeof(int), s) != hipSuccess) return BANET_ERR_LAUNCH;
   const bool b6 = !(lv->flags & (1 << 26));   // the bf16x6 form of the GEMM-shaped piece (bit 26: fp32 MFMA, A/B)
   switch ((K + 15) / 16) {
     case 1: launch_adj_basis<1>(a, pl.Ga, s); break;
@@ -1689,7 +2109,12 @@ int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T
   }
   launch_cell_scan(a.cnt, a.start, a.cursor, reinterpret_cast<int*>(base + pl.off_chunks), B, HW, s);
   hipLaunchKernelGGL(adj_fill_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, a.frac, a.cursor, a.list, N, HW);
-  {
+  if (pl.fold) {
+    const int2* cs = reinterpret_cast<const int2*>(a.start);
+    hipLaunchKernelGGL(adj_cellsort_kernel, dim3((HW + 255) / 256, B), dim3(256), 0, s, cs, a.list, a.frac, a.lrec, a.bigq, N, HW, pl.bigq_cap);
+    hipLaunchKernelGGL(adj_bigcell_kernel, dim3(64), dim3(256), 0, s, cs, a.list, a.list2, a.frac, a.lrec, a.bigq, N, HW, pl.bigq_cap);
+    launch_adj_tile(a, (flags & BANET_ADJOINT_TILE_8X4) != 0, s);
+  } else {
     const dim3 grid(pl.Gm, B), block(kBlock);
     launch_adj_map(a, lv->C, grid, block, s);
   }
@@ -1710,7 +2135,7 @@ void det_plan(int B, int N, int C, int H, int W, DetPlan* pl) {
     return at;
   };
   pl->off_arow = take((size_t)B * N * 3 * C * 4);
-  pl->off_frac = take((size_t)B * N * 4 * 4);
+  pl->off_frac = take((size_t)B * N * kFrac * 4);
   pl->off_cnt = take((size_t)B * HW * 4);
   pl->off_start = take((size_t)B * HW * 8);
   pl->off_cursor = take((size_t)B * HW * 4);

@@ -385,6 +385,12 @@ size_t banet_dense_adjoint_workspace_bytes(const banet_level_t* lv) {
   return dense_adjoint_workspace_bytes(lv);
 }
 
+size_t banet_dense_adjoint_workspace_bytes_ex(const banet_level_t* lv, int flags) {
+  if (!lv || lv->B <= 0 || lv->N <= 0) return 0;
+  if (flags & ~(BANET_ADJOINT_OVERWRITE | BANET_ADJOINT_OVERWRITE_MAP | BANET_ADJOINT_FOLD_TARGET | BANET_ADJOINT_TILE_8X4)) return 0;
+  return dense_adjoint_workspace_bytes(lv, flags);
+}
+
 int banet_dense_adjoint_ex_f32(const banet_level_t* lv, const float* R, const float* T, const float* Wc, const float* gAtA,
                                const float* gAtb, const float* gabs, float* dsrc, float* dmap3, float* ddepth, float* dbasis,
                                float* dpose, int flags, void* ws, size_t ws_bytes, banet_stream_t stream) {
@@ -392,8 +398,8 @@ int banet_dense_adjoint_ex_f32(const banet_level_t* lv, const float* R, const fl
   if (lv->K > 0 && (!Wc || !dbasis || !lv->basis)) return BANET_ERR_INVALID_ARG;     // K = 0 (pose only): no coefficient / basis tensors
   if (lv->B <= 0 || lv->N <= 0 || !lv->src || !lv->tgt || !lv->depth) return BANET_ERR_INVALID_ARG;
   if (lv->dense ? !lv->intr : (!lv->rays || !lv->fx || !lv->fy || !lv->ox || !lv->oy)) return BANET_ERR_INVALID_ARG;
-  if (flags & ~(BANET_ADJOINT_OVERWRITE | BANET_ADJOINT_OVERWRITE_MAP)) return BANET_ERR_INVALID_ARG;
-  const size_t need = dense_adjoint_workspace_bytes(lv);
+  if (flags & ~(BANET_ADJOINT_OVERWRITE | BANET_ADJOINT_OVERWRITE_MAP | BANET_ADJOINT_FOLD_TARGET | BANET_ADJOINT_TILE_8X4)) return BANET_ERR_INVALID_ARG;
+  const size_t need = dense_adjoint_workspace_bytes(lv, flags);
   if (need == 0) return BANET_ERR_UNSUPPORTED;
   if (ws_bytes < need || (reinterpret_cast<uintptr_t>(ws) & 255) != 0) return BANET_ERR_WORKSPACE;
   return launch_dense_adjoint(lv, R, T, Wc, gAtA, gAtb, gabs, dsrc, dmap3, ddepth, dbasis, dpose, flags, ws,

@@ -174,7 +174,7 @@ int launch_sample_stats_grad(const float* conv1, const float* conv2, const float
                              hipStream_t s);
 
 // ---- adjoint.hip: backward of the fused dense bundle assembly ----
-size_t dense_adjoint_workspace_bytes(const banet_level_t* lv);
+size_t dense_adjoint_workspace_bytes(const banet_level_t* lv, int flags = 0);   // flags: BANET_ADJOINT_FOLD_TARGET changes the layout
 int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T, const float* Wc, const float* gAtA,
                          const float* gAtb, const float* gabs, float* dsrc, float* dmap3, float* ddepth, float* dbasis,
                          float* dpose, int flags, void* ws, hipStream_t s);

@@ -222,14 +222,22 @@ def _small_step(tensors, N, l2_base, pairs=1, camera=False):
 
 
 ADJOINT_OVERWRITE, ADJOINT_OVERWRITE_MAP = 1, 2      # banet_hip.h: BANET_ADJOINT_OVERWRITE, BANET_ADJOINT_OVERWRITE_MAP
+ADJOINT_FOLD_TARGET, ADJOINT_TILE_8X4 = 4, 16         # banet_hip.h: BANET_ADJOINT_FOLD_TARGET, BANET_ADJOINT_TILE_8X4 (A/B)
+# the backward of a dense level writes the target map's gradient per texel tile (round 6) instead of 3C adjoint rows + a per-texel
+# gather + the [f|gx|gy] map adjoint + its fold: BANET_ADJOINT_FOLD=0 keeps the round-5 path (A/B), =2 the 8x4-tile variant (A/B)
+FOLD_MODE = os.environ.get("BANET_ADJOINT_FOLD", "1")
 
 
-def dense_adjoint(problem, R, T, Wc, gAtA, gAtb, gabs, dsrc, dmap3, ddepth, dbasis, ws=None, overwrite=False, overwrite_map=None):
+def dense_adjoint(problem, R, T, Wc, gAtA, gAtb, gabs, dsrc, dmap3, ddepth, dbasis, ws=None, overwrite=False, overwrite_map=None,
+                  fold=False, extra_flags=0):
     """banet_dense_adjoint_ex_f32 -> dpose [B, 12 + K]; dsrc / dmap3 / ddepth / dbasis are accumulated in place, or -- overwrite:
-    the first call on fresh (uninitialised) buffers -- written, every entry (overwrite_map: dmap3 on its own; default = overwrite)."""
+    the first call on fresh (uninitialised) buffers -- written, every entry (overwrite_map: dmap3 on its own; default = overwrite).
+    fold (BANET_ADJOINT_FOLD_TARGET, dense levels): `dmap3` is the target map's gradient [B,H,W,C] itself."""
     overwrite_map = overwrite if overwrite_map is None else overwrite_map
     L = capi.lib()
-    nb = L.banet_dense_adjoint_workspace_bytes(ctypes.byref(problem.c))
+    flags = ((ADJOINT_OVERWRITE if overwrite else 0) | (ADJOINT_OVERWRITE_MAP if overwrite_map else 0) |
+             (ADJOINT_FOLD_TARGET if fold else 0) | int(extra_flags))
+    nb = L.banet_dense_adjoint_workspace_bytes_ex(ctypes.byref(problem.c), flags)
     if nb == 0:
         raise capi.BanetError("dense_adjoint: unsupported level (bundle with 1 <= K <= 256 or bundle_camera, dense two-frame windows, C <= 256)")
     if ws is None or ws.numel() < nb:
@@ -237,8 +245,7 @@ def dense_adjoint(problem, R, T, Wc, gAtA, gAtb, gabs, dsrc, dmap3, ddepth, dbas
     dpose = torch.empty((problem.B, 12 + problem.K), dtype=torch.float32, device=problem.device)
     args = [capi.f32c(x) for x in (R, T, Wc, gAtA, gAtb, gabs)]          # (K = 0: Wc / dbasis are empty, never dereferenced)
     capi.check(L.banet_dense_adjoint_ex_f32(ctypes.byref(problem.c), *[capi.ptr(x) for x in args], capi.ptr(dsrc), capi.ptr(dmap3),
-                                            capi.ptr(ddepth), capi.ptr(dbasis), capi.ptr(dpose),
-                                            (ADJOINT_OVERWRITE if overwrite else 0) | (ADJOINT_OVERWRITE_MAP if overwrite_map else 0),
+                                            capi.ptr(ddepth), capi.ptr(dbasis), capi.ptr(dpose), flags,
                                             ctypes.c_void_p(ws.data_ptr()), ws.numel(), capi.stream()))
     return dpose, ws
 
@@ -298,8 +305,10 @@ class _LevelSolve(torch.autograd.Function):
         pprobs = [prob] if pairs == 1 else _pair_problems(ba, li)
         # no zero-fills: the first adjoint call that touches a buffer writes it (BANET_ADJOINT_OVERWRITE), the later ones accumulate --
         # 25 GB of fills and as many bytes of reads per 32-window 640x480 level
+        fold = FOLD_MODE != "0"          # the target gradient per texel tile: no 3C rows, no [f|gx|gy] map adjoint, no fold pass
+        xflags = ADJOINT_TILE_8X4 if FOLD_MODE == "2" else 0
         dsrc = torch.empty((B, N, C), dtype=torch.float32, device=dev)
-        dmap3 = [torch.empty((B, H, W, 3 * C), dtype=torch.float32, device=dev) for _ in range(pairs)]
+        dmap3 = [torch.empty((B, H, W, C if fold else 3 * C), dtype=torch.float32, device=dev) for _ in range(pairs)]
         ddepth = torch.empty((B, N), dtype=torch.float32, device=dev)
         dbasis = torch.empty((B, N, K), dtype=torch.float32, device=dev)
         flat = ctx.layers
@@ -329,12 +338,15 @@ class _LevelSolve(torch.autograd.Function):
                     gb_i = gAtb.index_select(1, idx).contiguous()
                 # dmap3[i] is fresh for every frame of the first iteration; dsrc / ddepth / dbasis are shared by the frames
                 dpose, ws = dense_adjoint(pprobs[i], Rv[:, i].contiguous(), Tv[:, i].contiguous(), Wi, gA_i, gb_i, gabs, dsrc,
-                                          dmap3[i], ddepth, dbasis, ws, overwrite=first and i == 0, overwrite_map=first)
+                                          dmap3[i], ddepth, dbasis, ws, overwrite=first and i == 0, overwrite_map=first, fold=fold,
+                                          extra_flags=xflags)
                 gR[:, i] += dpose[:, 0:9].reshape(B, 3, 3)
                 gT[:, i] += dpose[:, 9:12].reshape(B, 3, 1)
                 gW += dpose[:, 12:].reshape(B, K, 1)
             first = False
-        if pairs == 1:                                     # written in place: no fill, no copy
+        if fold:                                           # dmap3[i] IS the frame's target gradient
+            dtgt = dmap3[0].view(B, 1, H, W, C) if pairs == 1 else torch.stack(dmap3, 1)
+        elif pairs == 1:                                   # written in place: no fill, no copy
             dtgt = torch.empty((B, 1, H, W, C), dtype=torch.float32, device=dev)
             target_map_adjoint(dmap3[0], dtgt.view(B, H, W, C), overwrite=True)
         else:

@@ -38,7 +38,8 @@ def _scene(H, W, C, K, seed, B=2, scales=(1,)):
     return intr, levels, R, T, Wc, rng
 
 
-def _run_adjoint(intr, lv, R, T, Wc, G, gb, gabs, variant="bundle", overwrite=False):
+def _run_adjoint(intr, lv, R, T, Wc, G, gb, gabs, variant="bundle", overwrite=False, fold=False, tile8x4=False):
+    """fold: BANET_ADJOINT_FOLD_TARGET (round 6) -- the target gradient straight from the tile kernel, no dmap3 / fold pass"""
     from banet_amd import dense as bdense, dense_train
     B, H, W, C = lv["src"].shape
     K = lv["basis"].shape[-1] if variant == "bundle" else 0
@@ -48,9 +49,15 @@ def _run_adjoint(intr, lv, R, T, Wc, G, gb, gabs, variant="bundle", overwrite=Fa
     fill = float("nan") if overwrite else 0.0         # BANET_ADJOINT_OVERWRITE: every entry is written, nothing is read
     out = dict(dsrc=torch.full((B, H * W, C), fill, device=DEV), dmap3=torch.full((B, H, W, 3 * C), fill, device=DEV),
                ddepth=torch.full((B, H * W), fill, device=DEV), dbasis=torch.full((B, H * W, K), fill, device=DEV))
+    dtgt = torch.full((B, H, W, C), fill, device=DEV)
+    if fold:
+        dpose, _ = dense_train.dense_adjoint(prob, t(R), t(T), t(Wc), t(G), t(gb).reshape(B, -1), t(gabs).reshape(B, -1),
+                                            out["dsrc"], dtgt, out["ddepth"], out["dbasis"], overwrite=overwrite, fold=True,
+                                            extra_flags=dense_train.ADJOINT_TILE_8X4 if tile8x4 else 0)
+        torch.cuda.synchronize()
+        return dict(dsrc=out["dsrc"], ddepth=out["ddepth"], dbasis=out["dbasis"], dpose=dpose, dtgt=dtgt)
     dpose, _ = dense_train.dense_adjoint(prob, t(R), t(T), t(Wc), t(G), t(gb).reshape(B, -1), t(gabs).reshape(B, -1),
                                         out["dsrc"], out["dmap3"], out["ddepth"], out["dbasis"], overwrite=overwrite)
-    dtgt = torch.full((B, H, W, C), fill, device=DEV)
     dense_train.target_map_adjoint(out["dmap3"], dtgt, overwrite=overwrite)
     torch.cuda.synchronize()
     return dict(dsrc=out["dsrc"], dmap3=out["dmap3"], ddepth=out["ddepth"], dbasis=out["dbasis"], dpose=dpose, dtgt=dtgt)

@@ -1,0 +1,135 @@
+"""Round 6 (`-m gpu`, through the C ABI): the backward's target-tile kernel (BANET_ADJOINT_FOLD_TARGET, adjoint.hip::adj_tile_kernel:
+the target map's gradient accumulated per 8x8 texel tile in LDS -- no 3C adjoint rows, no [f|gx|gy] map adjoint, no fold pass)
+against the float64 statement of the adjoint (oracle/dense_adjoint.py) and against the round-5 path (rows + per-texel gather +
+banet_target_map_adjoint_f32), bit-reproducibility, overwrite == accumulate-into-zeros, windows with most / all pixels masked,
+and a collapsed warp (hundreds of pixels in one texel cell: the big-cell sort)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dense as odense, dense_adjoint as oadj, synth
+from test_gpu_dense_backward import _run_adjoint, _scene, n, t, DEV
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from banet_amd import _capi
+    _capi.lib()
+
+
+def _want(intr, lv, R, T, Wc, G, gb, gabs, H, W):
+    f32 = lambda v: np.asarray(v, np.float32).astype(np.float64)
+    lv64 = {k: (f32(v) if isinstance(v, np.ndarray) else v) for k, v in lv.items()}
+    a = odense.level_inputs(intr, lv64, True, np.float64)
+    return oadj.assembly_adjoint(a, lv64["tgt"], f32(R), f32(T), f32(Wc), f32(G), f32(gb), f32(gabs) * H * W)
+
+
+@pytest.mark.parametrize("tile8x4", [False, True])
+@pytest.mark.parametrize("H,W,C,K,seed", [(24, 32, 6, 5, 3), (48, 64, 128, 128, 7), (30, 41, 70, 33, 11), (9, 11, 3, 1, 5),
+                                          (16, 16, 64, 16, 2), (17, 33, 130, 40, 9), (20, 24, 256, 64, 4), (15, 21, 128, 128, 6),
+                                          (9, 7, 16, 8, 8), (37, 50, 129, 8, 12), (26, 19, 255, 4, 13)])
+def test_target_tile_adjoint_matches_the_float64_statement_and_the_row_gather_path(H, W, C, K, seed, tile8x4):
+    """every (channel chunks, vector width) instantiation: even C <= 128 / <= 256 (two channels per lane), odd C <= 64 / <= 128 / <= 256"""
+    intr, levels, R, T, Wc, rng = _scene(H, W, C, K, seed)
+    lv = levels[0]
+    B, P = 2, 6 + K
+    G = rng.standard_normal((B, P, P))
+    gb = rng.standard_normal((B, P, 1))
+    gabs = rng.standard_normal((B, 1, C)) * 0.1
+    want = _want(intr, lv, R, T, Wc, G, gb, gabs, H, W)
+    got = _run_adjoint(intr, lv, R, T, Wc, G, gb, gabs, fold=True, tile8x4=tile8x4)
+    old = _run_adjoint(intr, lv, R, T, Wc, G, gb, gabs)
+    assert want["fwd"]["mask"].mean() > 0.5
+    for name, w in (("dsrc", want["dsrc"]), ("dtgt", want["dtgt"]), ("ddepth", want["dD0"]), ("dbasis", want["dbasis"])):
+        g = n(got[name]).reshape(w.shape)
+        err = np.abs(g - w).max() / max(np.abs(w).max(), 1e-30)
+        assert err < 2e-4, (name, err)
+    # the other outputs do not depend on the mode at all; the target gradient only through the summation order
+    for k in ("dsrc", "ddepth", "dbasis", "dpose"):
+        assert torch.equal(got[k], old[k]), k
+    scale = float(old["dtgt"].abs().max())
+    assert float((got["dtgt"] - old["dtgt"]).abs().max()) <= 2e-5 * scale
+
+
+def test_target_tile_adjoint_is_bit_reproducible_and_overwrite_equals_accumulation():
+    H, W, C, K = 48, 64, 128, 32
+    intr, levels, R, T, Wc, rng = _scene(H, W, C, K, 5, B=3)
+    R, T = R.copy(), T.copy()
+    R[1] = synth.rodrigues(np.array([0.0, 0.35, 0.05]))       # most pixels masked
+    T[2] = np.array([[60.0], [0.0], [0.0]])                   # every pixel masked: no texel hit
+    B = 3
+    G = rng.standard_normal((B, 6 + K, 6 + K))
+    gb = rng.standard_normal((B, 6 + K, 1))
+    gabs = rng.standard_normal((B, 1, C)) * 0.1
+    a = _run_adjoint(intr, levels[0], R, T, Wc, G, gb, gabs, fold=True)
+    for _ in range(2):
+        b = _run_adjoint(intr, levels[0], R, T, Wc, G, gb, gabs, fold=True)
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    ow = _run_adjoint(intr, levels[0], R, T, Wc, G, gb, gabs, fold=True, overwrite=True)      # NaN-filled buffers: every entry written
+    for k in a:
+        assert torch.isfinite(ow[k]).all(), k
+        assert torch.equal(a[k], ow[k]), k
+    assert float(a["dtgt"][2].abs().max()) == 0.0 and float(a["dsrc"][2].abs().max()) == 0.0
+    want = _want(intr, levels[0], R, T, Wc, G, gb, gabs, H, W)
+    frac = want["fwd"]["mask"].mean(axis=1)
+    assert 0.02 < frac[1] < 0.7 and frac[2] == 0.0, frac
+    w = want["dtgt"]
+    assert np.abs(n(a["dtgt"]).reshape(w.shape) - w).max() <= 2e-4 * np.abs(w).max()
+
+
+def test_target_tile_adjoint_with_a_collapsed_warp():
+    """A translation of 60 scene units along the optical axis shrinks a whole window into a few target cells around the principal
+    point: hundreds of pixels per cell -- the big-cell queue / rank sort and long per-cell loops -- and still the float64 statement,
+    bit-reproducibly."""
+    H, W, C, K = 24, 32, 16, 8
+    intr, levels, R, T, Wc, rng = _scene(H, W, C, K, 21)
+    lv = levels[0]
+    T = T.copy()
+    T[:, 2, 0] += 60.0
+    B, P = 2, 6 + K
+    G = rng.standard_normal((B, P, P))
+    gb = rng.standard_normal((B, P, 1))
+    gabs = rng.standard_normal((B, 1, C)) * 0.1
+    want = _want(intr, lv, R, T, Wc, G, gb, gabs, H, W)
+    assert want["fwd"]["mask"].mean() > 0.5
+    got = _run_adjoint(intr, lv, R, T, Wc, G, gb, gabs, fold=True)
+    again = _run_adjoint(intr, lv, R, T, Wc, G, gb, gabs, fold=True)
+    old = _run_adjoint(intr, lv, R, T, Wc, G, gb, gabs)
+    w = want["dtgt"]
+    hit = (np.abs(w).max(axis=-1) > 0).reshape(B, -1).sum(axis=1)
+    assert hit.max() <= 64, hit                               # the window's footprint really is a handful of texels
+    assert np.abs(n(got["dtgt"]).reshape(w.shape) - w).max() <= 5e-4 * np.abs(w).max()
+    assert torch.equal(got["dtgt"], again["dtgt"])
+    assert float((got["dtgt"] - old["dtgt"]).abs().max()) <= 1e-4 * float(old["dtgt"].abs().max())
+
+
+def test_solve_differentiable_fold_and_row_gather_backward_agree(monkeypatch):
+    """DenseBA.solve_differentiable end to end (2 levels x 2 iterations, two-frame and 3-frame windows): the default backward
+    (target-tile kernel) against the round-5 one (BANET_ADJOINT_FOLD=0) -- equal to rounding in every gradient."""
+    from banet_amd import dense as bdense, dense_train, synth as bsynth
+    from banet_amd.bundlenet import he_normal_lambda_weights
+    for frames in (2, 3):
+        B, H, W, C, K = 2, 48, 64, 32, 16
+        scales = [2, 1]
+        intr, levels, gt = bsynth.make_dense_windows(B, H, W, C, K, scales, 7, torch.device(DEV), trans_mag=0.06, pairs=frames - 1)
+        mlps = [[(w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)) for w, b in he_normal_lambda_weights(C, 100 + i)]
+                for i in range(len(scales))]
+        for lv in levels:
+            for name in ("src", "tgt", "depth", "basis"):
+                setattr(lv, name, getattr(lv, name).requires_grad_(True))
+        ba = bdense.DenseBA(intr, levels, mlps, "bundle", 1.0)
+        T0 = (gt["T"] * 0.7).reshape(B * (frames - 1), 3, 1).to(DEV)
+        leaves = [getattr(lv, nm) for lv in levels for nm in ("src", "tgt", "depth", "basis")] + [x for lw in mlps for wb in lw for x in wb]
+        res = {}
+        for mode in ("1", "0"):
+            monkeypatch.setattr(dense_train, "FOLD_MODE", mode)
+            Rr, Tt, Ww = ba.solve_differentiable([2, 2], T=T0)
+            loss = (Rr * torch.arange(Rr.numel(), device=DEV).reshape(Rr.shape).float().cos()).sum() + Tt.sum() + (Ww * 0.5).sum()
+            res[mode] = torch.autograd.grad(loss, leaves)
+        for x, y in zip(res["1"], res["0"]):
+            assert torch.isfinite(x).all()
+            assert float((x - y).abs().max()) <= 2e-5 * max(float(y.abs().max()), 1e-30)
