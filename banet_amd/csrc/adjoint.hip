@@ -1257,23 +1257,26 @@ template <> struct VecOf<2> { typedef float T __attribute__((ext_vector_type(2))
 template <int V> __device__ __forceinline__ typename VecOf<V>::T vsplat(float x);
 template <> __device__ __forceinline__ float vsplat<1>(float x) { return x; }
 template <> __device__ __forceinline__ VecOf<2>::T vsplat<2>(float x) { return VecOf<2>::T{x, x}; }
-// LDS accumulate without a return value (ds_add_f32): the accumulators of a tile belong to one wave, whose LDS operations execute in order
-__device__ __forceinline__ void lds_add(float* p, float v) {
-  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-template <int V> __device__ __forceinline__ float vget(const typename VecOf<V>::T& v, int e);
-template <> __device__ __forceinline__ float vget<1>(const float& v, int) { return v; }
-template <> __device__ __forceinline__ float vget<2>(const VecOf<2>::T& v, int e) { return v[e]; }
 
 // CJ x V x 64 >= C: lane owns the V consecutive channels V lane + 64 V j (+ e); V = 2 needs an even C.  One wave per workgroup;
-// LDS = TW TH CJ V 64 floats, accumulator of (texel t, chunk j, element e) of this lane at ((t CJ + j) V + e) 64 + lane (bank = lane).
+// LDS = (TW TH + 1) CJ V 64 floats, the V accumulators of (texel t, chunk j) of this lane side by side at ((t CJ + j) 64 + lane) V
+// (8-byte accesses, conflict-free); slot TW TH is a dummy that takes the footprint texels outside the tile (no branch per
+// destination).
 // Work items are numbered so that the eight XCDs (workgroup id mod 8) each walk a contiguous range of tiles: the target halo and the
 // source rows that neighbouring tiles share then meet in one L2.
+// Memory pipeline: the record two pixels ahead, the source row one pixel ahead and the 12 target texels of the next non-empty cell
+// are requested at the top of an iteration and a full s_waitcnt vmcnt(0) closes it (after ~300 instructions of arithmetic): the
+// loop header then has nothing pending, so the compiler's conservative wait counts at the loop join cannot stall on loads that
+// were only just issued (the first version of this kernel did exactly that: 3.4 us per pixel).
+__device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0), expcnt / lgkmcnt untouched
+
 template <int CJ, int V, int TW, int TH>
 __global__ __launch_bounds__(64) void adj_tile_kernel(const AdjArgs a, int tiles_x, int ntiles, int total, int chunk) {
   typedef typename VecOf<V>::T vec;
   static_assert((TW + 3) * (TH + 3) <= 128, "the tile's cell table is two entries per lane");
-  extern __shared__ float sAcc[];
+  constexpr int kSlotV = CJ * 64;               // vecs per texel slot: accumulator of (texel t, chunk j) of this lane at (t CJ + j) 64 + lane
+  extern __shared__ __attribute__((aligned(16))) float sAcc[];
+  vec* sAccV = reinterpret_cast<vec*>(sAcc);
   const int lane = threadIdx.x;
   const int kk = blockIdx.x >> 3, work = (blockIdx.x & 7) * chunk + kk;
   if (kk >= chunk || work >= total) return;
@@ -1295,11 +1298,11 @@ __global__ __launch_bounds__(64) void adj_tile_kernel(const AdjArgs a, int tiles
     ga[j] = *reinterpret_cast<const vec*>(a.gabs + (size_t)b * C + coff[j]);
     if (!cok[j]) ga[j] = vsplat<V>(0.f);
   }
-  for (int i = lane; i < TW * TH * CJ * V * 64; i += 64) sAcc[i] = 0.f;
+  for (int i = lane; i < (TW * TH + 1) * kSlotV; i += 64) sAccV[i] = vsplat<V>(0.f);
 
   // the cells whose pixels can touch the tile: x0 in [tx0 - 2, tx0 + TW], y0 in [ty0 - 2, ty0 + TH], clipped to the image
   const int cxa = max(tx0 - 2, 0), cxb = min(tx0 + TW, W - 1), ncx = cxb - cxa + 1;
-  const int cya = max(ty0 - 2, 0), cyb = min(ty0 + TH, H - 1), ncell = ncx * (cyb - cya + 1);
+  const int cya = max(ty0 - 2, 0), cyb = min(ty0 + TH, H - 1), ncy = cyb - cya + 1, ncell = ncx * ncy;
   int cst[2], ccn[2];
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
@@ -1311,14 +1314,14 @@ __global__ __launch_bounds__(64) void adj_tile_kernel(const AdjArgs a, int tiles
     ccn[e] = ok ? v.y : 0;
   }
   unsigned long long q0 = __ballot(ccn[0] > 0), q1 = __ballot(ccn[1] > 0);
-  auto next_cell = [&](bool pop) -> int {      // id of the next non-empty cell in row-major order, -1 = none
+  auto next_cell = [&]() -> int {      // pops the id of the next non-empty cell in row-major order, -1 = none
     int id = -1;
     if (q0) {
       id = __builtin_ctzll(q0);
-      if (pop) q0 &= q0 - 1;
+      q0 &= q0 - 1;
     } else if (q1) {
       id = 64 + __builtin_ctzll(q1);
-      if (pop) q1 &= q1 - 1;
+      q1 &= q1 - 1;
     }
     return id;
   };
@@ -1327,15 +1330,22 @@ __global__ __launch_bounds__(64) void adj_tile_kernel(const AdjArgs a, int tiles
     s = id < 64 ? __builtin_amdgcn_readlane(cst[0], l) : __builtin_amdgcn_readlane(cst[1], l);
     L = id < 64 ? __builtin_amdgcn_readlane(ccn[0], l) : __builtin_amdgcn_readlane(ccn[1], l);
   };
+  const unsigned rowB = (unsigned)W * (unsigned)C, laneoff = 0;     // floats per target row
+  (void)laneoff;
   auto load_tex = [&](int id, vec (&tx)[4][4][CJ]) {
     const int r0 = id / ncx, cx = cxa + id - r0 * ncx, cy = cya + r0;
+    unsigned xo[4], yo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      xo[k] = (unsigned)min(max(cx - 1 + k, 0), W - 1) * (unsigned)C;
+      yo[k] = (unsigned)min(max(cy - 1 + k, 0), H - 1) * rowB;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
         if ((r == 0 || r == 3) && (cc == 0 || cc == 3)) continue;
-        const int yy = min(max(cy - 1 + r, 0), H - 1), xx = min(max(cx - 1 + cc, 0), W - 1);
-        const float* __restrict__ row = tgt_b + (size_t)(yy * W + xx) * C;
+        const float* __restrict__ row = tgt_b + (yo[r] + xo[cc]);      // (a window's target map is < 2^32 floats: plan check)
 #pragma unroll
         for (int j = 0; j < CJ; ++j) tx[r][cc][j] = *reinterpret_cast<const vec*>(row + coff[j]);
       }
@@ -1348,10 +1358,8 @@ __global__ __launch_bounds__(64) void adj_tile_kernel(const AdjArgs a, int tiles
 #pragma unroll
     for (int j = 0; j < CJ; ++j) f[j] = *reinterpret_cast<const vec*>(src_b + (size_t)n * C + coff[j]);
   };
-
   // the pixels in walking order: the list segments of a row of cells are contiguous (the list is sorted by cell), so the sequence
-  // is row by row [start of the row's first cell, end of its last); two records ahead are requested, one source row ahead
-  const int ncy = cyb - cya + 1;
+  // is row by row [start of the row's first cell, end of its last)
   auto row_range = [&](int r, int& rs, int& re) {
     int s2, L2, Lx;
     cell_range(r * ncx, rs, Lx);
@@ -1378,7 +1386,7 @@ __global__ __launch_bounds__(64) void adj_tile_kernel(const AdjArgs a, int tiles
   if (p0.i >= 0) {
     vec tex[4][4][CJ], texn[4][4][CJ], f1[CJ], f1n[CJ];
     f32x4 ra0, ra1, rb0 = {0.f, 0.f, 0.f, 0.f}, rb1 = rb0, rc0 = rb0, rc1 = rb0;     // records of this pixel, the next, the one after
-    int cur = next_cell(true), s, L;
+    int cur = next_cell(), s, L;
     cell_range(cur, s, L);
     int e = s + L;
     load_rec(p0.i, ra0, ra1);
@@ -1386,42 +1394,61 @@ __global__ __launch_bounds__(64) void adj_tile_kernel(const AdjArgs a, int tiles
     if (p1.i >= 0) load_rec(p1.i, rb0, rb1);
     load_tex(cur, tex);
     load_src(__builtin_amdgcn_readfirstlane(__float_as_int(ra0[0])), f1);
-    int nxt = next_cell(true), sn = 0, Ln = 0;      // the following non-empty cell: its texels travel while this cell's pixels are worked on
+    int nxt = next_cell(), sn = 0, Ln = 0;        // the following non-empty cell: its texels travel while this cell's pixels are worked on
+    bool want_texn = false;
     if (nxt >= 0) {
       cell_range(nxt, sn, Ln);
-      load_tex(nxt, texn);
+      want_texn = true;
     }
+    wait_vm0();
     while (true) {
+      const int n1 = __builtin_amdgcn_readfirstlane(__float_as_int(rb0[0]));
       const Seq p2 = seq_next(p1);
       if (p2.i >= 0) load_rec(p2.i, rc0, rc1);
-      if (p1.i >= 0) load_src(__builtin_amdgcn_readfirstlane(__float_as_int(rb0[0])), f1n);
+      if (p1.i >= 0) load_src(n1, f1n);
+      if (want_texn) {
+        load_tex(nxt, texn);
+        want_texn = false;
+      }
       // ---- this pixel: cell (x0, y0), fractions, the per-pixel scalars of adj_pixel*_kernel
       const int r0 = cur / ncx, x0 = cxa + cur - r0 * ncx, y0 = cya + r0;
       const float ax = ra0[1], ay = ra0[2], dg1 = ra0[3], dg2 = ra1[0], dM11 = ra1[1], dM12 = ra1[2], dM22 = ra1[3];
-      vec Sf[CJ], Sgx[CJ], Sgy[CJ];
-#pragma unroll
-      for (int j = 0; j < CJ; ++j) Sf[j] = Sgx[j] = Sgy[j] = vsplat<V>(0.f);
       float cf[4], cgx[4], cgy[4];      // tap weight x (in image, gx defined, gy defined): adj_pixel*_kernel's wt, fin, hx, hy
+      vec Sf[CJ], Sgx[CJ], Sgy[CJ];
+      if (x0 >= 1 && y0 >= 1 && x0 + 2 <= W - 1 && y0 + 2 <= H - 1) {      // the whole footprint inside the image, off the rim
+        const float bx = 1.f - ax, by = 1.f - ay;
+        cf[0] = bx * by, cf[1] = ax * by, cf[2] = bx * ay, cf[3] = ax * ay;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int ix = t & 1, iy = t >> 1;
-        const int tx = x0 + ix, ty = y0 + iy;
-        const bool in = tx <= W - 1 && ty <= H - 1;
-        const float hx = (in && tx > 0 && tx < W - 1) ? 0.5f : 0.f, hy = (in && ty > 0 && ty < H - 1) ? 0.5f : 0.f;
-        const float fin = in ? 1.f : 0.f;
-        const float wx = ix ? ax : 1.f - ax, wy = iy ? ay : 1.f - ay;
-        const float wt = wx * wy;
-        cf[t] = wt * fin;
-        cgx[t] = wt * hx;
-        cgy[t] = wt * hy;
+        for (int t = 0; t < 4; ++t) cgx[t] = cgy[t] = 0.5f * cf[t];
 #pragma unroll
         for (int j = 0; j < CJ; ++j) {
-          const vec F = fin * tex[1 + iy][1 + ix][j];
-          const vec GX = hx * (tex[1 + iy][2 + ix][j] - tex[1 + iy][ix][j]);
-          const vec GY = hy * (tex[2 + iy][1 + ix][j] - tex[iy][1 + ix][j]);
-          Sf[j] += wt * F;
-          Sgx[j] += wt * GX;
-          Sgy[j] += wt * GY;
+          Sf[j] = cf[0] * tex[1][1][j] + cf[1] * tex[1][2][j] + cf[2] * tex[2][1][j] + cf[3] * tex[2][2][j];
+          Sgx[j] = cgx[0] * (tex[1][2][j] - tex[1][0][j]) + cgx[1] * (tex[1][3][j] - tex[1][1][j]) + cgx[2] * (tex[2][2][j] - tex[2][0][j]) +
+                   cgx[3] * (tex[2][3][j] - tex[2][1][j]);
+          Sgy[j] = cgy[0] * (tex[2][1][j] - tex[0][1][j]) + cgy[1] * (tex[2][2][j] - tex[0][2][j]) + cgy[2] * (tex[3][1][j] - tex[1][1][j]) +
+                   cgy[3] * (tex[3][2][j] - tex[1][2][j]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) Sf[j] = Sgx[j] = Sgy[j] = vsplat<V>(0.f);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int ix = t & 1, iy = t >> 1;
+          const int tx = x0 + ix, ty = y0 + iy;
+          const bool in = tx <= W - 1 && ty <= H - 1;
+          const float hx = (in && tx > 0 && tx < W - 1) ? 0.5f : 0.f, hy = (in && ty > 0 && ty < H - 1) ? 0.5f : 0.f;
+          const float fin = in ? 1.f : 0.f;
+          const float wx = ix ? ax : 1.f - ax, wy = iy ? ay : 1.f - ay;
+          const float wt = wx * wy;
+          cf[t] = wt * fin;
+          cgx[t] = wt * hx;
+          cgy[t] = wt * hy;
+#pragma unroll
+          for (int j = 0; j < CJ; ++j) {
+            Sf[j] += cf[t] * tex[1 + iy][1 + ix][j];
+            Sgx[j] += cgx[t] * (tex[1 + iy][2 + ix][j] - tex[1 + iy][ix][j]);
+            Sgy[j] += cgy[t] * (tex[2 + iy][1 + ix][j] - tex[iy][1 + ix][j]);
+          }
         }
       }
       vec af[CJ], agx[CJ], agy[CJ];     // the adjoint of the sampled (f, gx, gy): what the 3C row held
@@ -1443,47 +1470,53 @@ __global__ __launch_bounds__(64) void adj_tile_kernel(const AdjArgs a, int tiles
         agx[j] = 2.f * (dM11 * Sgx[j] + dM12 * Sgy[j]) + dg1 * d;
         agy[j] = 2.f * (dM12 * Sgx[j] + dM22 * Sgy[j]) + dg2 * d;
       }
-      // ---- grad_fixed^T into the tile: texel (X, Y) of the 4x4-minus-corners footprint, if this wave owns it (wave-uniform test)
-      auto slot = [&](int X, int Y) -> float* {
-        const int ux = X - tx0, uy = Y - ty0;
-        return (ux >= 0 && ux < TW && uy >= 0 && uy < TH) ? sAcc + (size_t)((uy * TW + ux) * CJ) * V * 64 + lane : nullptr;
-      };
-      auto put1 = [&](int X, int Y, float k, const vec (&g)[CJ]) {          // += k g
-        if (float* dst = slot(X, Y)) {
+      // ---- grad_fixed^T into the tile: the 4x4-minus-corners footprint; a texel outside the tile goes to the dummy slot.
+      // Plain read-modify-write, all 12 reads before the 12 writes: the accumulators belong to this wave alone (LDS float
+      // atomics -- ds_add_f32 -- measured ~240 ns each here: 5.8 us per pixel with 24 of them)
+      {
+        const int ux = x0 - 1 - tx0, uy = y0 - 1 - ty0;     // footprint column cc / row r -> tile column ux + cc / row uy + r
+        int xo[4], yo[4];
 #pragma unroll
-          for (int j = 0; j < CJ; ++j) {
-            const vec v = k * g[j];
+        for (int k = 0; k < 4; ++k) {
+          xo[k] = (unsigned)(ux + k) < (unsigned)TW ? (ux + k) * kSlotV : -1;
+          yo[k] = (unsigned)(uy + k) < (unsigned)TH ? (uy + k) * TW * kSlotV : -1;
+        }
+        constexpr int kR[12] = {1, 1, 2, 2, 0, 3, 0, 3, 1, 1, 2, 2}, kC[12] = {0, 3, 0, 3, 1, 1, 2, 2, 1, 2, 1, 2};
+        vec* dst[12];
+        vec val[12][CJ], old[12][CJ];
 #pragma unroll
-            for (int q = 0; q < V; ++q) lds_add(dst + (j * V + q) * 64, vget<V>(v, q));
+        for (int k = 0; k < 12; ++k) {
+          const int o = (xo[kC[k]] | yo[kR[k]]) < 0 ? TW * TH * kSlotV : xo[kC[k]] + yo[kR[k]];
+          dst[k] = sAccV + o + lane;
+        }
+        // gx of tap (ix, iy) = hx (T[tx + 1] - T[tx - 1]), gy = hy (T[ty + 1] - T[ty - 1]); an inner texel also takes its tap's own
+        // value, the x-neighbour tap's gx (it is that tap's right / left neighbour) and the y-neighbour tap's gy
+        const float k8[8] = {-cgx[0], cgx[1], -cgx[2], cgx[3], -cgy[0], cgy[2], -cgy[1], cgy[3]};
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) val[k][j] = k8[k] * agx[j];
+#pragma unroll
+          for (int k = 4; k < 8; ++k) val[k][j] = k8[k] * agy[j];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int ix = t & 1, iy = t >> 1;
+            const float kx = ix ? cgx[2 * iy] : -cgx[2 * iy + 1], ky = iy ? cgy[ix] : -cgy[2 + ix];
+            val[8 + t][j] = cf[t] * af[j] + kx * agx[j] + ky * agy[j];
           }
         }
-      };
 #pragma unroll
-      for (int iy = 0; iy < 2; ++iy) {
-        put1(x0 - 1, y0 + iy, -cgx[2 * iy], agx);          // gx of tap (0, iy) = hx (T[tx + 1] - T[tx - 1])
-        put1(x0 + 2, y0 + iy, cgx[2 * iy + 1], agx);
+        for (int k = 0; k < 12; ++k)
+#pragma unroll
+          for (int j = 0; j < CJ; ++j) old[k][j] = dst[k][j * 64];
+#pragma unroll
+        for (int k = 0; k < 12; ++k)
+#pragma unroll
+          for (int j = 0; j < CJ; ++j) dst[k][j * 64] = old[k][j] + val[k][j];
       }
-#pragma unroll
-      for (int ix = 0; ix < 2; ++ix) {
-        put1(x0 + ix, y0 - 1, -cgy[ix], agy);
-        put1(x0 + ix, y0 + 2, cgy[2 + ix], agy);
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int ix = t & 1, iy = t >> 1;
-        // the tap's own value, the x-neighbour tap's gx (this texel is its right / left neighbour), the y-neighbour tap's gy
-        if (float* dst = slot(x0 + ix, y0 + iy)) {
-          const float kx = ix ? cgx[2 * iy] : -cgx[2 * iy + 1], ky = iy ? cgy[ix] : -cgy[2 + ix];
-#pragma unroll
-          for (int j = 0; j < CJ; ++j) {
-            const vec v = cf[t] * af[j] + kx * agx[j] + ky * agy[j];
-#pragma unroll
-            for (int q = 0; q < V; ++q) lds_add(dst + (j * V + q) * 64, vget<V>(v, q));
-          }
-        }
-      }
-      // ---- advance
+      // ---- advance: everything requested above has had the arithmetic to arrive
       if (p1.i < 0) break;
+      wait_vm0();
       ra0 = rb0;
       ra1 = rb1;
       rb0 = rc0;
@@ -1499,10 +1532,10 @@ __global__ __launch_bounds__(64) void adj_tile_kernel(const AdjArgs a, int tiles
           for (int cc = 0; cc < 4; ++cc)
 #pragma unroll
             for (int j = 0; j < CJ; ++j) tex[r][cc][j] = texn[r][cc][j];
-        nxt = next_cell(true);
+        nxt = next_cell();
         if (nxt >= 0) {
           cell_range(nxt, sn, Ln);
-          load_tex(nxt, texn);
+          want_texn = true;             // requested at the top of the next iteration
         }
       }
       p0 = p1;
@@ -1517,13 +1550,7 @@ __global__ __launch_bounds__(64) void adj_tile_kernel(const AdjArgs a, int tiles
 #pragma unroll
     for (int j = 0; j < CJ; ++j) {
       if (!cok[j]) continue;
-      vec v;
-      if constexpr (V == 1) {
-        v = sAcc[(size_t)(t * CJ + j) * 64 + lane];
-      } else {
-#pragma unroll
-        for (int q = 0; q < V; ++q) v[q] = sAcc[(size_t)((t * CJ + j) * V + q) * 64 + lane];
-      }
+      const vec v = sAccV[(t * CJ + j) * 64 + lane];
       vec* o = reinterpret_cast<vec*>(out_b + (size_t)(Y * W + X) * C + coff[j]);
       *o = a.overwrite_map ? v : *o + v;
     }
@@ -1932,36 +1959,40 @@ void adj_plan(const banet_level_t* lv, int flags, AdjPlan* pl) {
   pl->bytes = o;
 }
 
-// ---- launch of the tile kernel: (channel chunks, vector width) by C; 8 x 8 texel tiles (BANET_ADJOINT_TILE_8X4: 8 x 4, A/B) ----
+// ---- launch of the tile kernel: (channel chunks, vector width) by C; tile shape by flags bits 4-6 (A/B) ----
 template <int CJ, int V, int TW, int TH>
 void launch_adj_tile_t(const AdjArgs& a, hipStream_t s) {
   const int tiles_x = (a.lv.W + TW - 1) / TW, ntiles = tiles_x * ((a.lv.H + TH - 1) / TH);
   const int total = ntiles * a.lv.B, chunk = (total + 7) / 8;
-  const size_t shm = (size_t)TW * TH * CJ * V * 64 * sizeof(float);
+  const size_t shm = (size_t)(TW * TH + 1) * CJ * V * 64 * sizeof(float);     // + the dummy slot
   if (shm > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&adj_tile_kernel<CJ, V, TW, TH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
   hipLaunchKernelGGL((adj_tile_kernel<CJ, V, TW, TH>), dim3(8 * chunk), dim3(64), shm, s, a, tiles_x, ntiles, total, chunk);
 }
 template <int CJ, int V>
-void launch_adj_tile_cv(const AdjArgs& a, bool small, hipStream_t s) {
-  if (small)
-    launch_adj_tile_t<CJ, V, 8, 4>(a, s);
-  else
-    launch_adj_tile_t<CJ, V, 8, 8>(a, s);
+void launch_adj_tile_cv(const AdjArgs& a, int shape, hipStream_t s) {
+  switch (shape) {      // LDS per wave at C = 128 / waves per CU / visits per pixel
+    case 1: launch_adj_tile_t<CJ, V, 8, 4>(a, s); break;     // 16.5 KB / 9 / 2.4
+    case 2: launch_adj_tile_t<CJ, V, 4, 4>(a, s); break;     //  8.5 KB / 18 / 3.1
+    case 3: launch_adj_tile_t<CJ, V, 8, 2>(a, s); break;     //  8.5 KB / 18 / 3.4
+    case 4: launch_adj_tile_t<CJ, V, 8, 7>(a, s); break;     // 28.5 KB / 5 / 2.0
+    case 5: launch_adj_tile_t<CJ, V, 4, 2>(a, s); break;     //  4.5 KB / 32 / 4.4
+    default: launch_adj_tile_t<CJ, V, 8, 4>(a, s); break;
+  }
 }
-void launch_adj_tile(const AdjArgs& a, bool small, hipStream_t s) {
+void launch_adj_tile(const AdjArgs& a, int shape, hipStream_t s) {
   const int C = a.lv.C;
   if ((C & 1) == 0) {
     if (C <= 128)
-      launch_adj_tile_cv<1, 2>(a, small, s);
+      launch_adj_tile_cv<1, 2>(a, shape, s);
     else
-      launch_adj_tile_cv<2, 2>(a, small, s);
+      launch_adj_tile_cv<2, 2>(a, shape, s);
   } else if (C <= 64) {
-    launch_adj_tile_cv<1, 1>(a, small, s);
+    launch_adj_tile_cv<1, 1>(a, shape, s);
   } else if (C <= 128) {
-    launch_adj_tile_cv<2, 1>(a, small, s);
+    launch_adj_tile_cv<2, 1>(a, shape, s);
   } else {
-    launch_adj_tile_cv<4, 1>(a, small, s);
+    launch_adj_tile_cv<4, 1>(a, shape, s);
   }
 }
 
@@ -2113,7 +2144,7 @@ int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T
     const int2* cs = reinterpret_cast<const int2*>(a.start);
     hipLaunchKernelGGL(adj_cellsort_kernel, dim3((HW + 255) / 256, B), dim3(256), 0, s, cs, a.list, a.frac, a.lrec, a.bigq, N, HW, pl.bigq_cap);
     hipLaunchKernelGGL(adj_bigcell_kernel, dim3(64), dim3(256), 0, s, cs, a.list, a.list2, a.frac, a.lrec, a.bigq, N, HW, pl.bigq_cap);
-    launch_adj_tile(a, (flags & BANET_ADJOINT_TILE_8X4) != 0, s);
+    launch_adj_tile(a, (flags >> 4) & 7, s);      // BANET_ADJOINT_TILE_SHAPE(k): development switch, 0 = default
   } else {
     const dim3 grid(pl.Gm, B), block(kBlock);
     launch_adj_map(a, lv->C, grid, block, s);

@@ -222,10 +222,18 @@ def _small_step(tensors, N, l2_base, pairs=1, camera=False):
 
 
 ADJOINT_OVERWRITE, ADJOINT_OVERWRITE_MAP = 1, 2      # banet_hip.h: BANET_ADJOINT_OVERWRITE, BANET_ADJOINT_OVERWRITE_MAP
-ADJOINT_FOLD_TARGET, ADJOINT_TILE_8X4 = 4, 16         # banet_hip.h: BANET_ADJOINT_FOLD_TARGET, BANET_ADJOINT_TILE_8X4 (A/B)
+ADJOINT_FOLD_TARGET = 4                               # banet_hip.h: BANET_ADJOINT_FOLD_TARGET
+
+
+def ADJOINT_TILE_SHAPE(k):
+    """banet_hip.h: BANET_ADJOINT_TILE_SHAPE(k) -- development switch (A/B): 1 = 8x4, 2 = 4x4, 3 = 8x2, 4 = 8x7, 5 = 4x2 texel tiles"""
+    return (int(k) & 7) << 4
+
+
 # the backward of a dense level writes the target map's gradient per texel tile (round 6) instead of 3C adjoint rows + a per-texel
-# gather + the [f|gx|gy] map adjoint + its fold: BANET_ADJOINT_FOLD=0 keeps the round-5 path (A/B), =2 the 8x4-tile variant (A/B)
+# gather + the [f|gx|gy] map adjoint + its fold: BANET_ADJOINT_FOLD=0 keeps the round-5 path (A/B); BANET_ADJOINT_TILE=k the tile shape (A/B)
 FOLD_MODE = os.environ.get("BANET_ADJOINT_FOLD", "1")
+TILE_SHAPE = int(os.environ.get("BANET_ADJOINT_TILE", "0"))
 
 
 def dense_adjoint(problem, R, T, Wc, gAtA, gAtb, gabs, dsrc, dmap3, ddepth, dbasis, ws=None, overwrite=False, overwrite_map=None,
@@ -306,7 +314,7 @@ class _LevelSolve(torch.autograd.Function):
         # no zero-fills: the first adjoint call that touches a buffer writes it (BANET_ADJOINT_OVERWRITE), the later ones accumulate --
         # 25 GB of fills and as many bytes of reads per 32-window 640x480 level
         fold = FOLD_MODE != "0"          # the target gradient per texel tile: no 3C rows, no [f|gx|gy] map adjoint, no fold pass
-        xflags = ADJOINT_TILE_8X4 if FOLD_MODE == "2" else 0
+        xflags = ADJOINT_TILE_SHAPE(TILE_SHAPE)
         dsrc = torch.empty((B, N, C), dtype=torch.float32, device=dev)
         dmap3 = [torch.empty((B, H, W, C if fold else 3 * C), dtype=torch.float32, device=dev) for _ in range(pairs)]
         ddepth = torch.empty((B, N), dtype=torch.float32, device=dev)

@@ -38,7 +38,7 @@ def _scene(H, W, C, K, seed, B=2, scales=(1,)):
     return intr, levels, R, T, Wc, rng
 
 
-def _run_adjoint(intr, lv, R, T, Wc, G, gb, gabs, variant="bundle", overwrite=False, fold=False, tile8x4=False):
+def _run_adjoint(intr, lv, R, T, Wc, G, gb, gabs, variant="bundle", overwrite=False, fold=False, tile=0):
     """fold: BANET_ADJOINT_FOLD_TARGET (round 6) -- the target gradient straight from the tile kernel, no dmap3 / fold pass"""
     from banet_amd import dense as bdense, dense_train
     B, H, W, C = lv["src"].shape
@@ -53,7 +53,7 @@ def _run_adjoint(intr, lv, R, T, Wc, G, gb, gabs, variant="bundle", overwrite=Fa
     if fold:
         dpose, _ = dense_train.dense_adjoint(prob, t(R), t(T), t(Wc), t(G), t(gb).reshape(B, -1), t(gabs).reshape(B, -1),
                                             out["dsrc"], dtgt, out["ddepth"], out["dbasis"], overwrite=overwrite, fold=True,
-                                            extra_flags=dense_train.ADJOINT_TILE_8X4 if tile8x4 else 0)
+                                            extra_flags=dense_train.ADJOINT_TILE_SHAPE(tile))
         torch.cuda.synchronize()
         return dict(dsrc=out["dsrc"], ddepth=out["ddepth"], dbasis=out["dbasis"], dpose=dpose, dtgt=dtgt)
     dpose, _ = dense_train.dense_adjoint(prob, t(R), t(T), t(Wc), t(G), t(gb).reshape(B, -1), t(gabs).reshape(B, -1),

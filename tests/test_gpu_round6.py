@@ -27,11 +27,11 @@ def _want(intr, lv, R, T, Wc, G, gb, gabs, H, W):
     return oadj.assembly_adjoint(a, lv64["tgt"], f32(R), f32(T), f32(Wc), f32(G), f32(gb), f32(gabs) * H * W)
 
 
-@pytest.mark.parametrize("tile8x4", [False, True])
+@pytest.mark.parametrize("tile", [0, 2, 3, 4, 5])
 @pytest.mark.parametrize("H,W,C,K,seed", [(24, 32, 6, 5, 3), (48, 64, 128, 128, 7), (30, 41, 70, 33, 11), (9, 11, 3, 1, 5),
                                           (16, 16, 64, 16, 2), (17, 33, 130, 40, 9), (20, 24, 256, 64, 4), (15, 21, 128, 128, 6),
-                                          (9, 7, 16, 8, 8), (37, 50, 129, 8, 12), (26, 19, 255, 4, 13)])
-def test_target_tile_adjoint_matches_the_float64_statement_and_the_row_gather_path(H, W, C, K, seed, tile8x4):
+                                          (9, 7, 16, 8, 8), (37, 50, 131, 8, 12), (26, 19, 255, 4, 13)])
+def test_target_tile_adjoint_matches_the_float64_statement_and_the_row_gather_path(H, W, C, K, seed, tile):
     """every (channel chunks, vector width) instantiation: even C <= 128 / <= 256 (two channels per lane), odd C <= 64 / <= 128 / <= 256"""
     intr, levels, R, T, Wc, rng = _scene(H, W, C, K, seed)
     lv = levels[0]
@@ -40,18 +40,25 @@ def test_target_tile_adjoint_matches_the_float64_statement_and_the_row_gather_pa
     gb = rng.standard_normal((B, P, 1))
     gabs = rng.standard_normal((B, 1, C)) * 0.1
     want = _want(intr, lv, R, T, Wc, G, gb, gabs, H, W)
-    got = _run_adjoint(intr, lv, R, T, Wc, G, gb, gabs, fold=True, tile8x4=tile8x4)
+    # sign(d) (the adjoint of sum |d|) is undecidable in float32 where the float64 residual is below rounding: no upstream
+    # gradient on the channels that hold such an element (a handful at most; the smooth synthetic features cross zero somewhere)
+    tiny = (np.abs(want["fwd"]["diff"]) < 1e-5) & want["fwd"]["mask"][..., None]
+    if tiny.any():
+        gabs = gabs * (~tiny.any(axis=1))[:, None, :]
+        assert (gabs != 0).mean() > 0.8
+        want = _want(intr, lv, R, T, Wc, G, gb, gabs, H, W)
+    got = _run_adjoint(intr, lv, R, T, Wc, G, gb, gabs, fold=True, tile=tile)
     old = _run_adjoint(intr, lv, R, T, Wc, G, gb, gabs)
     assert want["fwd"]["mask"].mean() > 0.5
-    for name, w in (("dsrc", want["dsrc"]), ("dtgt", want["dtgt"]), ("ddepth", want["dD0"]), ("dbasis", want["dbasis"])):
-        g = n(got[name]).reshape(w.shape)
-        err = np.abs(g - w).max() / max(np.abs(w).max(), 1e-30)
-        assert err < 2e-4, (name, err)
     # the other outputs do not depend on the mode at all; the target gradient only through the summation order
     for k in ("dsrc", "ddepth", "dbasis", "dpose"):
         assert torch.equal(got[k], old[k]), k
     scale = float(old["dtgt"].abs().max())
     assert float((got["dtgt"] - old["dtgt"]).abs().max()) <= 2e-5 * scale
+    for name, w in (("dsrc", want["dsrc"]), ("dtgt", want["dtgt"]), ("ddepth", want["dD0"]), ("dbasis", want["dbasis"])):
+        g = n(got[name]).reshape(w.shape)
+        err = np.abs(g - w).max() / max(np.abs(w).max(), 1e-30)
+        assert err < 2e-4, (name, err)
 
 
 def test_target_tile_adjoint_is_bit_reproducible_and_overwrite_equals_accumulation():
