@@ -93,6 +93,9 @@ EXPORTS = {
     "banet_dense_adjoint_workspace_bytes_ex": (ctypes.c_size_t, [ctypes.POINTER(Level), ctypes.c_int]),
     "banet_dense_adjoint_f32": (ctypes.c_int, [ctypes.POINTER(Level)] + [_FP] * 11 + [_FP, ctypes.c_size_t, _FP]),
     "banet_dense_adjoint_ex_f32": (ctypes.c_int, [ctypes.POINTER(Level)] + [_FP] * 11 + [ctypes.c_int, _FP, ctypes.c_size_t, _FP]),
+    "banet_small_step_adjoint_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 6),
+    "banet_small_step_adjoint_f32": (ctypes.c_int, [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.POINTER(Mlp)] + [_FP] * 14 +
+                                     [ctypes.POINTER(Mlp), _FP, ctypes.c_size_t, _FP]),
     "banet_target_map_adjoint_f32": (ctypes.c_int, [_FP] * 2 + [ctypes.c_int] * 4 + [_FP]),
     "banet_target_map_adjoint_ex_f32": (ctypes.c_int, [_FP] * 2 + [ctypes.c_int] * 5 + [_FP]),
     "banet_build_id": (ctypes.c_char_p, []),

@@ -421,6 +421,27 @@ int banet_target_map_adjoint_f32(const float* dmap3, float* dimg, int B, int H, 
   return banet_target_map_adjoint_ex_f32(dmap3, dimg, B, H, W, C, 0, stream);
 }
 
+size_t banet_small_step_adjoint_workspace_bytes(int variant, int B, int N, int C, int K, int pairs) {
+  return small_step_workspace_bytes(variant, B, N, C, K, pairs);
+}
+
+int banet_small_step_adjoint_f32(int variant, int B, int N, int C, int K, int pairs, float l2_regularizer_base, const banet_mlp_t* mlp,
+                                 const float* AtA, const float* Atb, const float* absres, const float* delta, const float* R,
+                                 const float* T, const float* gR, const float* gT, const float* gW, float* gAtA, float* gAtb, float* gabs,
+                                 float* dR, float* dT, const banet_mlp_t* gmlp, void* ws, size_t ws_bytes, banet_stream_t stream) {
+  if (!mlp || !gmlp || !AtA || !Atb || !absres || !delta || !R || !T || !gR || !gT || !gAtA || !gAtb || !gabs || !dR || !dT || !ws)
+    return BANET_ERR_INVALID_ARG;
+  if (K > 0 && !gW) return BANET_ERR_INVALID_ARG;
+  for (int i = 0; i < 5; ++i)
+    if (!mlp->w[i] || !mlp->b[i] || !gmlp->w[i] || !gmlp->b[i]) return BANET_ERR_INVALID_ARG;
+  if (B <= 0 || N <= 0 || C <= 0 || K < 0 || pairs < 1) return BANET_ERR_INVALID_ARG;
+  const size_t need = small_step_workspace_bytes(variant, B, N, C, K, pairs);
+  if (need == 0) return BANET_ERR_UNSUPPORTED;
+  if (ws_bytes < need || (reinterpret_cast<uintptr_t>(ws) & 255) != 0) return BANET_ERR_WORKSPACE;
+  return launch_small_step_adjoint(variant, B, N, C, K, pairs, l2_regularizer_base, mlp, AtA, Atb, absres, delta, R, T, gR, gT, gW, gAtA,
+                                   gAtb, gabs, dR, dT, gmlp, ws, static_cast<hipStream_t>(stream));
+}
+
 #include "build_id.h"   // generated by build.sh: BANET_BUILD_ID
 const char* banet_build_id(void) { return BANET_BUILD_ID; }
 

@@ -5,7 +5,7 @@ cd "$(dirname "$0")"
 OUT=${BANET_BUILD_OUT:-../lib}     # BANET_BUILD_OUT: a second build (e.g. -DBANET_TIMING) next to the product library
 mkdir -p "$OUT"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-inline-asm"
-SRCS="gather gather128 gather128p gather128s gather128q syrk syrk_wide assemble eqcon eqcon_syrk eqcon_grad solve prep sstats adjoint api"
+SRCS="gather gather128 gather128p gather128s gather128q syrk syrk_wide assemble eqcon eqcon_syrk eqcon_grad solve prep sstats adjoint smallstep api"
 # build id: digest of every kernel source + the compile flags (banet_build_id(); bench.py ties PMC traffic files to it).
 # Only api.o depends on it, and the header is rewritten only when the digest changes.
 BID=$( { cat $(ls *.hip *.hpp | sort) ../../include/banet_hip.h; echo "$FLAGS ${EXTRA_HIPCC_FLAGS:-}"; } | sha256sum | cut -c1-16)

@@ -161,6 +161,7 @@ struct SolveArgs {
 };
 int launch_solve(const SolveArgs& a, hipStream_t s);
 int launch_spd_solve(const float* A, const float* rhs, float* x, int B, int P, hipStream_t s);   // 32 <= P, matrix in LDS
+bool spd_solve_fits(int P);     // launch_spd_solve accepts this size
 size_t solve_big_bytes(int B, int P, int C);
 void launch_ctl_init(LmCtl* ctl, int32_t* iters, int B, hipStream_t s);
 void launch_zero_iters(int32_t* iters, int B, hipStream_t s);
@@ -183,5 +184,13 @@ int launch_sample_stats_grad_det(const float* conv1, const float* conv2, const f
                                  int H, int W, const float* dstats, const float* dabs, float* dconv1, float* dconv2, float* dpos,
                                  void* ws, hipStream_t s);
 int launch_target_map_adjoint(const float* dmap3, float* dimg, int B, int H, int W, int C, int overwrite, hipStream_t s);
+
+// ---- smallstep.hip: backward of the small part of an iteration (lambda MLP, damping, solve, SE(3) / W update) ----
+bool small_step_supported(int variant, int B, int N, int C, int K, int pairs);
+size_t small_step_workspace_bytes(int variant, int B, int N, int C, int K, int pairs);
+int launch_small_step_adjoint(int variant, int B, int N, int C, int K, int pairs, float l2_base, const banet_mlp_t* mlp, const float* AtA,
+                              const float* Atb, const float* absres, const float* delta, const float* R, const float* T, const float* gR,
+                              const float* gT, const float* gW, float* gAtA, float* gAtb, float* gabs, float* dR, float* dT,
+                              const banet_mlp_t* gmlp, void* ws, hipStream_t s);
 
 }  // namespace banet

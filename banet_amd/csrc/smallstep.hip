@@ -15,6 +15,8 @@
 //   small_wgrad_kernel  the ten lambda-weight gradients, summed over the windows in window order (fixed order: bit-reproducible),
 //                       ACCUMULATED into the caller's buffers (the iterations of a level share them)
 // dL/dWc = gW' (W' = W + sol): the caller keeps it.
+#include <algorithm>
+
 #include "kernels.hpp"
 #include "mlp.hpp"
 
@@ -334,7 +336,7 @@ __global__ void small_wgrad_kernel(const SmallArgs a) {
   float s = 0.f;
   for (int b = 0; b < a.B; ++b) s = fmaf(i < nin ? hp[(size_t)b * rs] : 1.f, dp[(size_t)b * rs], s);
   if (i < nin)
-    a.gmlp.w[l][(size_t)i * nout + o] += s;
+    const_cast<float*>(a.gmlp.w[l])[(size_t)i * nout + o] += s;      // (banet_mlp_t's members are const float*: the caller's gradient buffers)
   else
     const_cast<float*>(a.gmlp.b[l])[o] += s;
 }
@@ -371,11 +373,7 @@ bool small_step_supported(int variant, int B, int N, int C, int K, int pairs) {
   } else {
     return false;
   }
-  if (P >= 32) {                       // the solve runs on spd_solve_kernel: its matrix must fit the LDS
-    float dummy = 0.f;
-    (void)dummy;
-    return launch_spd_solve(nullptr, nullptr, nullptr, 0, P, nullptr) == BANET_OK;
-  }
+  if (P >= 32) return spd_solve_fits(P);      // the solve runs on spd_solve_kernel: its matrix must fit the LDS
   return true;
 }
 

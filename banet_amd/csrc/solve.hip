@@ -909,6 +909,8 @@ static size_t spd_solve_lds_bytes(int P) {
   return fl * sizeof(float);
 }
 
+bool spd_solve_fits(int P) { return P >= kGrid && spd_solve_lds_bytes(P) <= 160 * 1024; }
+
 int launch_spd_solve(const float* A, const float* rhs, float* x, int B, int P, hipStream_t s) {
   if (P < kGrid) return BANET_ERR_UNSUPPORTED;                 // the blocked factorisation wants at least two panels
   const size_t lds = spd_solve_lds_bytes(P);

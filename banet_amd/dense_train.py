@@ -221,6 +221,57 @@ def _small_step(tensors, N, l2_base, pairs=1, camera=False):
     return st(tensors)
 
 
+# the backward's small step (lambda MLP / damping / solve / SE(3) update adjoint) as four HIP launches (banet_small_step_adjoint_f32,
+# csrc/smallstep.hip, round 6) instead of the ~150-launch torch graph above; BANET_SMALL_STEP_HIP=0 keeps the torch graph (A/B)
+SMALL_STEP_HIP = os.environ.get("BANET_SMALL_STEP_HIP", "1") != "0"
+
+
+class SmallStepHip:
+    """Per level-backward state of the HIP small step: the accumulated lambda-weight gradients (ten tensors, zero-initialised;
+    every call adds to them on the device) and the workspace."""
+
+    def __init__(self, variant, B, N, C, K, pairs, mlp, l2_base, dev):
+        self.args = (ops._VARIANT_OF[variant] if isinstance(variant, str) else int(variant), int(B), int(N), int(C), int(K), int(pairs))
+        self.l2, self.mlp, self.dev = float(l2_base), mlp, dev
+        nb = capi.lib().banet_small_step_adjoint_workspace_bytes(*self.args)
+        if nb == 0:
+            raise capi.BanetError("small step: unsupported shape")
+        self.ws = capi.workspace(nb, dev)
+        dims = [C, 2 * C, 4 * C, 2 * C, C, 1]
+        self.glayers = []
+        for i in range(5):
+            self.glayers += [torch.zeros(dims[i], dims[i + 1], dtype=torch.float32, device=dev),
+                             torch.zeros(dims[i + 1], dtype=torch.float32, device=dev)]
+        self.g = capi.Mlp()
+        for i in range(5):
+            self.g.w[i] = self.glayers[2 * i].data_ptr()
+            self.g.b[i] = self.glayers[2 * i + 1].data_ptr()
+
+    @staticmethod
+    def supported(variant, B, N, C, K, pairs, dev):
+        v = ops._VARIANT_OF[variant] if isinstance(variant, str) else int(variant)
+        return (SMALL_STEP_HIP and torch.device(dev).type == "cuda" and
+                capi.lib().banet_small_step_adjoint_workspace_bytes(v, int(B), int(N), int(C), int(K), int(pairs)) > 0)
+
+    def __call__(self, AtA, Atb, absres, delta, R, T, gR, gT, gW):
+        """-> (gAtA [B,P,P], gAtb [B,P], gabs [B,C], dR [B,pairs,3,3], dT [B,pairs,3,1]); dL/dWc = gW is the caller's."""
+        v, B, N, C, K, pairs = self.args
+        P = 6 * pairs + K
+        dev = self.dev
+        f = capi.f32c
+        ins = [f(AtA), f(Atb), f(absres), f(delta), f(R), f(T), f(gR), f(gT), f(gW) if K else None]
+        gAtA = torch.empty((B, P, P), dtype=torch.float32, device=dev)
+        gAtb = torch.empty((B, P), dtype=torch.float32, device=dev)
+        gabs = torch.empty((B, C), dtype=torch.float32, device=dev)
+        dR = torch.empty((B, pairs, 3, 3), dtype=torch.float32, device=dev)
+        dT = torch.empty((B, pairs, 3, 1), dtype=torch.float32, device=dev)
+        capi.check(capi.lib().banet_small_step_adjoint_f32(
+            v, B, N, C, K, pairs, self.l2, ctypes.byref(self.mlp.c), *[capi.ptr(x) if x is not None else None for x in ins],
+            capi.ptr(gAtA), capi.ptr(gAtb), capi.ptr(gabs), capi.ptr(dR), capi.ptr(dT), ctypes.byref(self.g),
+            ctypes.c_void_p(self.ws.data_ptr()), self.ws.numel(), capi.stream()))
+        return gAtA, gAtb, gabs, dR, dT
+
+
 ADJOINT_OVERWRITE, ADJOINT_OVERWRITE_MAP = 1, 2      # banet_hip.h: BANET_ADJOINT_OVERWRITE, BANET_ADJOINT_OVERWRITE_MAP
 ADJOINT_FOLD_TARGET = 4                               # banet_hip.h: BANET_ADJOINT_FOLD_TARGET
 
@@ -295,7 +346,7 @@ class _LevelSolve(torch.autograd.Function):
             Ri, Ti, Wi = st.R.clone(), st.T.clone(), st.Wc.clone()
             AtA, Atb, absres, nvalid = ops.ba_assemble(prob, st.R, st.T, st.Wc)
             sws = ops.ba_solve_update(prob, mlp, ba.l2_base, AtA, Atb, absres, nvalid, st, sws)
-            saved.append((Ri, Ti, Wi, AtA, Atb, absres))
+            saved.append((Ri, Ti, Wi, AtA, Atb, absres, st.delta.clone()))
         ctx.ba, ctx.li, ctx.saved = ba, li, saved
         ctx.layers = flat_layers
         ctx.shapes = (src.shape, tgt.shape, depth.shape, None if basis is None else basis.shape, R.shape, T.shape)
@@ -320,7 +371,6 @@ class _LevelSolve(torch.autograd.Function):
         ddepth = torch.empty((B, N), dtype=torch.float32, device=dev)
         dbasis = torch.empty((B, N, K), dtype=torch.float32, device=dev)
         flat = ctx.layers
-        glayers = [torch.zeros_like(t) for t in flat]
         gR = torch.zeros(B, pairs, 3, 3, device=dev) if gR is None else gR.reshape(B, pairs, 3, 3)
         gT = torch.zeros(B, pairs, 3, 1, device=dev) if gT is None else gT.reshape(B, pairs, 3, 1)
         gW = torch.zeros(B, K, 1, device=dev) if gW is None else gW.reshape(B, K, 1)
@@ -330,13 +380,21 @@ class _LevelSolve(torch.autograd.Function):
         if not ctx.saved:                                  # (no iteration ran: nothing writes the buffers)
             for t in [dsrc, ddepth, dbasis] + dmap3:
                 t.zero_()
-        for Ri, Ti, Wi, AtA, Atb, absres in reversed(ctx.saved):
+        hip_small = SmallStepHip(ba.variant, B, N, C, K, pairs, ba.mlps[li], ba.l2_base, dev) \
+            if SmallStepHip.supported(ba.variant, B, N, C, K, pairs, dev) else None
+        glayers = None if hip_small is not None else [torch.zeros_like(t) for t in flat]
+        for Ri, Ti, Wi, AtA, Atb, absres, delta in reversed(ctx.saved):
             Rv, Tv = Ri.reshape(B, pairs, 3, 3), Ti.reshape(B, pairs, 3, 1)
-            grads = _small_step([AtA, Atb, absres, Rv, Tv, Wi, gR, gT, gW] + [t.detach() for t in flat], N, ba.l2_base, pairs, camera)
-            gAtA, gAtb, gabs, dR, dT, dW = grads[:6]
-            for acc, g in zip(glayers, grads[6:]):
-                acc += g
-            gR, gT, gW = dR.reshape(B, pairs, 3, 3).clone(), dT.reshape(B, pairs, 3, 1).clone(), dW.reshape(B, K, 1).clone()
+            if hip_small is not None:       # four launches; the lambda-weight gradients accumulate on the device
+                gAtA, gAtb, gabs, dR, dT = hip_small(AtA, Atb, absres, delta, Rv, Tv, gR, gT, gW)
+                gR, gT = dR, dT             # (gW: W' = W + sol, the upstream gradient passes through)
+                gW = gW.clone()
+            else:
+                grads = _small_step([AtA, Atb, absres, Rv, Tv, Wi, gR, gT, gW] + [t.detach() for t in flat], N, ba.l2_base, pairs, camera)
+                gAtA, gAtb, gabs, dR, dT, dW = grads[:6]
+                for acc, g in zip(glayers, grads[6:]):
+                    acc += g
+                gR, gT, gW = dR.reshape(B, pairs, 3, 3).clone(), dT.reshape(B, pairs, 3, 1).clone(), dW.reshape(B, K, 1).clone()
             for i in range(pairs):
                 if pairs == 1:
                     gA_i, gb_i = gAtA, gAtb
@@ -363,6 +421,8 @@ class _LevelSolve(torch.autograd.Function):
                 di = torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
                 target_map_adjoint(dmap3[i], di, overwrite=True)
                 dtgt[:, i] = di
+        if hip_small is not None:
+            glayers = [g.reshape(t.shape) for g, t in zip(hip_small.glayers, flat)]
         s_src, s_tgt, s_dep, s_bas, s_R, s_T = ctx.shapes
         return (None, None, None, dsrc.reshape(s_src), dtgt.reshape(s_tgt), ddepth.reshape(s_dep),
                 None if s_bas is None else dbasis.reshape(s_bas), gR.reshape(s_R), gT.reshape(s_T), gW) + tuple(glayers)
@@ -422,7 +482,8 @@ class _SparseIteration(torch.autograd.Function):
         W0 = st.Wc.clone() if K else torch.zeros(nb, 0, 1, device=conv1.device)
         ops.ba_solve_update(prob, mlp, l2_base, AtA, Atb, absres, nvalid, st)
         ctx.prob, ctx.l2, ctx.camera = prob, float(l2_base), K == 0
-        ctx.saved = (R0, T0, W0, AtA, Atb, absres)
+        ctx.variant, ctx.mlp = variant, mlp
+        ctx.saved = (R0, T0, W0, AtA, Atb, absres, st.delta.clone())
         ctx.flat = flat_layers
         ctx.shapes = (conv1.shape, conv2.shape, D.shape, None if Bs is None else Bs.shape, R.shape, T.shape, None if W is None else W.shape)
         ctx.last = dict(AtA=AtA, Atb=Atb, lam=st.lambda_out.clone(), delta=st.delta.clone())
@@ -436,14 +497,20 @@ class _SparseIteration(torch.autograd.Function):
         B, N, C, K = prob.B, prob.N, prob.C, prob.K
         H, Wd = prob.c.H, prob.c.W
         dev = prob.device
-        R0, T0, W0, AtA, Atb, absres = ctx.saved
+        R0, T0, W0, AtA, Atb, absres, delta = ctx.saved
         gR = torch.zeros(B, 1, 3, 3, device=dev) if gR is None else gR.reshape(B, 1, 3, 3)
         gT = torch.zeros(B, 1, 3, 1, device=dev) if gT is None else gT.reshape(B, 1, 3, 1)
         gW = torch.zeros(B, K, 1, device=dev) if (gW is None or K == 0) else gW.reshape(B, K, 1)
         flat = ctx.flat
-        grads = _small_step([AtA, Atb, absres, R0.reshape(B, 1, 3, 3), T0.reshape(B, 1, 3, 1), W0, gR.contiguous(), gT.contiguous(),
-                             gW.contiguous()] + [t.detach() for t in flat], N, ctx.l2, 1, ctx.camera)
-        gAtA, gAtb, gabs, dR, dT, dW = grads[:6]
+        if SmallStepHip.supported(ctx.variant, B, N, C, K, 1, dev):       # four launches (csrc/smallstep.hip)
+            hs = SmallStepHip(ctx.variant, B, N, C, K, 1, ctx.mlp, ctx.l2, dev)
+            gAtA, gAtb, gabs, dR, dT = hs(AtA, Atb, absres, delta, R0.reshape(B, 1, 3, 3), T0.reshape(B, 1, 3, 1), gR, gT, gW)
+            dW, glayers = gW, tuple(g.reshape(t.shape) for g, t in zip(hs.glayers, flat))
+        else:
+            grads = _small_step([AtA, Atb, absres, R0.reshape(B, 1, 3, 3), T0.reshape(B, 1, 3, 1), W0, gR.contiguous(), gT.contiguous(),
+                                 gW.contiguous()] + [t.detach() for t in flat], N, ctx.l2, 1, ctx.camera)
+            gAtA, gAtb, gabs, dR, dT, dW = grads[:6]
+            glayers = tuple(grads[6:])
         dsrc = torch.empty((B, N, C), dtype=torch.float32, device=dev)
         dmap3 = torch.empty((B, H, Wd, 3 * C), dtype=torch.float32, device=dev)
         ddepth = torch.empty((B, N), dtype=torch.float32, device=dev)
@@ -454,7 +521,7 @@ class _SparseIteration(torch.autograd.Function):
         s1, s2, sD, sB, sR, sT, sW = ctx.shapes
         dWn = None if K == 0 else (dW.reshape(B, K, 1) + dpose[:, 12:].reshape(B, K, 1)).reshape(sW)
         return (None, None, None, dsrc.reshape(s1), dmap3.reshape(s2), ddepth.reshape(sD), None if sB is None else dbasis.reshape(sB),
-                dR.reshape(sR), dT.reshape(sT), dWn, None, None, None, None, None) + tuple(grads[6:])
+                dR.reshape(sR), dT.reshape(sT), dWn, None, None, None, None, None) + glayers
 
 
 def sparse_iteration_supported(conv1, conv2, Bs):

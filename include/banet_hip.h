@@ -356,6 +356,26 @@ int banet_target_map_adjoint_f32(const float* dmap3, float* dimg, int B, int H, 
 int banet_target_map_adjoint_ex_f32(const float* dmap3, float* dimg, int B, int H, int W, int C, int flags,
                                     banet_stream_t stream);
 
+/* (7c) backward of the SMALL part of one BundleIteration / CameraIteration (round 6) -- what tf.gradients derives for
+ *     bundlenet.py:165-190 / :241-276 after the EquationConstruction op: avg = sum|d| / (N pairs) -> lambda MLP -> lambda = l2
+ *     ||avg||^(2 + y) -> damping (bundle: last coefficient undamped, :264-266; bundle_camera: all six, no l2, :181-182) ->
+ *     tf.matrix_solve -> SE(3) / W update (AngleaAxisRotation :17-37, VMatrix :39-46).  Four launches instead of a ~150-launch
+ *     framework graph.  Inputs: the assembly outputs AtA [B,P,P], Atb [B,P], absres [B,C] (= sum |d|), the forward's solution
+ *     delta [B,P] (banet_state_t.delta), the state BEFORE the update R [B,pairs,9], T [B,pairs,3], and the upstream gradients of
+ *     the updated state gR [B,pairs,9], gT [B,pairs,3], gW [B,K].  Outputs (written): gAtA [B,P,P] (not symmetrised -- (7b) does
+ *     that), gAtb [B,P], gabs [B,C] = dL/d absres, dR [B,pairs,9], dT [B,pairs,3] = the direct dependence of (R', T') on (R, T);
+ *     dL/dWc = gW (W' = W + sol) is the caller's.  gmlp: the ten lambda-weight gradients, ACCUMULATED (+=, summed over the
+ *     windows in window order: bit-reproducible) -- zero them before the first iteration of a level.  The damped system is solved
+ *     by implicit differentiation on banet_spd_solve_f32's kernel (lam = A^-1 dL/dsol, dL/dA = -lam sol^T, dL/dAtb = lam): P must
+ *     fit it (32 <= P <= ~190) or be < 32 (pose only: in-kernel Cholesky); C <= 256; variant BANET_BUNDLE (K >= 1) or
+ *     BANET_BUNDLE_CAMERA (K = 0); else workspace_bytes = 0 and BANET_ERR_UNSUPPORTED.                                        */
+size_t banet_small_step_adjoint_workspace_bytes(int variant, int B, int N, int C, int K, int pairs);
+int banet_small_step_adjoint_f32(int variant, int B, int N, int C, int K, int pairs, float l2_regularizer_base,
+                                 const banet_mlp_t* mlp, const float* AtA, const float* Atb, const float* absres,
+                                 const float* delta, const float* R, const float* T, const float* gR, const float* gT,
+                                 const float* gW, float* gAtA, float* gAtb, float* gabs, float* dR, float* dT,
+                                 const banet_mlp_t* gmlp, void* ws, size_t ws_bytes, banet_stream_t stream);
+
 /* (8) optional kernel timing, used by bench.py for the roofline figure.  Between
  *     banet_profile_begin and banet_profile_end every launch of the fused assembly kernel
  *     (from banet_ba_assemble_f32 / banet_lm_level_f32) is bracketed by two hipEvents recorded

@@ -140,3 +140,99 @@ def test_solve_differentiable_fold_and_row_gather_backward_agree(monkeypatch):
         for x, y in zip(res["1"], res["0"]):
             assert torch.isfinite(x).all()
             assert float((x - y).abs().max()) <= 2e-5 * max(float(y.abs().max()), 1e-30)
+
+
+@pytest.mark.parametrize("variant,B,C,K,pairs,l2", [("bundle", 3, 128, 128, 1, 1000.0), ("bundle", 2, 32, 40, 3, 1.0),
+                                                    ("bundle_camera", 4, 16, 0, 1, 1.0), ("bundle", 2, 70, 33, 1, 10.0),
+                                                    ("bundle", 1, 256, 64, 2, 1000.0)])
+def test_small_step_adjoint_kernels_match_the_float64_torch_graph(variant, B, C, K, pairs, l2):
+    """banet_small_step_adjoint_f32 (csrc/smallstep.hip: lambda MLP forward + backward, damping, the solve by implicit
+    differentiation, the SE(3) / W update adjoint) against autograd through dense_train.solve_update_graph -- the statements
+    bundlenet.py:165-190 / 241-276 -- evaluated in FLOAT64 on the same inputs: every output, incl. the ten lambda-weight
+    gradients (accumulated over two calls) and the direct dL/d(R, T)."""
+    from banet_amd import dense_train, ops
+    from banet_amd.bundlenet import he_normal_lambda_weights
+    g = torch.Generator().manual_seed(1000 + C + K)
+    P, N = 6 * pairs + K, 4000
+    camera = variant == "bundle_camera"
+    M = torch.randn(B, P, P + 30, generator=g, dtype=torch.float64)
+    AtA = (M @ M.transpose(1, 2)) * 3.0
+    Atb = torch.randn(B, P, generator=g, dtype=torch.float64) * 2.0
+    absres = (torch.rand(B, C, generator=g, dtype=torch.float64) * 0.2 + 0.01) * N * pairs
+    R = torch.stack([torch.from_numpy(synth.rodrigues(0.05 * np.random.RandomState(i).standard_normal(3))) for i in range(B * pairs)]).reshape(B, pairs, 3, 3)
+    T = torch.randn(B, pairs, 3, 1, generator=g, dtype=torch.float64) * 0.1
+    Wc = torch.randn(B, K, 1, generator=g, dtype=torch.float64) * 0.05
+    gR, gT = torch.randn(B, pairs, 3, 3, generator=g, dtype=torch.float64), torch.randn(B, pairs, 3, 1, generator=g, dtype=torch.float64)
+    gW = torch.randn(B, K, 1, generator=g, dtype=torch.float64)
+    layers = [(w.double(), b.double()) for w, b in he_normal_lambda_weights(C, 7)]
+    # float64 statement: autograd through the graph
+    leaves = [t.clone().requires_grad_(True) for t in (AtA, Atb, absres, R, T, Wc)]
+    lw = [t.clone().requires_grad_(True) for wb in layers for t in (wb[0].reshape(wb[0].shape[-2], wb[0].shape[-1]), wb[1].reshape(-1))]
+    R2, T2, W2 = dense_train.solve_update_graph(leaves[0], leaves[1], leaves[2], N, leaves[3], leaves[4], leaves[5],
+                                                [(lw[2 * i], lw[2 * i + 1]) for i in range(5)], l2, pairs=pairs, camera=camera)
+    with torch.no_grad():       # the forward's solution, as the update kernel would leave it in banet_state_t.delta
+        lam_in = torch.linalg.vector_norm(absres / (N * pairs), dim=-1)
+    outs, seeds = ([R2, T2], [gR, gT]) if camera else ([R2, T2, W2], [gR, gT, gW])
+    want = torch.autograd.grad(outs, leaves + lw, seeds, allow_unused=True)
+    sol = (W2 - leaves[5]).detach().reshape(B, K) if K else torch.zeros(B, 0, dtype=torch.float64)
+    # pose part of sol: re-solve (the graph does not expose it)
+    with torch.no_grad():
+        h = (absres / (N * pairs)).unsqueeze(1)
+        a0 = h
+        for i, (w, b) in enumerate(layers):
+            z = torch.matmul(h, w.reshape(w.shape[-2], w.shape[-1])) + b.reshape(-1)
+            h = torch.tanh(z) if i == 4 else torch.nn.functional.selu(z)
+        lam = torch.linalg.vector_norm(a0, dim=-1, keepdim=True) ** (2.0 + h)
+        if not camera:
+            lam = l2 * lam
+        diag = torch.diagonal(AtA, dim1=1, dim2=2)
+        damp = diag + 1e-5 if camera else torch.cat([diag[:, :-1] + 1e-5, torch.zeros(B, 1, dtype=torch.float64)], -1)
+        delta = torch.linalg.solve(AtA + torch.diag_embed(damp * lam.squeeze(-1)), Atb.unsqueeze(-1)).reshape(B, P)
+    dev = torch.device(DEV)
+    mlp = ops.MlpWeights([(w.float(), b.float()) for w, b in layers], dev)
+    assert dense_train.SmallStepHip.supported(variant, B, N, C, K, pairs, dev)
+    hs = dense_train.SmallStepHip(variant, B, N, C, K, pairs, mlp, l2, dev)
+    c = lambda x: x.float().to(dev)
+    for _ in range(2):          # twice: the weight gradients accumulate
+        got = hs(c(AtA), c(Atb), c(absres), c(delta), c(R), c(T), c(gR), c(gT), c(gW))
+    torch.cuda.synchronize()
+    names = ["gAtA", "gAtb", "gabs", "dR", "dT"]
+    for name, gv, wv in zip(names, got, want[:5]):
+        wv = wv.reshape(gv.shape)
+        if name == "gAtA":      # the adjoint kernels symmetrise it; compare the symmetric parts
+            gv = 0.5 * (gv + gv.transpose(1, 2))
+            wv = 0.5 * (wv + wv.transpose(1, 2))
+        err = float((gv.double().cpu() - wv).abs().max()) / max(float(wv.abs().max()), 1e-30)
+        assert err < 2e-4, (name, err)
+    for i, (gv, wv) in enumerate(zip(hs.glayers, want[6:])):
+        err = float((gv.double().cpu() - 2.0 * wv.reshape(gv.shape)).abs().max()) / max(float(wv.abs().max()) * 2.0, 1e-30)
+        assert err < 5e-4, ("lambda weight %d" % i, err)
+
+
+def test_solve_differentiable_with_the_hip_small_step_equals_the_torch_small_step(monkeypatch):
+    """DenseBA.solve_differentiable: the backward's small step on csrc/smallstep.hip against the torch graph it replaces
+    (BANET_SMALL_STEP_HIP=0), two-frame and 3-frame windows -- every gradient to rounding.  (The two differ in how the forward's solution enters:
+    the kernels take the update kernel's own `delta`, the torch graph solves the damped system again.)"""
+    from banet_amd import dense as bdense, dense_train, synth as bsynth
+    from banet_amd.bundlenet import he_normal_lambda_weights
+    for frames in (2, 3):
+        B, H, W, C, K = 2, 48, 64, 32, 32
+        scales = [2, 1]
+        intr, levels, gt = bsynth.make_dense_windows(B, H, W, C, K, scales, 9, torch.device(DEV), trans_mag=0.06, pairs=frames - 1)
+        mlps = [[(w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)) for w, b in he_normal_lambda_weights(C, 100 + i)]
+                for i in range(len(scales))]
+        for lv in levels:
+            for name in ("src", "tgt", "depth", "basis"):
+                setattr(lv, name, getattr(lv, name).requires_grad_(True))
+        ba = bdense.DenseBA(intr, levels, mlps, "bundle", 1000.0)
+        T0 = (gt["T"] * 0.7).reshape(B * (frames - 1), 3, 1).to(DEV)
+        leaves = [getattr(lv, nm) for lv in levels for nm in ("src", "tgt", "depth", "basis")] + [x for lw in mlps for wb in lw for x in wb]
+        res = {}
+        for mode in (True, False):
+            monkeypatch.setattr(dense_train, "SMALL_STEP_HIP", mode)
+            Rr, Tt, Ww = ba.solve_differentiable([2, 2], T=T0)
+            loss = (Rr * torch.arange(Rr.numel(), device=DEV).reshape(Rr.shape).float().cos()).sum() + Tt.sum() + (Ww * 0.5).sum()
+            res[mode] = torch.autograd.grad(loss, leaves)
+        for x, y in zip(res[True], res[False]):
+            assert torch.isfinite(x).all()
+            assert float((x - y).abs().max()) <= 2e-4 * max(float(y.abs().max()), 1e-30)
