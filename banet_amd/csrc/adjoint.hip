@@ -68,6 +68,7 @@ struct AdjArgs {
   // fold mode (round 6, adj_tile_kernel): dmap3 is the target map's gradient itself, [B][H][W][C]
   float* lrec;        // [B][N][kFrac]  the records in cell-list order, key replaced by the pixel index
   int* list2;         // [B][N]         scratch of the big-cell sort
+  int2* lidx;         // [B][N]         (pixel index, x0 | y0 << 16) in cell-list order: what adj_tile2_kernel addresses with
   int* bigq;          // [1 + B*N/32]   queue of the cells with more than kSortSerial entries (bigq[0] = their number)
 };
 
@@ -1187,7 +1188,8 @@ constexpr int kSortSerial = 32;     // cells with up to this many pixels are ord
 // One thread per target cell: order the cell's pixel list (adj_fill_kernel's slots come from an atomic cursor) and write the
 // records in list order, key replaced by the pixel index.  Fuller cells (a collapsed warp) go to the big-cell queue.
 __global__ void adj_cellsort_kernel(const int2* __restrict__ cs, int* __restrict__ list, const float* __restrict__ frac,
-                                    float* __restrict__ lrec, int* __restrict__ bigq, int N, int HW, int bigq_cap) {
+                                    float* __restrict__ lrec, int2* __restrict__ lidx, int* __restrict__ bigq, int N, int HW, int W,
+                                    int bigq_cap) {
   const int b = blockIdx.y, cell = blockIdx.x * blockDim.x + threadIdx.x;
   if (cell >= HW) return;
   const int2 v = cs[(size_t)b * HW + cell];
@@ -1210,11 +1212,14 @@ __global__ void adj_cellsort_kernel(const int2* __restrict__ cs, int* __restrict
   }
   const float* __restrict__ fr = frac + (size_t)b * N * kFrac;
   float* __restrict__ lr = lrec + ((size_t)b * N + s0) * kFrac;
+  int2* __restrict__ lx = lidx + (size_t)b * N + s0;
+  const int cy = cell / W, cxy = (cell - cy * W) | (cy << 16);      // (W, H < 65536)
   for (int i = 0; i < L; ++i) {
     const int n = li[i];
     const f32x4 r0 = *reinterpret_cast<const f32x4*>(fr + (size_t)n * kFrac), r1 = *reinterpret_cast<const f32x4*>(fr + (size_t)n * kFrac + 4);
     *reinterpret_cast<f32x4*>(lr + (size_t)i * kFrac) = f32x4{__int_as_float(n), r0[1], r0[2], r0[3]};
     *reinterpret_cast<f32x4*>(lr + (size_t)i * kFrac + 4) = r1;
+    lx[i] = make_int2(n, cxy);
   }
 }
 
@@ -1222,7 +1227,8 @@ __global__ void adj_cellsort_kernel(const int2* __restrict__ cs, int* __restrict
 // degenerate warp (hundreds of pixels in one texel cell) gets here; adj_map_kernel's per-texel selection had the same order.
 __global__ __launch_bounds__(256) void adj_bigcell_kernel(const int2* __restrict__ cs, int* __restrict__ list, int* __restrict__ list2,
                                                           const float* __restrict__ frac, float* __restrict__ lrec,
-                                                          const int* __restrict__ bigq, int N, int HW, int bigq_cap) {
+                                                          int2* __restrict__ lidx, const int* __restrict__ bigq, int N, int HW, int W,
+                                                          int bigq_cap) {
   const int nbig = min(bigq[0], bigq_cap);
   for (int qi = blockIdx.x; qi < nbig; qi += gridDim.x) {
     const int gc = bigq[1 + qi], b = gc / HW;
@@ -1239,11 +1245,14 @@ __global__ __launch_bounds__(256) void adj_bigcell_kernel(const int2* __restrict
     __syncthreads();
     const float* __restrict__ fr = frac + (size_t)b * N * kFrac;
     float* __restrict__ lr = lrec + ((size_t)b * N + s0) * kFrac;
+    int2* __restrict__ lx = lidx + (size_t)b * N + s0;
+    const int cell = gc - b * HW, cy = cell / W, cxy = (cell - cy * W) | (cy << 16);
     for (int e = threadIdx.x; e < L; e += 256) {
       const int n = lo[e];
       const f32x4 r0 = *reinterpret_cast<const f32x4*>(fr + (size_t)n * kFrac), r1 = *reinterpret_cast<const f32x4*>(fr + (size_t)n * kFrac + 4);
       *reinterpret_cast<f32x4*>(lr + (size_t)e * kFrac) = f32x4{__int_as_float(n), r0[1], r0[2], r0[3]};
       *reinterpret_cast<f32x4*>(lr + (size_t)e * kFrac + 4) = r1;
+      lx[e] = make_int2(n, cxy);
     }
     __syncthreads();
     for (int e = threadIdx.x; e < L; e += 256) li[e] = lo[e];     // (the list itself in order too: diagnostics, the old per-texel path)
@@ -1554,6 +1563,244 @@ __global__ __launch_bounds__(64) void adj_tile_kernel(const AdjArgs a, int tiles
       vec* o = reinterpret_cast<vec*>(out_b + (size_t)(Y * W + X) * C + coff[j]);
       *o = a.overwrite_map ? v : *o + v;
     }
+  }
+}
+
+// ---- two visits per wave instruction (C % 4 == 0, C <= 128): a HALF wave per pixel, 4 channels per lane --------------------------
+// adj_tile_kernel above is bound by VALU issue: ~450 instructions per visit of which only a third is channel arithmetic (measured:
+// no tile shape moves it, 1420 SIMD cycles per visit).  Here lanes 0-31 and 32-63 work on two different pixels of the tile's walking
+// order (visit k and visit k + half: the two halves of the sequence, so that the pair's footprints are usually disjoint), every
+// per-pixel quantity is a per-lane value, every row access one 16-byte load per lane: the same instruction stream serves two visits.
+//   * walking order = the cell rows' list segments back to back; a lane finds its list index by a select chain over the row table
+//     (<= TH + 3 rows, uniform); lidx gives (pixel, cell), lrec the fractions and the five scalars;
+//   * two register sets (this pair / next pair), the loop unrolled twice so that nothing is copied; the (pixel, cell) pair two
+//     iterations ahead; one full s_waitcnt vmcnt(0) per iteration after the arithmetic (see adj_tile_kernel);
+//   * accumulators: (TH + 1) x (TW + 1) slots of 32 lanes x 16 bytes -- the extra row and column take what falls outside the tile,
+//     so a destination's address is row offset + column offset (unsigned min clamps either to the dummy), no select per texel;
+//   * the two halves' 12-texel footprints may overlap: then the read-modify-write runs half by half (two exec-masked phases, in
+//     order: deterministic), else once for the whole wave.
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+template <int TW, int TH>
+__global__ __launch_bounds__(64) void adj_tile2_kernel(const AdjArgs a, int tiles_x, int ntiles, int total, int chunk) {
+  constexpr int MAXR = TH + 3, SW = TW + 1, SH = TH + 1;
+  extern __shared__ __attribute__((aligned(16))) float sAcc[];
+  f32x4* sAccV = reinterpret_cast<f32x4*>(sAcc);               // slot (uy, ux), lane hl: (uy SW + ux) 32 + hl
+  const int lane = threadIdx.x, hl = lane & 31, hi = lane >> 5;
+  const int kk = blockIdx.x >> 3, work = (blockIdx.x & 7) * chunk + kk;
+  if (kk >= chunk || work >= total) return;
+  const int b = work / ntiles, tile = work - b * ntiles;
+  const int tyi = tile / tiles_x, tx0 = (tile - tyi * tiles_x) * TW, ty0 = tyi * TH;
+  const int N = a.lv.N, C = a.lv.C, H = a.lv.H, W = a.lv.W, HW = H * W;
+  const float* __restrict__ src_b = a.lv.src + (size_t)b * N * C;
+  const float* __restrict__ tgt_b = a.lv.tgt + (size_t)b * HW * C;
+  const float* __restrict__ lrec = a.lrec + (size_t)b * N * kFrac;
+  const int2* __restrict__ lidx = a.lidx + (size_t)b * N;
+  const int2* __restrict__ cs = reinterpret_cast<const int2*>(a.start) + (size_t)b * HW;
+  const bool cok = 4 * hl < C;
+  const int coff = cok ? 4 * hl : 0;
+  f32x4 ga = *reinterpret_cast<const f32x4*>(a.gabs + (size_t)b * C + coff);
+  if (!cok) ga = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = lane; i < SH * SW * 32; i += 64) sAccV[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // the rows of cells whose pixels can touch the tile, their list segments, the running visit count (all uniform)
+  const int cxa = max(tx0 - 2, 0), cxb = min(tx0 + TW, W - 1);
+  const int cya = max(ty0 - 2, 0), cyb = min(ty0 + TH, H - 1), ncy = cyb - cya + 1;
+  int rsv = 0, cntv = 0;
+  if (lane < ncy) {
+    const int2 c0 = cs[(cya + lane) * W + cxa], c1 = cs[(cya + lane) * W + cxb];
+    rsv = c0.x;
+    cntv = c1.x + c1.y - c0.x;
+  }
+  // visit v of row r has list index v + base_r, base_r = (start of the row's segment) - (visits before the row); a lane adds up the
+  // steps base_r - base_{r-1} of the rows it has passed (a sum of conditional terms: a select CHAIN over base_r is turned into a
+  // lookup table in scratch memory by the compiler, one scratch load per index)
+  int cum[MAXR + 1], step[MAXR];
+  cum[0] = 0;
+  int prev = 0;
+#pragma unroll
+  for (int r = 0; r < MAXR; ++r) {
+    const int cnt = __builtin_amdgcn_readlane(cntv, r);         // (rows >= ncy hold 0)
+    const int bs = __builtin_amdgcn_readlane(rsv, r) - cum[r];
+    step[r] = bs - prev;
+    prev = bs;
+    cum[r + 1] = cum[r] + cnt;
+  }
+  const int nv = cum[MAXR], half = (nv + 1) >> 1;
+  auto list_index = [&](int k) -> int {      // the list index of this lane's visit in iteration k (clamped to a valid one)
+    const int v = min(k + hi * half, nv - 1);
+    int idx = v + step[0];
+#pragma unroll
+    for (int r = 1; r < MAXR; ++r) idx += step[r] & -(int)(v >= cum[r]);
+    return idx;
+  };
+  struct Set {                 // one pair of visits: everything its arithmetic needs
+    f32x3 r0;                  // (ax, ay, dg1) -- 12 bytes: a 16-byte load would leave a dead register (the pixel index) that the
+    f32x4 r1;                  // compiler re-uses at once, waiting for the load it belongs to;  (dg2, dM11, dM12, dM22)
+    f32x4 f1;                  // the pixel's source row, this lane's 4 channels
+    f32x4 tex[4][4];           // the 4x4-minus-corners target texels of its cell
+    int xy;                    // x0 | y0 << 16
+  };
+  auto request = [&](int i, const int2 nx, Set& q) {
+    q.r0 = *reinterpret_cast<const f32x3*>(lrec + (size_t)i * kFrac + 1);
+    q.r1 = *reinterpret_cast<const f32x4*>(lrec + (size_t)i * kFrac + 4);
+    q.f1 = *reinterpret_cast<const f32x4*>(src_b + (size_t)nx.x * C + coff);
+    q.xy = nx.y;
+    const int cx = nx.y & 0xffff, cy = nx.y >> 16;
+    unsigned xo[4], yo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      xo[k] = (unsigned)min(max(cx - 1 + k, 0), W - 1) * (unsigned)C + (unsigned)coff;
+      yo[k] = (unsigned)min(max(cy - 1 + k, 0), H - 1) * ((unsigned)W * (unsigned)C);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        if ((r == 0 || r == 3) && (cc == 0 || cc == 3)) continue;
+        q.tex[r][cc] = *reinterpret_cast<const f32x4*>(tgt_b + (yo[r] + xo[cc]));
+      }
+  };
+  auto work_on = [&](int k, const Set& q) {
+    const bool live = k + hi * half < nv;                       // (an odd count: the upper half idles in the last iteration)
+    const int x0 = q.xy & 0xffff, y0 = q.xy >> 16;
+    const float ax = q.r0[0], ay = q.r0[1], dg1 = q.r0[2], dg2 = q.r1[0], dM11 = q.r1[1], dM12 = q.r1[2], dM22 = q.r1[3];
+    float cf[4], cgx[4], cgy[4];      // tap weight x (in image, gx defined, gy defined): adj_pixel*_kernel's wt, fin, hx, hy
+    const bool inner = x0 >= 1 && y0 >= 1 && x0 + 2 <= W - 1 && y0 + 2 <= H - 1;
+    if (__all(inner)) {               // (wave-uniform) both footprints inside the image, off the rim
+      const float bx = 1.f - ax, by = 1.f - ay;
+      cf[0] = bx * by, cf[1] = ax * by, cf[2] = bx * ay, cf[3] = ax * ay;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) cgx[t] = cgy[t] = 0.5f * cf[t];
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int ix = t & 1, iy = t >> 1;
+        const int tx = x0 + ix, ty = y0 + iy;
+        const bool in = tx <= W - 1 && ty <= H - 1;
+        const float hx = (in && tx > 0 && tx < W - 1) ? 0.5f : 0.f, hy = (in && ty > 0 && ty < H - 1) ? 0.5f : 0.f;
+        const float wx = ix ? ax : 1.f - ax, wy = iy ? ay : 1.f - ay;
+        const float wt = wx * wy;
+        cf[t] = in ? wt : 0.f;
+        cgx[t] = wt * hx;
+        cgy[t] = wt * hy;
+      }
+    }
+    f32x4 Sf = cf[0] * q.tex[1][1] + cf[1] * q.tex[1][2] + cf[2] * q.tex[2][1] + cf[3] * q.tex[2][2];
+    f32x4 Sgx = cgx[0] * (q.tex[1][2] - q.tex[1][0]) + cgx[1] * (q.tex[1][3] - q.tex[1][1]) + cgx[2] * (q.tex[2][2] - q.tex[2][0]) +
+                cgx[3] * (q.tex[2][3] - q.tex[2][1]);
+    f32x4 Sgy = cgy[0] * (q.tex[2][1] - q.tex[0][1]) + cgy[1] * (q.tex[2][2] - q.tex[0][2]) + cgy[2] * (q.tex[3][1] - q.tex[1][1]) +
+                cgy[3] * (q.tex[3][2] - q.tex[1][2]);
+    f32x4 f1 = q.f1;
+    if (!cok || !live) {
+      Sf = Sgx = Sgy = f32x4{0.f, 0.f, 0.f, 0.f};
+      f1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const f32x4 d = f1 - Sf;
+    f32x4 sg;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sg[e] = d[e] > 0.f ? 1.f : (d[e] < 0.f ? -1.f : 0.f);
+    const f32x4 af = -(dg1 * Sgx + dg2 * Sgy + sg * ga);
+    const f32x4 agx = 2.f * (dM11 * Sgx + dM12 * Sgy) + dg1 * d;
+    const f32x4 agy = 2.f * (dM12 * Sgx + dM22 * Sgy) + dg2 * d;
+    // ---- grad_fixed^T into the tile (see adj_tile_kernel); footprint column cc / row r -> slot column ux + cc / row uy + r, clamped
+    // (unsigned) to the dummy column TW / row TH; an idle half goes to the dummy corner altogether
+    const int ux = live ? x0 - 1 - tx0 : TW, uy = live ? y0 - 1 - ty0 : TH;
+    unsigned xo[4], yo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      xo[k] = min((unsigned)(ux + k), (unsigned)TW) * 32u + (unsigned)hl;
+      yo[k] = min((unsigned)(uy + k), (unsigned)TH) * (unsigned)(SW * 32);
+    }
+    constexpr int kR[12] = {1, 1, 2, 2, 0, 3, 0, 3, 1, 1, 2, 2}, kC[12] = {0, 3, 0, 3, 1, 1, 2, 2, 1, 2, 1, 2};
+    const float k8[8] = {-cgx[0], cgx[1], -cgx[2], cgx[3], -cgy[0], cgy[2], -cgy[1], cgy[3]};
+    // do the two halves' footprints overlap?  (uniform: the other half's cell through a lane read)
+    const int xyo = __builtin_amdgcn_readlane(q.xy, 32), xyl = __builtin_amdgcn_readlane(q.xy, 0);
+    const int ddx = (xyo & 0xffff) - (xyl & 0xffff), ddy = (xyo >> 16) - (xyl >> 16);
+    const bool apart = ddx >= 4 || ddx <= -4 || ddy >= 4 || ddy <= -4 || k + half >= nv;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {         // two groups of six destinations: 48 registers of values + old contents at a time
+      f32x4 val[6];
+      f32x4* dst[6];
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int kd = 6 * g + u;
+        dst[u] = sAccV + (yo[kR[kd]] + xo[kC[kd]]);
+        if (kd < 4) {
+          val[u] = k8[kd] * agx;
+        } else if (kd < 8) {
+          val[u] = k8[kd] * agy;
+        } else {
+          const int t = kd - 8, ix = t & 1, iy = t >> 1;
+          const float kx = ix ? cgx[2 * iy] : -cgx[2 * iy + 1], ky = iy ? cgy[ix] : -cgy[2 + ix];
+          val[u] = cf[t] * af + kx * agx + ky * agy;
+        }
+      }
+      if (apart) {
+        f32x4 old[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) old[u] = *dst[u];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) *dst[u] = old[u] + val[u];
+      } else {
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+          if (hi == ph) {
+            f32x4 old[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) old[u] = *dst[u];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) *dst[u] = old[u] + val[u];
+          }
+          // the other half reads what this half wrote: lanes of one wave, but different THREADS to the compiler -- without the
+          // fence it may move the second phase's loads above the first phase's (exec-masked) stores
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // (and the next visit's reads stay behind this visit's writes)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+
+  if (nv > 0) {
+    Set A, B;
+    int2 nx1, nx2 = make_int2(0, 0);
+    {
+      const int i0 = list_index(0);
+      const int2 nx0 = lidx[i0];
+      request(i0, nx0, A);
+      nx1 = lidx[list_index(1)];          // (clamped: valid even when there is no second iteration)
+    }
+    wait_vm0();
+    for (int k = 0; k < half; k += 2) {
+      // iteration k on A: request k + 1 into B, the (pixel, cell) of k + 2.  Unconditionally (list_index clamps past the end: the
+      // last iteration requests a valid pair it never uses) -- a conditional request makes the compiler merge the register set with
+      // its old contents by copies that wait for the loads just issued
+      request(list_index(k + 1), nx1, B);
+      nx2 = lidx[list_index(k + 2)];
+      work_on(k, A);
+      wait_vm0();
+      nx1 = nx2;
+      if (k + 1 >= half) break;
+      // iteration k + 1 on B: request k + 2 into A
+      request(list_index(k + 2), nx1, A);
+      nx2 = lidx[list_index(k + 3)];
+      work_on(k + 1, B);
+      wait_vm0();
+      nx1 = nx2;
+    }
+  }
+  // ---- the tile's texels: written once (overwrite_map) or added to the gradient of the earlier iterations; a half wave per texel
+  float* __restrict__ out_b = a.dmap3 + (size_t)b * HW * C;
+  for (int t2 = 0; t2 < TW * TH; t2 += 2) {
+    const int t = t2 + hi;
+    const int uy = t / TW, ux = t - uy * TW, X = tx0 + ux, Y = ty0 + uy;
+    if (t >= TW * TH || X >= W || Y >= H || !cok) continue;
+    const f32x4 v = sAccV[(uy * SW + ux) * 32 + hl];
+    f32x4* o = reinterpret_cast<f32x4*>(out_b + (size_t)(Y * W + X) * C + coff);
+    *o = a.overwrite_map ? v : *o + v;
   }
 }
 
@@ -1913,7 +2160,7 @@ struct AdjPlan {
   int fold;           // adj_tile_kernel instead of the 3C rows + per-texel gather (BANET_ADJOINT_FOLD_TARGET)
   int bigq_cap;
   size_t off_S, off_z2, off_arec, off_arow, off_frac, off_cnt, off_start, off_cursor, off_list, off_part, off_chunks, off_lrec, off_list2,
-      bytes;
+      off_lidx, bytes;
 };
 
 bool adj_supported(const banet_level_t* lv) {
@@ -1956,6 +2203,7 @@ void adj_plan(const banet_level_t* lv, int flags, AdjPlan* pl) {
   pl->off_chunks = take(B * ((HW + 1023) / 1024) * 4);
   pl->off_lrec = pl->fold ? take(B * N * kFrac * 4) : 0;
   pl->off_list2 = pl->fold ? take(B * N * 4) : 0;
+  pl->off_lidx = pl->fold ? take(B * N * 8) : 0;
   pl->bytes = o;
 }
 
@@ -1980,8 +2228,28 @@ void launch_adj_tile_cv(const AdjArgs& a, int shape, hipStream_t s) {
     default: launch_adj_tile_t<CJ, V, 8, 4>(a, s); break;
   }
 }
+template <int TW, int TH>
+void launch_adj_tile2_t(const AdjArgs& a, hipStream_t s) {
+  const int tiles_x = (a.lv.W + TW - 1) / TW, ntiles = tiles_x * ((a.lv.H + TH - 1) / TH);
+  const int total = ntiles * a.lv.B, chunk = (total + 7) / 8;
+  const size_t shm = (size_t)(TW + 1) * (TH + 1) * 32 * 16;       // 512 bytes per slot, one dummy row and column
+  hipLaunchKernelGGL((adj_tile2_kernel<TW, TH>), dim3(8 * chunk), dim3(64), shm, s, a, tiles_x, ntiles, total, chunk);
+}
+
 void launch_adj_tile(const AdjArgs& a, int shape, hipStream_t s) {
   const int C = a.lv.C;
+  if ((C & 3) == 0 && C <= 128 && (shape == 0 || shape >= 8) && a.lv.W < 65536 && a.lv.H < 65536) {     // two visits per wave instruction
+    switch (shape) {     // LDS per wave / waves per CU by LDS / visits per pixel
+      case 9: launch_adj_tile2_t<8, 3>(a, s); break;      // 18.4 KB / 8 / 2.75
+      case 10: launch_adj_tile2_t<8, 5>(a, s); break;     // 27.6 KB / 5 / 2.2
+      case 11: launch_adj_tile2_t<8, 7>(a, s); break;     // 36.9 KB / 4 / 1.96
+      case 12: launch_adj_tile2_t<16, 3>(a, s); break;    // 34.8 KB / 4 / 2.4
+      case 13: launch_adj_tile2_t<16, 2>(a, s); break;    // 26.1 KB / 6 / 2.97
+      default: launch_adj_tile2_t<8, 4>(a, s); break;     // 23.0 KB / 7 / 2.4
+    }
+    return;
+  }
+  if (shape >= 8) shape = 0;
   if ((C & 1) == 0) {
     if (C <= 128)
       launch_adj_tile_cv<1, 2>(a, shape, s);
@@ -2064,6 +2332,7 @@ int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T
   a.part = reinterpret_cast<float*>(base + pl.off_part);
   a.lrec = pl.fold ? reinterpret_cast<float*>(base + pl.off_lrec) : nullptr;
   a.list2 = pl.fold ? reinterpret_cast<int*>(base + pl.off_list2) : nullptr;
+  a.lidx = pl.fold ? reinterpret_cast<int2*>(base + pl.off_lidx) : nullptr;
   a.bigq = pl.fold ? a.cnt + (size_t)B * HW : nullptr;
   a.G = pl.G;
   a.dsrc = dsrc;
@@ -2142,9 +2411,11 @@ int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T
   hipLaunchKernelGGL(adj_fill_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, a.frac, a.cursor, a.list, N, HW);
   if (pl.fold) {
     const int2* cs = reinterpret_cast<const int2*>(a.start);
-    hipLaunchKernelGGL(adj_cellsort_kernel, dim3((HW + 255) / 256, B), dim3(256), 0, s, cs, a.list, a.frac, a.lrec, a.bigq, N, HW, pl.bigq_cap);
-    hipLaunchKernelGGL(adj_bigcell_kernel, dim3(64), dim3(256), 0, s, cs, a.list, a.list2, a.frac, a.lrec, a.bigq, N, HW, pl.bigq_cap);
-    launch_adj_tile(a, (flags >> 4) & 7, s);      // BANET_ADJOINT_TILE_SHAPE(k): development switch, 0 = default
+    hipLaunchKernelGGL(adj_cellsort_kernel, dim3((HW + 255) / 256, B), dim3(256), 0, s, cs, a.list, a.frac, a.lrec, a.lidx, a.bigq, N, HW,
+                       lv->W, pl.bigq_cap);
+    hipLaunchKernelGGL(adj_bigcell_kernel, dim3(64), dim3(256), 0, s, cs, a.list, a.list2, a.frac, a.lrec, a.lidx, a.bigq, N, HW, lv->W,
+                       pl.bigq_cap);
+    launch_adj_tile(a, (flags >> 4) & 15, s);      // BANET_ADJOINT_TILE_SHAPE(k): development switch, 0 = default
   } else {
     const dim3 grid(pl.Gm, B), block(kBlock);
     launch_adj_map(a, lv->C, grid, block, s);

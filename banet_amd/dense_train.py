@@ -277,8 +277,9 @@ ADJOINT_FOLD_TARGET = 4                               # banet_hip.h: BANET_ADJOI
 
 
 def ADJOINT_TILE_SHAPE(k):
-    """banet_hip.h: BANET_ADJOINT_TILE_SHAPE(k) -- development switch (A/B): 1 = 8x4, 2 = 4x4, 3 = 8x2, 4 = 8x7, 5 = 4x2 texel tiles"""
-    return (int(k) & 7) << 4
+    """banet_hip.h: BANET_ADJOINT_TILE_SHAPE(k) -- development switch (A/B): 1 .. 5 = adj_tile_kernel with 8x4 / 4x4 / 8x2 / 8x7 / 4x2 texel tiles,
+    8 .. 13 = adj_tile2_kernel (two visits per wave instruction) with 8x4 / 8x3 / 8x5 / 8x7 / 16x3 / 16x2; 0 = the default"""
+    return (int(k) & 15) << 4
 
 
 # the backward of a dense level writes the target map's gradient per texel tile (round 6) instead of 3C adjoint rows + a per-texel

@@ -344,10 +344,10 @@ int banet_dense_adjoint_f32(const banet_level_t* lv, const float* R, const float
  *     tile, pixels in a fixed order (cells row-major, ascending pixel index): still no float atomics between waves, still
  *     bit-reproducible.  Neither the per-pixel 3C adjoint rows nor the [f|gx|gy] map adjoint exist, and banet_target_map_adjoint_f32
  *     is not called: 3C (N + HW) floats less memory per window, about a third of the backward's traffic.  The workspace layout
- *     differs: size it with banet_dense_adjoint_workspace_bytes_ex(lv, flags).  BANET_ADJOINT_TILE_SHAPE(k), k = 1 .. 5: development
- *     switch (A/B) -- the tile shape (8x4, 4x4, 8x2, 8x7, 4x2 texels); 0 = the default.                                              */
+ *     differs: size it with banet_dense_adjoint_workspace_bytes_ex(lv, flags).  BANET_ADJOINT_TILE_SHAPE(k), k = 1 .. 13: development
+ *     switch (A/B) -- the tile kernel and its tile shape (csrc/adjoint.hip::launch_adj_tile); 0 = the default.                                              */
 enum { BANET_ADJOINT_OVERWRITE = 1, BANET_ADJOINT_OVERWRITE_MAP = 2, BANET_ADJOINT_FOLD_TARGET = 4 };
-#define BANET_ADJOINT_TILE_SHAPE(k) (((k) & 7) << 4)
+#define BANET_ADJOINT_TILE_SHAPE(k) (((k) & 15) << 4)
 size_t banet_dense_adjoint_workspace_bytes_ex(const banet_level_t* lv, int flags);
 int banet_dense_adjoint_ex_f32(const banet_level_t* lv, const float* R, const float* T, const float* Wc, const float* gAtA,
                                const float* gAtb, const float* gabs, float* dsrc, float* dmap3, float* ddepth,

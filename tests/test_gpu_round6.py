@@ -27,7 +27,7 @@ def _want(intr, lv, R, T, Wc, G, gb, gabs, H, W):
     return oadj.assembly_adjoint(a, lv64["tgt"], f32(R), f32(T), f32(Wc), f32(G), f32(gb), f32(gabs) * H * W)
 
 
-@pytest.mark.parametrize("tile", [0, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [0, 1, 2, 4, 5, 9, 11, 12])
 @pytest.mark.parametrize("H,W,C,K,seed", [(24, 32, 6, 5, 3), (48, 64, 128, 128, 7), (30, 41, 70, 33, 11), (9, 11, 3, 1, 5),
                                           (16, 16, 64, 16, 2), (17, 33, 130, 40, 9), (20, 24, 256, 64, 4), (15, 21, 128, 128, 6),
                                           (9, 7, 16, 8, 8), (37, 50, 131, 8, 12), (26, 19, 255, 4, 13)])
