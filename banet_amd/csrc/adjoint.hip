@@ -1717,13 +1717,13 @@ __global__ __launch_bounds__(64) void adj_tile2_kernel(const AdjArgs a, int tile
     const int xyo = __builtin_amdgcn_readlane(q.xy, 32), xyl = __builtin_amdgcn_readlane(q.xy, 0);
     const int ddx = (xyo & 0xffff) - (xyl & 0xffff), ddy = (xyo >> 16) - (xyl >> 16);
     const bool apart = ddx >= 4 || ddx <= -4 || ddy >= 4 || ddy <= -4 || k + half >= nv;
+    {                                     // all 12 destinations at once: 48 registers of values + 48 of old contents
+      constexpr int ND = 12;
+      f32x4 val[ND];
+      f32x4* dst[ND];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {         // two groups of six destinations: 48 registers of values + old contents at a time
-      f32x4 val[6];
-      f32x4* dst[6];
-#pragma unroll
-      for (int u = 0; u < 6; ++u) {
-        const int kd = 6 * g + u;
+      for (int u = 0; u < ND; ++u) {
+        const int kd = u;
         dst[u] = sAccV + (yo[kR[kd]] + xo[kC[kd]]);
         if (kd < 4) {
           val[u] = k8[kd] * agx;
@@ -1736,20 +1736,20 @@ __global__ __launch_bounds__(64) void adj_tile2_kernel(const AdjArgs a, int tile
         }
       }
       if (apart) {
-        f32x4 old[6];
+        f32x4 old[ND];
 #pragma unroll
-        for (int u = 0; u < 6; ++u) old[u] = *dst[u];
+        for (int u = 0; u < ND; ++u) old[u] = *dst[u];
 #pragma unroll
-        for (int u = 0; u < 6; ++u) *dst[u] = old[u] + val[u];
+        for (int u = 0; u < ND; ++u) *dst[u] = old[u] + val[u];
       } else {
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {
           if (hi == ph) {
-            f32x4 old[6];
+            f32x4 old[ND];
 #pragma unroll
-            for (int u = 0; u < 6; ++u) old[u] = *dst[u];
+            for (int u = 0; u < ND; ++u) old[u] = *dst[u];
 #pragma unroll
-            for (int u = 0; u < 6; ++u) *dst[u] = old[u] + val[u];
+            for (int u = 0; u < ND; ++u) *dst[u] = old[u] + val[u];
           }
           // the other half reads what this half wrote: lanes of one wave, but different THREADS to the compiler -- without the
           // fence it may move the second phase's loads above the first phase's (exec-masked) stores

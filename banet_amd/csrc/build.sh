@@ -46,4 +46,7 @@ done
 OBJS=""
 for f in $SRCS; do OBJS="$OBJS $OUT/$f.o"; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libbanet_hip.so" $OBJS -ldl   # dlopen of the roctx marker library (assemble.hip)
+# what this run of the script did (bench.py puts it into its line as `build_mode`, next to the driver's build_exercised record)
+nsrc=$(echo $SRCS | wc -w)
+echo "build_id=$BID recompiled=${#names[@]} of $nsrc objects ($(date -u +%Y-%m-%dT%H:%M:%SZ))" > "$OUT/build_mode.txt"
 echo "built $OUT/libbanet_hip.so"

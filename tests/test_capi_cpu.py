@@ -330,19 +330,57 @@ def test_bench_compact_line_of_an_8_rank_run(tmp_path, capsys, monkeypatch):
     for rec in full["sweep"].values():
         if "parity" in rec:
             rec["parity"].update(max_pose_depth=1.8e-6, max_last=2.579e-3, max_last_ref32=1.728e-3)
+    # round 6: at N > 1 ranks the sweep holds BASELINE's two 8-GPU configurations, run by all ranks (bench.py main): configs[3] and
+    # configs[4], each with the whole job's value, the step time, the gather's roofline fraction and the slowest / fastest rank
+    one = dict(full["sweep"]["cfg3_5frame_B32"])
+    one.pop("parity", None)
+    full["sweep"] = {"cfg4_5frame_B256_dp8": dict(one, value=81234.5, n_gpus=8, windows_total=256, rank_ms_per_step_max=157.3,
+                                                  rank_ms_per_step_min=151.9),
+                     "cfg5_8frame_B64_dp8": dict(one, value=8650.1, n_gpus=8, windows_total=64, rank_ms_per_step_max=552.0,
+                                                 rank_ms_per_step_min=541.2)}
+    full.update(value_exact_syrk=190000.0, ms_per_step_exact_syrk=67.1, rank_ms_per_step_max=63.9, rank_ms_per_step_min=62.8,
+                build_mode="build_id=0123456789abcdef recompiled=0 of 18 objects (2026-10-01T00:00:00Z)")
     monkeypatch.setenv("BANET_BENCH_DETAIL_DIR", str(tmp_path))
     bench.emit(full)
     last = capsys.readouterr().out.strip().split("\n")[-1]
     assert len(last) < 4096, len(last)
     rec = json.loads(last)
+    assert set(rec["sweep"]) == {"cfg4_5frame_B256_dp8", "cfg5_8frame_B64_dp8"}
+    for e in rec["sweep"].values():
+        assert e["n_gpus"] == 8 and e["rank_ms_per_step_max"] >= e["rank_ms_per_step_min"] > 0 and e["value"] > 0 and "frac" in e
+    assert rec["value_exact_syrk"] == 190000.0 and rec["rank_ms_per_step_max"] == 63.9 and rec["build_mode"].startswith("build_id=")
     assert rec["n_gpus"] == 8 and rec["config"]["world_size"] == 8 and rec["config"]["backend"] == "nccl"
     assert "dp8" in rec["config"]["parallelism"] and rec["scaling"] == "weak"
     assert rec["parity"]["max_pose_depth"] == 3.9e-5 and rec["parity"]["max_last"] == 8.1e-5 and rec["parity"]["ok"] is True
     assert rec["roofline"]["syrk_form"].endswith("640x480:f16x2")
+
+
+def test_bench_compact_line_carries_the_round6_parity_fields(tmp_path, capsys, monkeypatch):
+    """1-rank line: per sweep entry [lambda / pose / damped depth, last coefficient, its float32 yardstick], `own_mask_max` where an
+    entry needed the GPU's mask bits, the l2_base = 1 scene of the headline parity and the `backward` block."""
+    import json
+    sys.path.insert(0, ROOT) if ROOT not in sys.path else None
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_run12_bench_detail.json")))
+    for name, rec in full["sweep"].items():
+        if "parity" in rec:
+            rec["parity"].update(max_pose_depth=1.8e-6, max_last=2.579e-3, max_last_ref32=1.728e-3,
+                                 own_mask_max=[2.2e-4, 0.31] if name == "B256_2frame" else None)
+    full["parity"]["large_step_scene"] = {"step_pose_depth": 4.1e-5, "max_last_ref32": 3.0e-3, "ok": True,
+                                          "per_level": {"640x480": {"step_last": 1.2e-3}, "40x30": {"step_last": 7e-5}}}
+    full["backward"] = {"ms": 99.0, "forward_only_ms": 13.5, "x_forward": 7.33, "peak_extra_GB": 19.99}
+    monkeypatch.setenv("BANET_BENCH_DETAIL_DIR", str(tmp_path))
+    bench.emit(full)
+    last = capsys.readouterr().out.strip().split("\n")[-1]
+    assert len(last) < 4096, len(last)
+    rec = json.loads(last)
     for name, e in rec["sweep"].items():
         if "parity" in e:                          # [lambda / pose / damped depth, last coefficient, its float32 yardstick]
             assert e["parity"] == [1.8e-6, 2.579e-3, 1.728e-3], name
             assert e["parity"][0] <= 1e-4 and e["parity"][1] <= max(1e-4, 2 * e["parity"][2])
+    assert rec["sweep"]["B256_2frame"]["own_mask_max"] == [2.2e-4, 0.31] and "own_mask_max" not in rec["sweep"]["B8_2frame"]
+    assert rec["parity"]["l2_base_1"] == [4.1e-5, 1.2e-3, 3.0e-3, True]
+    assert rec["backward"]["x_forward"] == 7.33
 
 
 def test_strip_gather_register_contract():
