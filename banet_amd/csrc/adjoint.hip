@@ -25,6 +25,7 @@
 // and, once per level after all iterations, target_map_adjoint_kernel: d tgt += dmap_f + grad_fixed^T (dmap_gx, dmap_gy)
 // (REFLECT rim: bundlenet.py:92-100).
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernels.hpp"
 #include "syrk_split.hpp"
@@ -65,6 +66,8 @@ struct AdjArgs {
   float* dpose;
   int overwrite;      // 1: dsrc / ddepth / dbasis are WRITTEN (every entry, zeros where nothing contributes) instead of accumulated
   int overwrite_map;  // 1: the same for dmap3
+  int abl;            // TIMING-ONLY ablations (BANET_ADJOINT_ABLATE bits, wrong results): 1 adj_basis6 without the z2 stores, 2 without
+                      // zeta (the basis re-read in accumulator layout), 4 adj_pixel2 without its target texel loads, 8 without its stores
   // fold mode (round 6, adj_tile_kernel): dmap3 is the target map's gradient itself, [B][H][W][C]
   float* lrec;        // [B][N][kFrac]  the records in cell-list order, key replaced by the pixel index
   int* list2;         // [B][N]         scratch of the big-cell sort
@@ -248,40 +251,60 @@ __global__ __launch_bounds__(kAdjB6Threads) void adj_basis6_kernel(const AdjArgs
       for (int jb = 0; jb < NB; ++jb)
 #pragma unroll
         for (int t = 0; t < 3; ++t) pb[jb][t] = *reinterpret_cast<const u32x4_t*>(&sB6[(((ks * NB + jb) * 3 + t) * 64 + lane) * 4]);
+      // round 6: the SEED block is the A operand and the basis rows the B operand -- S_dd is symmetric and the extra block is kept
+      // transposed, so the LDS image serves either way -- which transposes the product: lane (m, rq) then holds coefficients
+      // 16 jb + 4 rq .. + 3 of pixel m, four CONSECUTIVE floats: z2 and the basis re-read of zeta are 16-byte accesses (the old layout
+      // -- lane = column, four rows -- needed 32 scattered 4-byte loads and stores per block: 56 % of the kernel's time by ablation)
 #pragma unroll
       for (int t = 0; t < 6; ++t)       // term-major: consecutive MFMAs write different accumulators
 #pragma unroll
         for (int jb = 0; jb < NB; ++jb)
-          acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8a, pa[kTa[t]]), __builtin_bit_cast(bf16x8a, pb[jb][kTb[t]]),
+          acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8a, pb[jb][kTb[t]]), __builtin_bit_cast(bf16x8a, pa[kTa[t]]),
                                                             acc[jb], 0, 0, 0);
       if (ks + 1 < KS) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) av[e] = an[e];
       }
     }
-    // accumulator layout: lane (j = m, rq = kq) holds rows 4 rq + v, column 16 jb + j  (as adj_basis_kernel)
-    float zeta[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int nn = rb * 16 + 4 * kq + v;
-      const bool ok = nn < N;
+    // accumulator layout: lane (m = pixel, rq = kq) holds z[pixel m][16 jb + 4 rq + v], v = 0..3
+    const int nn = rb * 16 + m;
+    const bool ok = nn < N;
+    const size_t ro = (size_t)(ok ? nn : 0) * K;
+    float zeta = 0.f;
+    if ((K & 3) == 0) {
 #pragma unroll
       for (int jb = 0; jb < NK; ++jb) {
-        const int j = 16 * jb + m;
+        const int j = 16 * jb + 4 * kq;
         if (ok && j < K) {
-          zeta[v] = fmaf(acc[jb][v], bas[(size_t)nn * K + j], zeta[v]);
-          z2[(size_t)nn * K + j] = 2.f * acc[jb][v];
+          if (!(a.abl & 2)) {
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(bas + ro + j);
+            zeta += acc[jb][0] * bq[0] + acc[jb][1] * bq[1] + acc[jb][2] * bq[2] + acc[jb][3] * bq[3];
+          }
+          if (!(a.abl & 1)) *reinterpret_cast<f32x4*>(z2 + ro + j) = 2.f * acc[jb];
         }
       }
-    }
+    } else {
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const float zt = row16_sum(zeta[v]);
-      const int nn = rb * 16 + 4 * kq + v;
-      if (nn < N) {
-        if (m < 6) arec[(size_t)nn * 8 + m] = acc[NK][v];
-        if (m == 6) arec[(size_t)nn * 8 + 7] = acc[NK][v];
-        if (m == 7) arec[(size_t)nn * 8 + 6] = zt;
+      for (int jb = 0; jb < NK; ++jb)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int j = 16 * jb + 4 * kq + v;
+          if (ok && j < K) {
+            zeta = fmaf(acc[jb][v], bas[ro + j], zeta);
+            z2[ro + j] = 2.f * acc[jb][v];
+          }
+        }
+    }
+    zeta += __shfl_xor(zeta, 16, 64);      // the pixel's four coefficient quarters (lanes m, m + 16, m + 32, m + 48)
+    zeta += __shfl_xor(zeta, 32, 64);
+    if (ok) {                              // the extra block: rows 0..5 = q = S_cd b, row 6 = e = gAtb_d . b  (row 4 rq + v)
+      float* __restrict__ ar = arec + (size_t)nn * 8;
+      if (kq == 0) *reinterpret_cast<f32x4*>(ar) = acc[NK];
+      if (kq == 1) {
+        ar[4] = acc[NK][0];
+        ar[5] = acc[NK][1];
+        ar[7] = acc[NK][2];
+        ar[6] = zeta;
       }
     }
   }
@@ -849,7 +872,8 @@ __global__ __launch_bounds__(kBlock, 2) void adj_pixel2_kernel(const AdjArgs a) 
         const int yy = min(max(y0 - 1 + r, 0), H - 1), xx = min(max(x0 - 1 + cc, 0), W - 1);
         const float* __restrict__ row = tgt_b + (size_t)(yy * W + xx) * C;
 #pragma unroll
-        for (int j = 0; j < CJ4; ++j) tex[j][r][cc] = *reinterpret_cast<const f32x4*>(row + (cok[j] ? 4 * hl + 128 * j : 0));
+        for (int j = 0; j < CJ4; ++j)
+          tex[j][r][cc] = (a.abl & 4) ? f32x4{0.1f * r, 0.2f * cc, 0.3f, 0.4f} : *reinterpret_cast<const f32x4*>(row + (cok[j] ? 4 * hl + 128 * j : 0));
       }
     f32x4 Sf[CJ4], Sgx[CJ4], Sgy[CJ4], Ax[CJ4][3], Ay[CJ4][3];
 #pragma unroll
@@ -974,7 +998,7 @@ __global__ __launch_bounds__(kBlock, 2) void adj_pixel2_kernel(const AdjArgs a) 
           dpy += -dd[e] * Ay[j][0][e] + dgx[e] * Ay[j][1][e] + dgy[e] * Ay[j][2][e];
         }
         if (a.overwrite && live && !m) *reinterpret_cast<f32x4*>(dsrc_n + 128 * j) = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (m) {
+        if (m && !((a.abl & 8) && dd[0] != 12345.f)) {
           f32x4* ds = reinterpret_cast<f32x4*>(dsrc_n + 128 * j);
           *ds = a.overwrite ? dd : *ds + dd;
           if (a.arow) {
@@ -1025,7 +1049,7 @@ __global__ __launch_bounds__(kBlock, 2) void adj_pixel2_kernel(const AdjArgs a) 
         dwc[e] = fmaf(dD, bv[e], dwc[e]);
       }
       f32x4* db = reinterpret_cast<f32x4*>(a.dbasis + q * K + k0);
-      *db = a.overwrite ? v : *db + v;
+      if (!((a.abl & 8) && v[0] != 12345.f)) *db = a.overwrite ? v : *db + v;
     } else if (a.overwrite && live && kok) {
       *reinterpret_cast<f32x4*>(a.dbasis + q * K + k0) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -2342,6 +2366,10 @@ int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T
   a.dpose = dpose;
   a.overwrite = (flags & BANET_ADJOINT_OVERWRITE) ? 1 : 0;
   a.overwrite_map = (flags & BANET_ADJOINT_OVERWRITE_MAP) ? 1 : 0;
+  {
+    static const int abl = std::getenv("BANET_ADJOINT_ABLATE") ? std::atoi(std::getenv("BANET_ADJOINT_ABLATE")) : 0;   // timing experiments only
+    a.abl = abl;
+  }
   const size_t tot = (size_t)B * P * P;
   hipLaunchKernelGGL(adj_sym_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, gAtA, S, P, tot);
   if (hipMemsetAsync(a.cnt, 0, ((size_t)B * HW + (pl.fold ? 1 : 0)) * sizeof(int), s) != hipSuccess) return BANET_ERR_LAUNCH;
