@@ -66,8 +66,6 @@ struct AdjArgs {
   float* dpose;
   int overwrite;      // 1: dsrc / ddepth / dbasis are WRITTEN (every entry, zeros where nothing contributes) instead of accumulated
   int overwrite_map;  // 1: the same for dmap3
-  int abl;            // TIMING-ONLY ablations (BANET_ADJOINT_ABLATE bits, wrong results): 1 adj_basis6 without the z2 stores, 2 without
-                      // zeta (the basis re-read in accumulator layout), 4 adj_pixel2 without its target texel loads, 8 without its stores
   // fold mode (round 6, adj_tile_kernel): dmap3 is the target map's gradient itself, [B][H][W][C]
   float* lrec;        // [B][N][kFrac]  the records in cell-list order, key replaced by the pixel index
   int* list2;         // [B][N]         scratch of the big-cell sort
@@ -276,11 +274,9 @@ __global__ __launch_bounds__(kAdjB6Threads) void adj_basis6_kernel(const AdjArgs
       for (int jb = 0; jb < NK; ++jb) {
         const int j = 16 * jb + 4 * kq;
         if (ok && j < K) {
-          if (!(a.abl & 2)) {
-            const f32x4 bq = *reinterpret_cast<const f32x4*>(bas + ro + j);
-            zeta += acc[jb][0] * bq[0] + acc[jb][1] * bq[1] + acc[jb][2] * bq[2] + acc[jb][3] * bq[3];
-          }
-          if (!(a.abl & 1)) *reinterpret_cast<f32x4*>(z2 + ro + j) = 2.f * acc[jb];
+          const f32x4 bq = *reinterpret_cast<const f32x4*>(bas + ro + j);
+          zeta += acc[jb][0] * bq[0] + acc[jb][1] * bq[1] + acc[jb][2] * bq[2] + acc[jb][3] * bq[3];
+          *reinterpret_cast<f32x4*>(z2 + ro + j) = 2.f * acc[jb];
         }
       }
     } else {
@@ -762,7 +758,7 @@ __device__ __forceinline__ float hsum(float v) {   // sum over the 32 lanes of e
   return bfly_merge(v, v, 16);
 }
 
-template <int CJ4>
+template <int CJ4, bool OW>     // OW: dsrc / ddepth / dbasis are written (BANET_ADJOINT_OVERWRITE), else read (early, with the texels) and added to
 __global__ __launch_bounds__(kBlock, 2) void adj_pixel2_kernel(const AdjArgs a) {
   const banet_level_t& lv = a.lv;
   const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x & 63, w = wave_id();
@@ -818,6 +814,22 @@ __global__ __launch_bounds__(kBlock, 2) void adj_pixel2_kernel(const AdjArgs a) 
 
   const int nw = a.G * kNumWaves, chunk = ((N + nw - 1) / nw + 1) & ~1;   // even: the pairs of a wave never straddle two waves
   const int n_lo = (g * kNumWaves + w) * chunk, n_hi = min(N, n_lo + chunk);
+  // Software pipeline (round 6; by ablation the kernel was bound by two exposed memory round trips per pixel pair, not by its
+  // bytes): the rows a pair's geometry needs -- basis, depth, the (q, zeta, e) record -- are requested one pair ahead; the 12 target
+  // texel loads go out as soon as the projection is known and the part of the per-pixel algebra that does not depend on the texels
+  // (Jacobians, J S_cc + jd q^T, t, dM, dg) runs while they travel.
+  auto pix_of = [&](int n2) { const int n = n2 + hi; return n < n_hi ? n : n_hi - 1; };     // a dead upper half recomputes the lower pixel
+  const int kc = kok ? k0 : 0;      // loads are unconditional at clamped offsets (a conditional load is merged with its default by
+                                    // copies that wait for it on the spot); what a lane without coefficients / channels reads is masked where it is used
+  f32x4 bv_n, ar0_n, ar1_n;
+  float dep_n;
+  {
+    const size_t q0 = (size_t)b * N + pix_of(n_lo < n_hi ? n_lo : 0);
+    bv_n = *reinterpret_cast<const f32x4*>(bas_b + (q0 - (size_t)b * N) * K + kc);
+    ar0_n = *reinterpret_cast<const f32x4*>(a.arec + q0 * 8);
+    ar1_n = *reinterpret_cast<const f32x4*>(a.arec + q0 * 8 + 4);
+    dep_n = lv.depth[q0];
+  }
   for (int n2 = n_lo; n2 < n_hi; n2 += 2) {
     const int n = n2 + hi;
     const bool live = n < n_hi;
@@ -831,20 +843,10 @@ __global__ __launch_bounds__(kBlock, 2) void adj_pixel2_kernel(const AdjArgs a) 
       p2 *= inv;
     }
     const size_t q = (size_t)b * N + nn;
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f}, z2v = {0.f, 0.f, 0.f, 0.f};
-    if (kok) {
-      bv = *reinterpret_cast<const f32x4*>(bas_b + (size_t)nn * K + k0);
-      z2v = *reinterpret_cast<const f32x4*>(a.z2 + q * K + k0);
-    }
-    f32x4 f1v[CJ4];
-#pragma unroll
-    for (int j = 0; j < CJ4; ++j)
-      f1v[j] = cok[j] ? *reinterpret_cast<const f32x4*>(src_b + (size_t)nn * C + 4 * hl + 128 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* __restrict__ ar = a.arec + q * 8;
-    const f32x4 ar0 = *reinterpret_cast<const f32x4*>(ar), ar1 = *reinterpret_cast<const f32x4*>(ar + 4);
+    const f32x4 bv = bv_n, ar0 = ar0_n, ar1 = ar1_n;
     const float qv[6] = {ar0[0], ar0[1], ar0[2], ar0[3], ar1[0], ar1[1]};
     const float zeta = ar1[2], ee = ar1[3];
-    const float D = lv.depth[q] + hsum(bv[0] * wc[0] + bv[1] * wc[1] + bv[2] * wc[2] + bv[3] * wc[3]);
+    const float D = dep_n + hsum(bv[0] * wc[0] + bv[1] * wc[1] + bv[2] * wc[2] + bv[3] * wc[3]);
     const float rx = Rm[0] * p0 + Rm[1] * p1 + Rm[2] * p2;
     const float ry = Rm[3] * p0 + Rm[4] * p1 + Rm[5] * p2;
     const float rz = Rm[6] * p0 + Rm[7] * p1 + Rm[8] * p2;
@@ -872,62 +874,30 @@ __global__ __launch_bounds__(kBlock, 2) void adj_pixel2_kernel(const AdjArgs a) 
         const int yy = min(max(y0 - 1 + r, 0), H - 1), xx = min(max(x0 - 1 + cc, 0), W - 1);
         const float* __restrict__ row = tgt_b + (size_t)(yy * W + xx) * C;
 #pragma unroll
-        for (int j = 0; j < CJ4; ++j)
-          tex[j][r][cc] = (a.abl & 4) ? f32x4{0.1f * r, 0.2f * cc, 0.3f, 0.4f} : *reinterpret_cast<const f32x4*>(row + (cok[j] ? 4 * hl + 128 * j : 0));
+        for (int j = 0; j < CJ4; ++j) tex[j][r][cc] = *reinterpret_cast<const f32x4*>(row + (cok[j] ? 4 * hl + 128 * j : 0));
       }
-    f32x4 Sf[CJ4], Sgx[CJ4], Sgy[CJ4], Ax[CJ4][3], Ay[CJ4][3];
+    // this pair's source row and z2 row (needed after the taps / at the very end), the next pair's geometry rows
+    const f32x4 z2v = *reinterpret_cast<const f32x4*>(a.z2 + q * K + kc);
+    f32x4 f1v[CJ4];
 #pragma unroll
-    for (int j = 0; j < CJ4; ++j) {
-      Sf[j] = Sgx[j] = Sgy[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < CJ4; ++j) f1v[j] = *reinterpret_cast<const f32x4*>(src_b + (size_t)nn * C + (cok[j] ? 4 * hl + 128 * j : 0));
+    f32x4 ds_old[CJ4], db_old;      // accumulate mode: the old contents travel with the texels
+    float dd_old = 0.f;
+    if constexpr (!OW) {
 #pragma unroll
-      for (int e = 0; e < 3; ++e) Ax[j][e] = Ay[j][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < CJ4; ++j) ds_old[j] = *reinterpret_cast<const f32x4*>(a.dsrc + q * C + (cok[j] ? 4 * hl + 128 * j : 0));
+      db_old = *reinterpret_cast<const f32x4*>(a.dbasis + q * K + kc);
+      dd_old = a.ddepth[q];
     }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int ix = t & 1, iy = t >> 1;
-      const int tx = x0 + ix, ty = y0 + iy;
-      const bool in = tx <= W - 1 && ty <= H - 1;
-      const float hx = (in && tx > 0 && tx < W - 1) ? 0.5f : 0.f, hy = (in && ty > 0 && ty < H - 1) ? 0.5f : 0.f;
-      const float fin = in ? 1.f : 0.f;
-      const float wx = ix ? ax : 1.f - ax, wy = iy ? ay : 1.f - ay;
-      const float wt = wx * wy, sx = (ix ? 1.f : -1.f) * wy, sy = (iy ? 1.f : -1.f) * wx;
-#pragma unroll
-      for (int j = 0; j < CJ4; ++j) {
-        const f32x4 F = fin * tex[j][1 + iy][1 + ix];
-        const f32x4 GX = hx * (tex[j][1 + iy][2 + ix] - tex[j][1 + iy][ix]);
-        const f32x4 GY = hy * (tex[j][2 + iy][1 + ix] - tex[j][iy][1 + ix]);
-        Sf[j] += wt * F;
-        Sgx[j] += wt * GX;
-        Sgy[j] += wt * GY;
-        Ax[j][0] += sx * F;
-        Ax[j][1] += sx * GX;
-        Ax[j][2] += sx * GY;
-        Ay[j][0] += sy * F;
-        Ay[j][1] += sy * GX;
-        Ay[j][2] += sy * GY;
-      }
+    {
+      const int nx = pix_of(n2 + 2 < n_hi ? n2 + 2 : n2);      // (the last pair requests itself again: no branch around the loads)
+      const size_t qn = (size_t)b * N + nx;
+      bv_n = *reinterpret_cast<const f32x4*>(bas_b + (size_t)nx * K + kc);
+      ar0_n = *reinterpret_cast<const f32x4*>(a.arec + qn * 8);
+      ar1_n = *reinterpret_cast<const f32x4*>(a.arec + qn * 8 + 4);
+      dep_n = lv.depth[qn];
     }
-    f32x4 dif[CJ4];
-    float M11 = 0.f, M12 = 0.f, M22 = 0.f, g1 = 0.f, g2 = 0.f;
-#pragma unroll
-    for (int j = 0; j < CJ4; ++j) {
-      if (!cok[j]) Sf[j] = Sgx[j] = Sgy[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      dif[j] = f1v[j] - Sf[j];       // bundlenet.py:234
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        M11 = fmaf(Sgx[j][e], Sgx[j][e], M11);
-        M12 = fmaf(Sgx[j][e], Sgy[j][e], M12);
-        M22 = fmaf(Sgy[j][e], Sgy[j][e], M22);
-        g1 = fmaf(Sgx[j][e], dif[j][e], g1);
-        g2 = fmaf(Sgy[j][e], dif[j][e], g2);
-      }
-    }
-    M11 = hsum(M11);
-    M12 = hsum(M12);
-    M22 = hsum(M22);
-    g1 = hsum(g1);
-    g2 = hsum(g2);
-    // ---- per-pixel algebra (as adj_pixel_kernel)
+    // ---- per-pixel algebra, the part without M and g (as adj_pixel_kernel), under the texel loads
     const float iz = 1.f / Z;
     float J0[6], J1[6];
     J0[0] = fx * (-(x * y));
@@ -969,6 +939,60 @@ __global__ __launch_bounds__(kBlock, 2) void adj_pixel2_kernel(const AdjArgs a) 
     dM11 = fmaf(t0, jd0, dM11);
     dM12 = fmaf(t0, jd1, dM12);
     dM22 = fmaf(t1, jd1, dM22);
+    asm volatile("" ::: "memory");      // (keeps the block above ahead of the first use of a texel)
+    f32x4 Sf[CJ4], Sgx[CJ4], Sgy[CJ4], Ax[CJ4][3], Ay[CJ4][3];
+#pragma unroll
+    for (int j = 0; j < CJ4; ++j) {
+      Sf[j] = Sgx[j] = Sgy[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 3; ++e) Ax[j][e] = Ay[j][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int ix = t & 1, iy = t >> 1;
+      const int tx = x0 + ix, ty = y0 + iy;
+      const bool in = tx <= W - 1 && ty <= H - 1;
+      const float hx = (in && tx > 0 && tx < W - 1) ? 0.5f : 0.f, hy = (in && ty > 0 && ty < H - 1) ? 0.5f : 0.f;
+      const float fin = in ? 1.f : 0.f;
+      const float wx = ix ? ax : 1.f - ax, wy = iy ? ay : 1.f - ay;
+      const float wt = wx * wy, sx = (ix ? 1.f : -1.f) * wy, sy = (iy ? 1.f : -1.f) * wx;
+#pragma unroll
+      for (int j = 0; j < CJ4; ++j) {
+        const f32x4 F = fin * tex[j][1 + iy][1 + ix];
+        const f32x4 GX = hx * (tex[j][1 + iy][2 + ix] - tex[j][1 + iy][ix]);
+        const f32x4 GY = hy * (tex[j][2 + iy][1 + ix] - tex[j][iy][1 + ix]);
+        Sf[j] += wt * F;
+        Sgx[j] += wt * GX;
+        Sgy[j] += wt * GY;
+        Ax[j][0] += sx * F;
+        Ax[j][1] += sx * GX;
+        Ax[j][2] += sx * GY;
+        Ay[j][0] += sy * F;
+        Ay[j][1] += sy * GX;
+        Ay[j][2] += sy * GY;
+      }
+    }
+    f32x4 dif[CJ4];
+    float M11 = 0.f, M12 = 0.f, M22 = 0.f, g1 = 0.f, g2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < CJ4; ++j) {
+      if (!cok[j]) Sf[j] = Sgx[j] = Sgy[j] = f1v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dif[j] = f1v[j] - Sf[j];       // bundlenet.py:234
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        M11 = fmaf(Sgx[j][e], Sgx[j][e], M11);
+        M12 = fmaf(Sgx[j][e], Sgy[j][e], M12);
+        M22 = fmaf(Sgy[j][e], Sgy[j][e], M22);
+        g1 = fmaf(Sgx[j][e], dif[j][e], g1);
+        g2 = fmaf(Sgy[j][e], dif[j][e], g2);
+      }
+    }
+    M11 = hsum(M11);
+    M12 = hsum(M12);
+    M22 = hsum(M22);
+    g1 = hsum(g1);
+    g2 = hsum(g2);
+    // ---- per-pixel algebra, the part with M and g
     float dJ0[6], dJ1[6], u[6];
     const float Mjd0 = M11 * jd0 + M12 * jd1, Mjd1 = M12 * jd0 + M22 * jd1;
 #pragma unroll
@@ -991,16 +1015,21 @@ __global__ __launch_bounds__(kBlock, 2) void adj_pixel2_kernel(const AdjArgs a) 
         for (int e = 0; e < 4; ++e) {
           const float d = dif[j][e], gx = Sgx[j][e], gy = Sgy[j][e];
           const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-          dd[e] = dg1 * gx + dg2 * gy + sgn * ga[j][e];
-          dgx[e] = 2.f * (dM11 * gx + dM12 * gy) + dg1 * d;
-          dgy[e] = 2.f * (dM12 * gx + dM22 * gy) + dg2 * d;
+          // (explicit fused operations: the two instantiations of this kernel -- write / accumulate -- must round alike, and the
+          // compiler's own contraction of a * b + c * d + e * f is free to differ between them)
+          dd[e] = fmaf(sgn, ga[j][e], fmaf(dg2, gy, dg1 * gx));
+          dgx[e] = fmaf(dg1, d, 2.f * fmaf(dM12, gy, dM11 * gx));
+          dgy[e] = fmaf(dg2, d, 2.f * fmaf(dM22, gy, dM12 * gx));
           dpx += -dd[e] * Ax[j][0][e] + dgx[e] * Ax[j][1][e] + dgy[e] * Ax[j][2][e];
           dpy += -dd[e] * Ay[j][0][e] + dgx[e] * Ay[j][1][e] + dgy[e] * Ay[j][2][e];
         }
-        if (a.overwrite && live && !m) *reinterpret_cast<f32x4*>(dsrc_n + 128 * j) = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (m && !((a.abl & 8) && dd[0] != 12345.f)) {
+        if (OW && live && !m) *reinterpret_cast<f32x4*>(dsrc_n + 128 * j) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (m) {
           f32x4* ds = reinterpret_cast<f32x4*>(dsrc_n + 128 * j);
-          *ds = a.overwrite ? dd : *ds + dd;
+          if constexpr (OW)
+            *ds = dd;
+          else
+            *ds = ds_old[j] + dd;
           if (a.arow) {
             *reinterpret_cast<f32x4*>(arow_n + 128 * j) = -dd;
             *reinterpret_cast<f32x4*>(arow_n + C + 128 * j) = dgx;
@@ -1045,19 +1074,22 @@ __global__ __launch_bounds__(kBlock, 2) void adj_pixel2_kernel(const AdjArgs a) 
         float su = 0.f;
 #pragma unroll
         for (int i = 0; i < 6; ++i) su = fmaf(u[i], scd[i][e], su);
-        v[e] = fmaf(2.f, su, s_n * z2v[e] + r_n * gbd[e] + dD * wc[e]);
+        v[e] = fmaf(2.f, su, fmaf(dD, wc[e], fmaf(r_n, gbd[e], s_n * z2v[e])));
         dwc[e] = fmaf(dD, bv[e], dwc[e]);
       }
       f32x4* db = reinterpret_cast<f32x4*>(a.dbasis + q * K + k0);
-      if (!((a.abl & 8) && v[0] != 12345.f)) *db = a.overwrite ? v : *db + v;
-    } else if (a.overwrite && live && kok) {
+      if constexpr (OW)
+        *db = v;
+      else
+        *db = db_old + v;
+    } else if (OW && live && kok) {
       *reinterpret_cast<f32x4*>(a.dbasis + q * K + k0) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (hl == 0 && live) {
       float* __restrict__ fr = a.frac + q * kFrac;
-      if (a.overwrite && !m) a.ddepth[q] = 0.f;
+      if (OW && !m) a.ddepth[q] = 0.f;
       if (m) {
-        a.ddepth[q] = a.overwrite ? dD : a.ddepth[q] + dD;
+        a.ddepth[q] = OW ? dD : dd_old + dD;
         const int key = y0 * W + x0;
         *reinterpret_cast<f32x4*>(fr) = f32x4{__int_as_float(key), ax, ay, dg1};
         *reinterpret_cast<f32x4*>(fr + 4) = f32x4{dg2, dM11, dM12, dM22};
@@ -2366,10 +2398,7 @@ int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T
   a.dpose = dpose;
   a.overwrite = (flags & BANET_ADJOINT_OVERWRITE) ? 1 : 0;
   a.overwrite_map = (flags & BANET_ADJOINT_OVERWRITE_MAP) ? 1 : 0;
-  {
-    static const int abl = std::getenv("BANET_ADJOINT_ABLATE") ? std::atoi(std::getenv("BANET_ADJOINT_ABLATE")) : 0;   // timing experiments only
-    a.abl = abl;
-  }
+
   const size_t tot = (size_t)B * P * P;
   hipLaunchKernelGGL(adj_sym_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, gAtA, S, P, tot);
   if (hipMemsetAsync(a.cnt, 0, ((size_t)B * HW + (pl.fold ? 1 : 0)) * sizeof(int), s) != hipSuccess) return BANET_ERR_LAUNCH;
@@ -2389,6 +2418,7 @@ int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T
       if (hipMemsetAsync(a.arec, 0, (size_t)B * N * 8 * sizeof(float), s) != hipSuccess) return BANET_ERR_LAUNCH;
       a.lv.basis = a.arec;
       a.z2 = a.arec;
+      a.dbasis = a.arec;       // (adj_pixel2_kernel reads its rows unconditionally at clamped offsets: a valid address, never written)
       break;
     default: return BANET_ERR_UNSUPPORTED;
   }
@@ -2411,7 +2441,10 @@ int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T
     BANET_ADJ_POINT(2, 4);
 #undef BANET_ADJ_POINT
   } else if ((lv->C & 3) == 0 && (K & 3) == 0 && lv->C <= 128 && K <= 128 && !(lv->flags & (1 << 27))) {   // bit 27: one pixel per wave (A/B)
-    hipLaunchKernelGGL((adj_pixel2_kernel<1>), dim3(pl.G, B), dim3(kBlock), 0, s, a);   // (C = 256: 264 B of spills -> the one-pixel kernel)
+    if (a.overwrite)
+      hipLaunchKernelGGL((adj_pixel2_kernel<1, true>), dim3(pl.G, B), dim3(kBlock), 0, s, a);   // (C = 256: 264 B of spills -> the one-pixel kernel)
+    else
+      hipLaunchKernelGGL((adj_pixel2_kernel<1, false>), dim3(pl.G, B), dim3(kBlock), 0, s, a);
   } else {
     const int CJ = (lv->C + 63) / 64, KJ = std::max(1, (K + 63) / 64);
     const dim3 grid(pl.G, B), block(kBlock);
