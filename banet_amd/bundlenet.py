@@ -305,14 +305,17 @@ class BundleNet:
             conv1, conv2, fx, fy, ox, oy, p, D, B, R, T, W, l2, level = args
             from . import dense_train
             data_grad = any(torch.is_tensor(x) and x.requires_grad for x in (fx, fy, ox, oy, p))     # (data in the reference: no gradient path)
-            if not data_grad and dense_train.sparse_iteration_supported(conv1, conv2, B):
+            # a regulariser base that is itself a differentiable tensor needs the torch graph (the fused node takes it as a number)
+            l2_grad = torch.is_tensor(l2) and l2.requires_grad
+            if not data_grad and not l2_grad and dense_train.sparse_iteration_supported(conv1, conv2, B, D, R, T):
                 lw = self.lambda_weights[str(level)]
                 layers = [(w if torch.is_tensor(w) else torch.as_tensor(w), b if torch.is_tensor(b) else torch.as_tensor(b)) for w, b in lw]
                 layers = [(w.to(conv1.device), b.to(conv1.device)) for w, b in layers]
                 bundle = B is not None
                 l2v = (1.0 if l2 is None else float(l2)) if bundle else 1.0            # CameraIteration ignores the argument (:122-191)
-                R2, T2, W2 = dense_train.sparse_iteration("bundle" if bundle else "bundle_camera", self._mlp(level, conv1.device), l2v,
-                                                          conv1, conv2, D, B, R, T, W, fx, fy, ox, oy, p, layers)
+                R2, T2, W2, last = dense_train.sparse_iteration("bundle" if bundle else "bundle_camera", self._mlp(level, conv1.device), l2v,
+                                                                conv1, conv2, D, B, R, T, W, fx, fy, ox, oy, p, layers)
+                self.last = last          # (AtA, Atb, lam, delta: as the inference path leaves them)
                 return R2, T2, W2
             return self._iteration_autograd_lean(*args)
         if self.training_graph in ("lean", "fused") and self.exact_gradients:

@@ -447,6 +447,8 @@ int plan_gather(const banet_level_t* lv, GatherPlan* pl) {
   const int kCUs = num_cus();
   const int Bsel = lv ? selection_batch(lv) : 0;   // decisions: Bsel; grids and buffer sizes: lv->B
   if (!lv || lv->B <= 0 || lv->N <= 0 || lv->C <= 0 || lv->K < 0 || lv->H < 4 || lv->W < 4) return BANET_ERR_INVALID_ARG;
+  // (the field was a must-be-zero pad until round 4: anything but the two policies is a caller's garbage, not "throughput")
+  if (lv->policy != BANET_POLICY_THROUGHPUT && lv->policy != BANET_POLICY_BATCH_INVARIANT) return BANET_ERR_INVALID_ARG;
   if (lv->C > 256 || lv->K > 256) return BANET_ERR_UNSUPPORTED;
   if (lv->dense && lv->N != lv->H * lv->W) return BANET_ERR_INVALID_ARG;
   if (lv->dense) {

@@ -59,14 +59,19 @@ class DenseBA:
         # The coarsest level (<= 1200 pixels) of a large batch as two half batches on two HIP streams (host-side orchestration only;
         # opt-in: BANET_SPLIT_COARSE=1).  Measured at 32 windows (profiles/r05_run13_*): 40x30 1.37 -> 1.08 ms per 10 iterations, but
         # 80x60 +7 % and 160x120 +13 % when split too -- net zero over a solve, +0.5 % with the coarsest level alone: not the default.
+        # Under the default throughput policy the two B / 2 launches choose kernels and summation splits from THEIR batch, so enabling
+        # it changes results in the low bits (equal to rounding, like any other batching: DESIGN.md section 6); BATCH_INVARIANT does not.
         self.split_coarse = os.environ.get("BANET_SPLIT_COARSE", "0") == "1"
         self._parts, self._side = {}, None
         self._variant_args = dict(variant=variant, legacy=legacy)
 
     def _level_parts(self, li, st):
         """two half-batch views of level li (problems over slices of the level tensors, workspaces) + views of the state"""
-        if li not in self._parts:
-            lv, B = self.levels[li], self.B
+        lv = self.levels[li]
+        # the halves alias the level's tensors: rebuilt whenever one of them (or the level's problem) has been replaced since
+        key = (id(self.problems[li]),) + tuple(t.data_ptr() for t in (lv.src, lv.tgt, lv.depth) + ((lv.basis,) if lv.basis is not None else ()))
+        if li not in self._parts or self._parts[li][0] != key:
+            B = self.B
             cuts = [(0, B // 2), (B // 2, B)]
             parts = []
             for lo, hi in cuts:
@@ -77,9 +82,9 @@ class DenseBA:
                                         normalize_rays=not self._variant_args["legacy"], pairs=lv.pairs)
                 prob.c.flags, prob.c.policy = self.problems[li].c.flags, self.problems[li].c.policy
                 parts.append((lo, hi, prob, ops.capi.workspace(ops.lm_level_workspace_bytes(prob), self.intr.device)))
-            self._parts[li] = parts
+            self._parts[li] = (key, parts)
         out = []
-        for lo, hi, prob, ws in self._parts[li]:
+        for lo, hi, prob, ws in self._parts[li][1]:
             prob.c.flags, prob.c.policy = self.problems[li].c.flags, self.problems[li].c.policy    # (follow later changes of the level's)
             sub = ops.capi.State()
             sub.R, sub.T = st.R[lo:hi].data_ptr(), st.T[lo:hi].data_ptr()

@@ -238,10 +238,17 @@ class SmallStepHip:
             raise capi.BanetError("small step: unsupported shape")
         self.ws = capi.workspace(nb, dev)
         dims = [C, 2 * C, 4 * C, 2 * C, C, 1]
+        sizes = []
+        for i in range(5):
+            sizes += [dims[i] * dims[i + 1], dims[i + 1]]
+        offs = [0]
+        for n_ in sizes:
+            offs.append(offs[-1] + (n_ + 3) // 4 * 4)                     # 16-byte aligned views of ONE zero-filled buffer (one fill launch)
+        flatbuf = torch.zeros(offs[-1], dtype=torch.float32, device=dev)
         self.glayers = []
         for i in range(5):
-            self.glayers += [torch.zeros(dims[i], dims[i + 1], dtype=torch.float32, device=dev),
-                             torch.zeros(dims[i + 1], dtype=torch.float32, device=dev)]
+            self.glayers += [flatbuf[offs[2 * i]:offs[2 * i] + sizes[2 * i]].view(dims[i], dims[i + 1]),
+                             flatbuf[offs[2 * i + 1]:offs[2 * i + 1] + sizes[2 * i + 1]]]
         self.g = capi.Mlp()
         for i in range(5):
             self.g.w[i] = self.glayers[2 * i].data_ptr()
@@ -470,31 +477,39 @@ class _SparseIteration(torch.autograd.Function):
     fx / fy / ox / oy / p are data (bundlenet.py:112-120 computes them from the sampled points): no gradient."""
 
     @staticmethod
-    def forward(ctx, variant, mlp, l2_base, conv1, conv2, D, Bs, R, T, W, fx, fy, ox, oy, p, *flat_layers):
+    def forward(ctx, variant, mlp, l2_base, last, conv1, conv2, D, Bs, R, T, W, fx, fy, ox, oy, p, *flat_layers):
         nb, H, Wd, C3 = conv2.shape
         C = conv1.shape[2]
         K = 0 if Bs is None else Bs.shape[-1]
         prob = ops.LevelProblem(variant, conv1.detach(), conv2.detach(), D.detach(), H, Wd, C, basis=None if Bs is None else Bs.detach(),
                                 rays=p.detach(), fx=fx.detach(), fy=fy.detach(), ox=ox.detach(), oy=oy.detach(), dense=False,
                                 tgt_has_grad=True)
-        st = ops.LmState(R.detach().clone(), T.detach().clone(), None if K == 0 else W.detach().reshape(nb, K, 1).clone(), P=6 + K)
+        # the update kernel works in place on a private copy of the state; the inputs themselves are the state before the update
+        R0, T0 = capi.f32c(R.detach()), capi.f32c(T.detach())
+        W0 = capi.f32c(W.detach().reshape(nb, K, 1)) if K else torch.zeros(nb, 0, 1, device=conv1.device)
+        st = ops.LmState(R0.clone(), T0.clone(), None if K == 0 else W0.clone(), P=6 + K)
         AtA, Atb, absres, nvalid = ops.ba_assemble(prob, st.R, st.T, st.Wc)
-        R0, T0 = st.R.clone(), st.T.clone()
-        W0 = st.Wc.clone() if K else torch.zeros(nb, 0, 1, device=conv1.device)
         ops.ba_solve_update(prob, mlp, l2_base, AtA, Atb, absres, nvalid, st)
         ctx.prob, ctx.l2, ctx.camera = prob, float(l2_base), K == 0
         ctx.variant, ctx.mlp = variant, mlp
-        ctx.saved = (R0, T0, W0, AtA, Atb, absres, st.delta.clone())
+        ctx.saved = (R0, T0, W0, AtA, Atb, absres, st.delta)          # (st is private to this node: no copies)
         ctx.flat = flat_layers
         ctx.shapes = (conv1.shape, conv2.shape, D.shape, None if Bs is None else Bs.shape, R.shape, T.shape, None if W is None else W.shape)
-        ctx.last = dict(AtA=AtA, Atb=Atb, lam=st.lambda_out.clone(), delta=st.delta.clone())
-        Wn = st.Wc.clone().reshape(W.shape) if K else None
-        return st.R.clone().reshape(R.shape), st.T.clone().reshape(T.shape), Wn
+        last.update(AtA=AtA, Atb=Atb, lam=st.lambda_out, delta=st.delta)
+        # the problem aliases the (detached) inputs: remember their versions, so that an in-place change between forward and
+        # backward is an error here as it would be for tensors kept with save_for_backward
+        ctx.inputs = [t for t in (conv1, conv2, D, Bs, fx, fy, ox, oy, p, R, T, W) if torch.is_tensor(t)]
+        ctx.versions = [t._version for t in ctx.inputs]
+        Wn = st.Wc.reshape(W.shape) if K else None
+        return st.R.reshape(R.shape), st.T.reshape(T.shape), Wn
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, gR, gT, gW):
         prob = ctx.prob
+        if any(t._version != v for t, v in zip(ctx.inputs, ctx.versions)):
+            raise RuntimeError("one of the tensors the fused BA iteration reads (features, target map, depth, basis, rays, intrinsics) "
+                               "was modified in place between its forward and its backward")
         B, N, C, K = prob.B, prob.N, prob.C, prob.K
         H, Wd = prob.c.H, prob.c.W
         dev = prob.device
@@ -521,15 +536,21 @@ class _SparseIteration(torch.autograd.Function):
         dT = dT.reshape(B, 3, 1) + dpose[:, 9:12].reshape(B, 3, 1)
         s1, s2, sD, sB, sR, sT, sW = ctx.shapes
         dWn = None if K == 0 else (dW.reshape(B, K, 1) + dpose[:, 12:].reshape(B, K, 1)).reshape(sW)
-        return (None, None, None, dsrc.reshape(s1), dmap3.reshape(s2), ddepth.reshape(sD), None if sB is None else dbasis.reshape(sB),
+        ctx.prob = ctx.inputs = None          # (release the aliased inputs now, not when the graph node dies)
+        return (None, None, None, None, dsrc.reshape(s1), dmap3.reshape(s2), ddepth.reshape(sD), None if sB is None else dbasis.reshape(sB),
                 dR.reshape(sR), dT.reshape(sT), dWn, None, None, None, None, None) + glayers
 
 
-def sparse_iteration_supported(conv1, conv2, Bs):
-    """shapes the fused sparse backward is compiled for (adjoint.hip): C <= 256, K <= 256, not C > 128 together with K > 128"""
+def sparse_iteration_supported(conv1, conv2, Bs, D=None, R=None, T=None):
+    """what the fused sparse node accepts (adjoint.hip): float32 CUDA tensors on ONE device, C <= 256, K <= 256, not C > 128 together
+    with K > 128, a [f|gx|gy] map of at least 4 x 4 texels (the gather plans refuse smaller ones: the caller falls back to the lean
+    torch graph instead of raising)"""
     C = conv1.shape[-1]
     K = 0 if Bs is None else Bs.shape[-1]
-    return conv1.is_cuda and 1 <= C <= 256 and K <= 256 and not (C > 128 and K > 128) and conv2.shape[-1] == 3 * C
+    tensors = [t for t in (conv1, conv2, Bs, D, R, T) if torch.is_tensor(t)]
+    same = all(t.is_cuda and t.device == conv1.device and t.dtype == torch.float32 for t in tensors)
+    return (same and conv2.dim() == 4 and conv2.shape[1] >= 4 and conv2.shape[2] >= 4 and 1 <= C <= 256 and K <= 256 and
+            not (C > 128 and K > 128) and conv2.shape[-1] == 3 * C)
 
 
 def sparse_iteration(variant, mlp, l2_base, conv1, conv2, D, Bs, R, T, W, fx, fy, ox, oy, p, layers):
@@ -537,4 +558,6 @@ def sparse_iteration(variant, mlp, l2_base, conv1, conv2, D, Bs, R, T, W, fx, fy
     flat = []
     for w, b in layers:
         flat += [w.reshape(w.shape[-2], w.shape[-1]), b.reshape(-1)]
-    return _SparseIteration.apply(variant, mlp, l2_base, conv1, conv2, D, Bs, R, T, W, fx, fy, ox, oy, p, *flat)
+    last = {}
+    R2, T2, W2 = _SparseIteration.apply(variant, mlp, l2_base, last, conv1, conv2, D, Bs, R, T, W, fx, fy, ox, oy, p, *flat)
+    return R2, T2, W2, last

@@ -101,7 +101,9 @@ enum { /* banet_level_t.variant: which reference iteration is restated */
  *   BANET_FLAG_SYRK_THREE_PRODUCTS : OPT-IN, reduced precision -- the K = 128 depth-block contraction with the three largest
  *       bf16 products only (~2^-16 per product instead of fp32-exact).  Never the default, never what bench.py's `value`
  *       is measured with.
- * (Until round 4 this field was called `reserved_` and the bits BANET_DEV_*: same offset, same values; the old names stay as aliases.) */
+ * (Until round 4 this field was called `reserved_` and the bits BANET_DEV_*: same offset, same values.  The BANET_DEV_* ENUM names stay
+ * as aliases; the STRUCT FIELDS were renamed -- `reserved_` -> `flags`, `pad_` -> `policy` -- which is source-breaking for a C / C++
+ * caller that named them (binary layout unchanged; the Python ctypes mirror keeps a `reserved_` property).) */
 enum {
   BANET_FLAG_FORCE_PATCH_GATHER = 1 << 9,
   BANET_FLAG_FORCE_STRIP_GATHER = 1 << 18,

@@ -150,7 +150,7 @@ def _rodrigues(w):
     c, s = torch.cos(thc)[:, None, None], torch.sin(thc)[:, None, None]
     z = torch.zeros_like(th)
     Kn = torch.stack([z, -k[:, 2], k[:, 1], k[:, 2], z, -k[:, 0], -k[:, 1], k[:, 0], z], -1).reshape(-1, 3, 3)
-    eye = torch.eye(3, dtype=w.dtype)[None]
+    eye = torch.eye(3, dtype=w.dtype, device=w.device)[None]
     Rw = c * eye + (1 - c) * k[:, :, None] * k[:, None, :] + s * Kn
     Kw = torch.stack([z, -w[:, 2], w[:, 1], w[:, 2], z, -w[:, 0], -w[:, 1], w[:, 0], z], -1).reshape(-1, 3, 3)
     a = ((1 - torch.cos(th)) / (th * th))[:, None, None]
@@ -246,3 +246,81 @@ def window_iteration(intr, scale, src, tgts, depth, basis, Rs, Ts, Wc, mlp, l2_b
                                                              mask=torch.stack(stats["mask"], 1),
                                                              px=torch.stack([q[0] for q in stats["pxy"]], 1),
                                                              py=torch.stack([q[1] for q in stats["pxy"]], 1))
+
+
+# --------------------------------------------------------------------------------------
+# the sparse-point iteration as differentiable float64 torch statements (test yardstick for the training graphs' gradients)
+# --------------------------------------------------------------------------------------
+def _bilinear_sparse(conv2, px, py):
+    """tf.contrib.resampler on the [f|gx|gy] map (bundlenet.py:227 / oracle.banet_oracle.resampler): four taps, a tap outside the map
+    contributes zero; differentiable in the map and in (px, py).  conv2 [B,H,W,C3], px / py [B,N] -> [B,N,C3]"""
+    B, H, W, C3 = conv2.shape
+    x0, y0 = torch.floor(px), torch.floor(py)
+    ax, ay = (px - x0).unsqueeze(-1), (py - y0).unsqueeze(-1)
+    x0, y0 = x0.long(), y0.long()
+    bi = torch.arange(B, device=conv2.device)[:, None]
+
+    def tap(yi, xi):
+        inside = ((xi >= 0) & (yi >= 0) & (xi <= W - 1) & (yi <= H - 1)).unsqueeze(-1)
+        v = conv2[bi, yi.clamp(0, H - 1), xi.clamp(0, W - 1)]
+        return torch.where(inside, v, torch.zeros_like(v))
+    return (tap(y0, x0) * (1 - ax) * (1 - ay) + tap(y0, x0 + 1) * ax * (1 - ay) + tap(y0 + 1, x0) * (1 - ax) * ay +
+            tap(y0 + 1, x0 + 1) * ax * ay)
+
+
+def sparse_iteration(conv1, conv2, D, Bs, R, T, Wc, lw, bundle, l2, fx, fy, ox, oy, p):
+    """bundlenet.py:122-278 on N sampled points -- BundleIteration (bundle = True) or the pose-only CameraIteration -- every statement
+    a differentiable torch expression in the dtype of its inputs (float64 in the tests): the twin of banet_oracle.bundle_iteration /
+    camera_iteration (pinned to it in tests/test_torch_ref_cpu.py), written with this module's own helpers only.
+    conv1 [B,N,C], conv2 [B,H,W,3C] = [f|gx|gy], D [B,N,1], Bs [B,N,K] or None, R [B,3,3], T [B,3,1], Wc [B,K,1] or None, lw five
+    (filters, biases) pairs, p [B,3,N], fx .. oy [B,N].  -> (R', T', W' or None)"""
+    C, N = conv1.shape[-1], conv1.shape[1]
+    dt = conv1.dtype
+    fx8, fy8, ox8, oy8, p8 = fx.to(dt), fy.to(dt), ox.to(dt), oy.to(dt), p.to(dt)
+    Dd = D + torch.matmul(Bs, Wc) if bundle else D                                     # :206
+    Rp = torch.matmul(R, p8)
+    rx, ry, rz = Rp[:, 0], Rp[:, 1], Rp[:, 2]
+    RPT = Rp * Dd.transpose(1, 2) + T
+    X, Y, Z = RPT[:, 0], RPT[:, 1], RPT[:, 2]
+    x, y = X / Z, Y / Z
+    px, py = fx8 * x + ox8, fy8 * y + oy8
+    samp = _bilinear_sparse(conv2, px, py)
+    Hh, Ww = conv2.shape[1], conv2.shape[2]
+    m = (~((px < 0) | (px > float(Ww - 1)) | (py < 0) | (py > float(Hh - 1)))).to(dt)   # :231-233
+    d = (conv1 - samp[..., :C]) * m[..., None]
+    gx, gy = samp[..., C:2 * C] * m[..., None], samp[..., 2 * C:] * m[..., None]
+    M11, M12, M22, g1, g2 = (gx * gx).sum(-1), (gx * gy).sum(-1), (gy * gy).sum(-1), (gx * d).sum(-1), (gy * d).sum(-1)
+    avg = (d.abs().sum(dim=1) / float(N)).unsqueeze(1)
+    y_ = lambda_mlp(avg, lw)
+    lam = torch.sqrt((avg * avg).sum(-1, keepdim=True)) ** (2.0 + y_)
+    if bundle:
+        lam = l2 * lam
+    # bundlenet.py:49-61 (CameraJacobianMatrix, with its leading minus), one row per residual component
+    iz = 1.0 / Z
+    zero = torch.zeros_like(x)
+    J0 = -fx8.unsqueeze(-1) * torch.stack([x * y, -1.0 - x * x, y, -iz, zero, x * iz], dim=-1)
+    J1 = -fy8.unsqueeze(-1) * torch.stack([1.0 + y * y, -(x * y), -x, zero, -iz, y * iz], dim=-1)
+    MJ0 = M11.unsqueeze(-1) * J0 + M12.unsqueeze(-1) * J1
+    MJ1 = M12.unsqueeze(-1) * J0 + M22.unsqueeze(-1) * J1
+    Hcc = torch.matmul(J0.transpose(1, 2), MJ0) + torch.matmul(J1.transpose(1, 2), MJ1)
+    bc = (J0 * g1.unsqueeze(-1) + J1 * g2.unsqueeze(-1)).sum(dim=1)
+    nb = conv1.shape[0]
+    if bundle:
+        jd0 = fx8 * ((rx - rz * x) * iz)                                              # :63-74 (DepthJacobianMatrix)
+        jd1 = fy8 * ((ry - rz * y) * iz)
+        u = MJ0 * jd0.unsqueeze(-1) + MJ1 * jd1.unsqueeze(-1)
+        s_ = M11 * jd0 ** 2 + 2.0 * M12 * jd0 * jd1 + M22 * jd1 ** 2
+        r = jd0 * g1 + jd1 * g2
+        Hcd = torch.matmul(u.transpose(1, 2), Bs)
+        Hdd = torch.matmul(Bs.transpose(1, 2), Bs * s_.unsqueeze(-1))
+        bd = torch.matmul(Bs.transpose(1, 2), r.unsqueeze(-1)).squeeze(-1)
+        AtA = torch.cat([torch.cat([Hcc, Hcd], dim=2), torch.cat([Hcd.transpose(1, 2), Hdd], dim=2)], dim=1)
+        Atb = torch.cat([bc, bd], dim=1).unsqueeze(-1)
+        diag = torch.diagonal(AtA, dim1=1, dim2=2)
+        damp = torch.cat([diag[:, :-1] + 1e-5, torch.zeros(nb, 1, device=diag.device, dtype=diag.dtype)], dim=-1)     # :264-266
+    else:
+        AtA, Atb = Hcc, bc.unsqueeze(-1)
+        damp = torch.diagonal(AtA, dim1=1, dim2=2) + 1e-5                             # :181-182
+    sol = torch.linalg.solve(AtA + torch.diag_embed(damp * lam.squeeze(-1)), Atb)
+    Rw, V = _rodrigues(sol[:, 0:3, 0])
+    return torch.matmul(Rw, R), torch.matmul(V, sol[:, 3:6]) + torch.matmul(Rw, T), (Wc + sol[:, 6:]) if bundle else None

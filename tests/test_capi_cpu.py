@@ -448,9 +448,12 @@ def test_batch_invariant_policy_selects_by_level_only(capi):
     # the dependence the policy removes: cfg-5's 320x240 level, K = 256, 7 target frames
     assert sel(64, 240, 320, 256, 7)[1] == 4 and sel(8, 240, 320, 256, 7)[1] == 3
     assert sel(64, 240, 320, 256, 7, policy=1) == sel(8, 240, 320, 256, 7, policy=1)
-    # the field that used to be `pad_` still rejects garbage
+    # the field that used to be `pad_` still rejects garbage: the plans (workspace sizes, selections) refuse an unknown policy
     lv = _level(capi, 8, 30, 40, 128, 1, policy=7)
-    assert L.banet_lm_level_workspace_bytes(ctypes.byref(lv)) == 0 or L.banet_gather_selection(ctypes.byref(lv)) >= 0
+    assert L.banet_lm_level_workspace_bytes(ctypes.byref(lv)) == 0 and L.banet_ba_assemble_workspace_bytes(ctypes.byref(lv)) == 0
+    assert L.banet_gather_selection(ctypes.byref(lv)) == -1 and L.banet_syrk_selection(ctypes.byref(lv)) == -1      # BANET_ERR_INVALID_ARG
+    lv.policy = 1
+    assert L.banet_lm_level_workspace_bytes(ctypes.byref(lv)) > 0 and L.banet_gather_selection(ctypes.byref(lv)) > 0
     # the old field name is an alias of the new one (tools/ still use it)
     lv.reserved_ = 1 << 18
     assert lv.flags == 1 << 18

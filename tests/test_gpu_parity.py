@@ -812,37 +812,58 @@ def _sparse_case(seed, B=2, H=24, W=32, C=6, K=5, N=300):
 
 @pytest.mark.parametrize("graph", ["fused", "lean", "reference"])
 def test_training_graph_matches_fused_forward_and_finite_difference_gradients(graph):
+    """every differentiable input of the iteration -- features, the target map, depth, basis, R, T, W AND the ten lambda-weight tensors
+    (round 6: R and the weights were not checked) -- against central differences of the float64 NUMPY oracle"""
     from banet_amd.bundlenet import BundleNet
     c = _sparse_case(17)
     names = ["conv1", "conv2", "fx", "fy", "ox", "oy", "p", "D", "Bs", "R", "T", "W"]
-    net = BundleNet(lambda_weights={"2": [(t(w), t(b)) for w, b in c["mlp"]]})
+    lw = [(t(w).requires_grad_(True), t(b).requires_grad_(True)) for w, b in c["mlp"]]
+    net = BundleNet(lambda_weights={"2": lw})
     net.training_graph = graph
     args = {k: t(c[k]) for k in names}
     with torch.no_grad():
         Rf, Tf, Wf = net.BundleIteration(*[args[k] for k in names], 1000.0, "2")           # fused HIP path
-    leaves = {k: args[k].clone().requires_grad_(True) for k in ("conv1", "conv2", "D", "Bs", "T", "W")}
+    lkeys = ("conv1", "conv2", "D", "Bs", "R", "T", "W")
+    leaves = {k: args[k].clone().requires_grad_(True) for k in lkeys}
     call = [leaves.get(k, args[k]) for k in names]
     Ra, Ta, Wa = net.BundleIteration(*call, 1000.0, "2")                                  # autograd graph
     assert relerr(n(Ra), n(Rf)) < 1e-5 and relerr(n(Ta), n(Tf)) < 1e-4 and relerr(n(Wa), n(Wf)) < 1e-4
     rng = np.random.RandomState(5)
     cR, cT, cW = [rng.standard_normal(x.shape) for x in (n(Ra), n(Ta), n(Wa))]
     loss = (Ra * t(cR)).sum() + (Ta * t(cT)).sum() + (Wa * t(cW)).sum()
-    grads = torch.autograd.grad(loss, list(leaves.values()))
-    grads = dict(zip(leaves.keys(), [n(g).astype(np.float64) for g in grads]))
+    flat_lw = [x for wb in lw for x in wb]
+    grads = torch.autograd.grad(loss, list(leaves.values()) + flat_lw)
+    gl = [n(g).astype(np.float64) for g in grads[len(leaves):]]
+    grads = dict(zip(leaves.keys(), [n(g).astype(np.float64) for g in grads[:len(leaves)]]))
 
-    def oracle_loss(over):                                                            # float64 oracle forward
+    def oracle_loss(over, mlp=None):                                                  # float64 oracle forward
         a = {k: (over[k] if k in over else c[k]).astype(np.float64) for k in names}
         R2, T2, W2, _ = orc.bundle_iteration(a["conv1"], a["conv2"], a["fx"], a["fy"], a["ox"], a["oy"], a["p"], a["D"],
-                                             a["Bs"], a["R"], a["T"], a["W"], c["mlp"], 1000.0)
+                                             a["Bs"], a["R"], a["T"], a["W"], c["mlp"] if mlp is None else mlp, 1000.0)
         return float((R2 * cR).sum() + (T2 * cT).sum() + (W2 * cW).sum())
 
-    for k in ("conv1", "conv2", "D", "Bs", "T", "W"):
+    for k in lkeys:
         v = rng.standard_normal(c[k].shape)
         v /= np.linalg.norm(v)
         eps = 1e-4 if k in ("conv1", "conv2", "Bs") else 1e-5
         fd = (oracle_loss({k: c[k].astype(np.float64) + eps * v}) - oracle_loss({k: c[k].astype(np.float64) - eps * v})) / (2 * eps)
         ad = float((grads[k] * v).sum())
         assert abs(ad - fd) <= 3e-2 * max(abs(fd), abs(ad)) + 1e-6, (k, ad, fd)
+    # the ten lambda-weight tensors (filters and biases of the five layers), one random direction each
+    base = [(np.asarray(w, np.float64), np.asarray(b, np.float64)) for w, b in c["mlp"]]
+    for i in range(10):
+        li, isb = divmod(i, 2)
+        v = rng.standard_normal(base[li][isb].shape)
+        v /= np.linalg.norm(v)
+        eps = 1e-5          # (the biases start at 0 and avg is small: a 1e-3 step straddles the selu kink of many units -- 6 % off)
+
+        def shifted(sgn):
+            m = [list(wb) for wb in base]
+            m[li][isb] = base[li][isb] + sgn * eps * v
+            return [tuple(wb) for wb in m]
+        fd = (oracle_loss({}, shifted(+1)) - oracle_loss({}, shifted(-1))) / (2 * eps)
+        ad = float((gl[i].reshape(v.shape) * v).sum())
+        assert abs(ad - fd) <= 3e-2 * max(abs(fd), abs(ad)) + 1e-7, ("lambda tensor %d" % i, ad, fd)
 
 
 def test_lean_training_graph_equals_the_reference_style_graph():

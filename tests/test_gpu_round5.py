@@ -123,60 +123,12 @@ def test_batch_invariant_policy_is_bit_identical_across_batch_sizes(pairs):
         np.testing.assert_array_equal(a, b)
 
 
-def _sparse_iteration64(conv1, conv2, D, Bs, R, T, Wc, lw, bundle, l2, fx, fy, ox, oy, p):
-    """bundlenet.py:122-278 on sparse points in float64, every statement a differentiable torch expression (the lean graph's
-    statements with the C-wide part -- resampler, mask, d, G^T G, G^T d, sum |d| -- written out): the yardstick for both float32
-    training graphs."""
-    from banet_amd.bundlenet import AngleaAxisRotation, CameraJacobianMatrix, DepthJacobianMatrix, VMatrix, _resampler_autograd
-    C, N = conv1.shape[-1], conv1.shape[1]
-    fx8, fy8, ox8, oy8, p8 = fx.double(), fy.double(), ox.double(), oy.double(), p.double()
-    Dd = D + torch.matmul(Bs, Wc) if bundle else D
-    Rp = torch.matmul(R, p8)
-    rx, ry, rz = Rp[:, 0], Rp[:, 1], Rp[:, 2]
-    RPT = Rp * Dd.transpose(1, 2) + T
-    X, Y, Z = RPT[:, 0], RPT[:, 1], RPT[:, 2]
-    x, y = X / Z, Y / Z
-    px, py = fx8 * x + ox8, fy8 * y + oy8
-    samp = _resampler_autograd(conv2, torch.stack([px, py], dim=-1))
-    Hh, Ww = conv2.shape[1], conv2.shape[2]
-    m = (~((px < 0) | (px > float(Ww - 1)) | (py < 0) | (py > float(Hh - 1)))).to(torch.float64)
-    d = (conv1 - samp[..., :C]) * m[..., None]
-    gx, gy = samp[..., C:2 * C] * m[..., None], samp[..., 2 * C:] * m[..., None]
-    M11, M12, M22, g1, g2 = (gx * gx).sum(-1), (gx * gy).sum(-1), (gy * gy).sum(-1), (gx * d).sum(-1), (gy * d).sum(-1)
-    avg = (d.abs().sum(dim=1) / float(N)).unsqueeze(1)
-    h = avg
-    for i, (w, b) in enumerate(lw):
-        z = torch.matmul(h, w) + b
-        h = torch.tanh(z) if i == 4 else torch.nn.functional.selu(z)
-    lam = torch.linalg.vector_norm(avg, dim=-1, keepdim=True) ** (2.0 + h)
-    if bundle:
-        lam = l2 * lam
-    Jc = CameraJacobianMatrix(x, y, Z, fx8, fy8)
-    MJ0 = M11.unsqueeze(-1) * Jc[:, :, 0] + M12.unsqueeze(-1) * Jc[:, :, 1]
-    MJ1 = M12.unsqueeze(-1) * Jc[:, :, 0] + M22.unsqueeze(-1) * Jc[:, :, 1]
-    Hcc = torch.matmul(Jc[:, :, 0].transpose(1, 2), MJ0) + torch.matmul(Jc[:, :, 1].transpose(1, 2), MJ1)
-    bc = (Jc[:, :, 0] * g1.unsqueeze(-1) + Jc[:, :, 1] * g2.unsqueeze(-1)).sum(dim=1)
-    nb = conv1.shape[0]
-    if bundle:
-        jd = DepthJacobianMatrix(rx.unsqueeze(1), ry.unsqueeze(1), rz.unsqueeze(1), x, y, Z, fx8, fy8)
-        u = MJ0 * jd[..., 0:1] + MJ1 * jd[..., 1:2]
-        s_ = M11 * jd[..., 0] ** 2 + 2.0 * M12 * jd[..., 0] * jd[..., 1] + M22 * jd[..., 1] ** 2
-        r = jd[..., 0] * g1 + jd[..., 1] * g2
-        Hcd = torch.matmul(u.transpose(1, 2), Bs)
-        Hdd = torch.matmul(Bs.transpose(1, 2), Bs * s_.unsqueeze(-1))
-        bd = torch.matmul(Bs.transpose(1, 2), r.unsqueeze(-1)).squeeze(-1)
-        AtA = torch.cat([torch.cat([Hcc, Hcd], dim=2), torch.cat([Hcd.transpose(1, 2), Hdd], dim=2)], dim=1)
-        Atb = torch.cat([bc, bd], dim=1).unsqueeze(-1)
-        diag = torch.diagonal(AtA, dim1=1, dim2=2)
-        damp = torch.cat([diag[:, :-1] + 1e-5, torch.zeros(nb, 1, device=diag.device, dtype=diag.dtype)], dim=-1)
-    else:
-        AtA, Atb = Hcc, bc.unsqueeze(-1)
-        damp = torch.diagonal(AtA, dim1=1, dim2=2) + 1e-5
-    sol = torch.linalg.solve(AtA + torch.diag_embed(damp * lam.squeeze(-1)), Atb)
-    wx, wy, wz = sol[:, 0], sol[:, 1], sol[:, 2]
-    dr = AngleaAxisRotation(wx, wy, wz)
-    dv = VMatrix(wx.reshape(-1), wy.reshape(-1), wz.reshape(-1))
-    return torch.matmul(dr, R), torch.matmul(dv, sol[:, 3:6]) + torch.matmul(dr, T), (Wc + sol[:, 6:]) if bundle else None
+def _sparse_iteration64(*args):
+    """the float64 yardstick of both float32 training graphs: oracle/torch_port.sparse_iteration -- bundlenet.py:122-278 on sparse
+    points as differentiable torch statements, written with the ORACLE's own helpers (round 6: it used to be built from the product's
+    torch helpers) and pinned to the numpy oracle on the CPU (tests/test_torch_ref_cpu.py)"""
+    from oracle import torch_port
+    return torch_port.sparse_iteration(*args)
 
 
 @pytest.mark.parametrize("B,N,C,K,H,W", [(2, 4096, 128, 128, 96, 128),      # the reference's training shape class (bundlenet.py:332-399)

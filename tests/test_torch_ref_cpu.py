@@ -135,3 +135,39 @@ def test_window_twin_matches_oracle_window_iteration():
     np.testing.assert_allclose(R2.numpy(), np.stack(Rn, 1), rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(T2.numpy(), np.stack(Tn, 1), rtol=1e-8, atol=1e-12)
     np.testing.assert_allclose(W2.numpy(), Wn, rtol=1e-8, atol=1e-12)
+
+
+def test_sparse_iteration_twin_matches_the_numpy_oracle():
+    """oracle/torch_port.sparse_iteration (the differentiable float64 statement the GPU tests measure training gradients against)
+    == banet_oracle.bundle_iteration / bundle_camera_iteration on sampled points, incl. points that leave the image."""
+    from oracle import torch_port
+    rng = np.random.RandomState(3)
+    sc = synth.make_pair_scene(24, 32, 6, 5, [1], 9, normalize_rays=True, w_gt=[0.02, -0.015, 0.01], t_gt=[0.12, -0.08, 0.05])
+    intr, levels = odense.batch_scene([sc])
+    lv = levels[0]
+    N = 300
+    pts = np.stack([rng.uniform(0.2, 30.8, (1, N)), rng.uniform(0.2, 22.8, (1, N))], axis=-1)
+    fx = np.repeat(intr[:, 0:1], N, 1); fy = np.repeat(intr[:, 1:2], N, 1)
+    ox = np.repeat(intr[:, 2:3], N, 1); oy = np.repeat(intr[:, 3:4], N, 1)
+    p = orc.compute_coordinates(pts, fx, fy, ox, oy, True)
+    conv1 = orc.resampler(lv["src"].astype(np.float64), pts)
+    conv2 = orc.target_map(lv["tgt"].astype(np.float64))
+    D = orc.resampler(lv["D0"][..., None].astype(np.float64), pts)
+    Bs = orc.resampler(lv["basis"].astype(np.float64), pts)
+    R = synth.rodrigues(np.array([0.01, 0.004, -0.006]))[None]
+    T = (np.asarray(sc["T_gt"]) * 0.6).reshape(1, 3, 1)
+    Wc = rng.standard_normal((1, 5, 1)) * 0.02
+    mlp = orc.he_normal_mlp_weights(6, 4, np.float64)
+    tt = lambda x: torch.from_numpy(np.ascontiguousarray(np.asarray(x, np.float64)))  # noqa: E731
+    lw = [(tt(w).reshape(w.shape[-2], w.shape[-1]), tt(b).reshape(-1)) for w, b in mlp]
+    R2, T2, W2, dbg = orc.bundle_iteration(conv1, conv2, fx, fy, ox, oy, p, D, Bs, R, T, Wc, mlp, 1000.0)
+    assert 0 < dbg["mask"].sum() < N                          # some points really leave the image
+    r2, t2, w2 = torch_port.sparse_iteration(tt(conv1), tt(conv2), tt(D), tt(Bs), tt(R), tt(T), tt(Wc), lw, True, 1000.0,
+                                              tt(fx), tt(fy), tt(ox), tt(oy), tt(p))
+    for a, b in ((r2, R2), (t2, T2), (w2, W2)):
+        np.testing.assert_allclose(a.numpy(), b, rtol=1e-8, atol=1e-10 * max(np.abs(b).max(), 1.0))
+    Rc, Tc, _ = orc.bundle_camera_iteration(conv1, conv2, fx, fy, ox, oy, p, D, R, T, mlp)
+    rc, tc, _ = torch_port.sparse_iteration(tt(conv1), tt(conv2), tt(D), None, tt(R), tt(T), None, lw, False, 1.0,
+                                            tt(fx), tt(fy), tt(ox), tt(oy), tt(p))
+    np.testing.assert_allclose(rc.numpy(), Rc, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(tc.numpy(), Tc, rtol=1e-8, atol=1e-10)
