@@ -42,7 +42,7 @@ def test_every_declared_symbol_is_exported(capi):
 
 def test_version_and_error_strings(capi):
     L = capi.lib()
-    assert L.banet_version() == 140
+    assert L.banet_version() == 150
     assert L.banet_error_string(0) == b"ok"
     assert b"workspace" in L.banet_error_string(-2)
 
@@ -204,7 +204,7 @@ def test_plain_c_program_links_against_the_library(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
                            "-L", libdir, "-lbanet_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.check_output([str(exe)]).decode()
-    assert out.startswith("c-abi ok 140")
+    assert out.startswith("c-abi ok 150")
 
 
 def test_backward_entry_points_validate_their_arguments_without_gpu(capi):
