@@ -486,3 +486,31 @@ def test_adjoint_accepts_the_sparse_reference_layout(capi):
     assert ws(0, 1, 4096, 384, 512, C=200, K=200) == 0             # sparse: not C > 128 together with K > 128 ...
     assert ws(0, 1, 4096, 384, 512, C=200, K=64) > 0 and ws(0, 1, 4096, 384, 512, C=64, K=200) > 0
     assert ws(0, 1, 4096, 384, 512, K=0, variant=capi.BUNDLE_CAMERA) > 0       # pose-only iteration
+
+
+def test_round6_backward_entry_points_on_the_host(capi):
+    """banet_dense_adjoint_workspace_bytes_ex / banet_small_step_adjoint_*: the host-side plans and argument checks (no launch).
+    BANET_ADJOINT_FOLD_TARGET drops the 3C adjoint rows from the workspace, exists for the dense layout only; the small step is
+    compiled for bundle (K >= 1) and bundle_camera (K = 0) with a system the SPD kernel can hold (or P < 32)."""
+    L = capi.lib()
+    FOLD = 4
+    lv = capi.Level()
+    lv.B, lv.N, lv.C, lv.K, lv.H, lv.W = 32, 480 * 640, 128, 128, 480, 640
+    lv.variant, lv.dense, lv.scale, lv.pairs, lv.normalize_rays = capi.BUNDLE, 1, 1.0, 1, 1
+    plain, fold = L.banet_dense_adjoint_workspace_bytes_ex(ctypes.byref(lv), 0), L.banet_dense_adjoint_workspace_bytes_ex(ctypes.byref(lv), FOLD)
+    assert plain == L.banet_dense_adjoint_workspace_bytes(ctypes.byref(lv)) and 0 < fold < plain
+    rows = 4 * 32 * 480 * 640 * 3 * 128                       # the [B, N, 3C] adjoint rows: 15.1 GB that no longer exist
+    assert plain - fold > 0.95 * rows - 2 * 4 * 32 * 480 * 640 * 12
+    assert L.banet_dense_adjoint_workspace_bytes_ex(ctypes.byref(lv), 64 << 4) == 0          # unknown flag bits
+    lv.dense, lv.tgt_has_grad = 0, 1                          # the reference's sparse layout: the row-gather path only
+    keep = [ctypes.c_float(0)] * 5
+    for name in ("rays", "fx", "fy", "ox", "oy"):
+        setattr(lv, name, ctypes.addressof(keep[0]))
+    lv.N = 4096
+    assert L.banet_dense_adjoint_workspace_bytes_ex(ctypes.byref(lv), 0) > 0 and L.banet_dense_adjoint_workspace_bytes_ex(ctypes.byref(lv), FOLD) == 0
+    ws = L.banet_small_step_adjoint_workspace_bytes
+    assert ws(capi.BUNDLE, 32, 307200, 128, 128, 1) > 0 and ws(capi.BUNDLE, 8, 307200, 128, 128, 4) > 0       # P = 134, 152
+    assert ws(capi.BUNDLE_CAMERA, 4, 4096, 128, 0, 1) > 0                                     # P = 6: in-kernel Cholesky
+    assert ws(capi.BUNDLE, 8, 1228800, 128, 256, 7) == 0                                      # P = 298: beyond the SPD kernel's LDS
+    assert ws(capi.BUNDLE, 8, 1000, 300, 16, 1) == 0 and ws(capi.BUNDLE, 8, 1000, 64, 0, 1) == 0 and ws(capi.LEGACY_LM, 1, 100, 16, 0, 1) == 0
+    assert L.banet_small_step_adjoint_f32(capi.BUNDLE, 2, 100, 16, 8, 1, 1000.0, None, *([None] * 14), None, None, 0, None) == -1
