@@ -75,74 +75,104 @@ __device__ __forceinline__ void mlp_layer(const float* in, float* out, const flo
   mlp_layer_t<kSolveThreads>(in, out, Wt, bias, nin, nout, act, sPart, sred);
 }
 
-// Householder QR of a 6x6 system and back-substitution (thread 0, LDS-resident, fp32):
-// the algorithm class of tf.qr + tf.linalg.solve on the triangular factor.
-__device__ void qr_solve_small(float* A, int ld, float* rhs, int n, float* x) {
+// Householder QR of the 6x6 legacy system and back-substitution (thread 0, fp32): the algorithm class of tf.qr +
+// tf.linalg.solve on the triangular factor.  Round 6: the matrix lives in REGISTERS (every loop has compile-time bounds and is
+// unrolled) -- the LDS-resident loop form cost ~400 dependent LDS round trips and, with inverse_solve_small's dynamically indexed
+// rows, 644 scratch instructions in the kernel (round-5 review): same operations in the same order, so the same bits.
+__device__ void qr_solve_small(const float* A_lds, int ld, const float* rhs_in, int /*n = 6*/, float* x) {
+  constexpr int n = 6;
+  float A[n][n], rhs[n];
+#pragma unroll
+  for (int i = 0; i < n; ++i) {
+    rhs[i] = rhs_in[i];
+#pragma unroll
+    for (int j = 0; j < n; ++j) A[i][j] = A_lds[i * ld + j];
+  }
+#pragma unroll
   for (int k = 0; k < n; ++k) {
     float nrm = 0.f;
-    for (int i = k; i < n; ++i) nrm += A[i * ld + k] * A[i * ld + k];
+#pragma unroll
+    for (int i = k; i < n; ++i) nrm += A[i][k] * A[i][k];
     nrm = sqrtf(nrm);
-    if (nrm == 0.f) continue;
-    const float akk = A[k * ld + k];
-    const float alpha = akk > 0.f ? -nrm : nrm;
-    // v = a_k - alpha e_k  (stored over the column), beta = 2 / v^T v
-    A[k * ld + k] = akk - alpha;
-    float vtv = 0.f;
-    for (int i = k; i < n; ++i) vtv += A[i * ld + k] * A[i * ld + k];
-    const float beta = 2.f / vtv;
-    for (int j = k + 1; j < n; ++j) {
+    if (nrm != 0.f) {
+      const float akk = A[k][k];
+      const float alpha = akk > 0.f ? -nrm : nrm;
+      // v = a_k - alpha e_k  (stored over the column), beta = 2 / v^T v
+      A[k][k] = akk - alpha;
+      float vtv = 0.f;
+#pragma unroll
+      for (int i = k; i < n; ++i) vtv += A[i][k] * A[i][k];
+      const float beta = 2.f / vtv;
+#pragma unroll
+      for (int j = k + 1; j < n; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = k; i < n; ++i) s += A[i][k] * A[i][j];
+        s *= beta;
+#pragma unroll
+        for (int i = k; i < n; ++i) A[i][j] -= s * A[i][k];
+      }
       float s = 0.f;
-      for (int i = k; i < n; ++i) s += A[i * ld + k] * A[i * ld + j];
+#pragma unroll
+      for (int i = k; i < n; ++i) s += A[i][k] * rhs[i];
       s *= beta;
-      for (int i = k; i < n; ++i) A[i * ld + j] -= s * A[i * ld + k];
+#pragma unroll
+      for (int i = k; i < n; ++i) rhs[i] -= s * A[i][k];
+      A[k][k] = alpha;  // R's diagonal
     }
-    float s = 0.f;
-    for (int i = k; i < n; ++i) s += A[i * ld + k] * rhs[i];
-    s *= beta;
-    for (int i = k; i < n; ++i) rhs[i] -= s * A[i * ld + k];
-    A[k * ld + k] = alpha;  // R's diagonal
   }
+  float xs[n];
+#pragma unroll
   for (int k = n - 1; k >= 0; --k) {
     float s = rhs[k];
-    for (int j = k + 1; j < n; ++j) s -= A[k * ld + j] * x[j];
-    x[k] = s / A[k * ld + k];
+#pragma unroll
+    for (int j = k + 1; j < n; ++j) s -= A[k][j] * xs[j];
+    xs[k] = s / A[k][k];
   }
+#pragma unroll
+  for (int k = 0; k < n; ++k) x[k] = xs[k];
 }
 
 // tf.matmul(tf.matrix_inverse(AtA), Atb) for the 6x6 legacy system (legacy/ba.py:203,290, `qr = False`): the explicit
 // inverse by Gauss-Jordan elimination with partial pivoting (the algorithm class of tf.matrix_inverse: LU-PP solves
-// against the identity), then the product.  Thread 0, registers.
+// against the identity), then the product.  Thread 0, registers: the pivot row is brought up by conditional swaps with
+// compile-time row indices (the largest candidate ends in row k whatever the order of the others), so no row is addressed dynamically.
 __device__ void inverse_solve_small(const float* A, int ld, const float* rhs, float* x) {
   float M[6][12];
+#pragma unroll
   for (int i = 0; i < 6; ++i)
+#pragma unroll
     for (int j = 0; j < 6; ++j) {
       M[i][j] = A[i * ld + j];
       M[i][6 + j] = (i == j) ? 1.f : 0.f;
     }
+#pragma unroll
   for (int k = 0; k < 6; ++k) {
-    int p = k;
-    float best = fabsf(M[k][k]);
-    for (int i = k + 1; i < 6; ++i)
-      if (fabsf(M[i][k]) > best) {
-        best = fabsf(M[i][k]);
-        p = i;
-      }
-    if (p != k)
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i) {
+      const bool sw = fabsf(M[i][k]) > fabsf(M[k][k]);
+#pragma unroll
       for (int j = 0; j < 12; ++j) {
-        const float t = M[k][j];
-        M[k][j] = M[p][j];
-        M[p][j] = t;
+        const float a = M[k][j], c = M[i][j];
+        M[k][j] = sw ? c : a;
+        M[i][j] = sw ? a : c;
       }
+    }
     const float inv = 1.f / M[k][k];
+#pragma unroll
     for (int j = 0; j < 12; ++j) M[k][j] *= inv;
+#pragma unroll
     for (int i = 0; i < 6; ++i) {
       if (i == k) continue;
       const float f = M[i][k];
+#pragma unroll
       for (int j = 0; j < 12; ++j) M[i][j] = fmaf(-f, M[k][j], M[i][j]);
     }
   }
+#pragma unroll
   for (int i = 0; i < 6; ++i) {
     float s = 0.f;
+#pragma unroll
     for (int j = 0; j < 6; ++j) s = fmaf(M[i][6 + j], rhs[j], s);
     x[i] = s;
   }
