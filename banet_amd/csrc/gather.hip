@@ -24,7 +24,7 @@
 //      texel rows are coalesced 512-B loads with scalar bases; two pixels per trip = 26 loads in
 //      flight per wave; the five channel sums per pixel go through the same butterfly so that
 //      pixel j's sums land on lane j;
-//   4. 6x6 algebra with lane = pixel; H_cc in LDS accumulators (ds_add_f32, one owner per address).
+//   4. 6x6 algebra with lane = pixel; H_cc in LDS accumulators (one owner per address, plain read-modify-write).
 #include <algorithm>
 #include "gather_common.hpp"
 
@@ -106,10 +106,12 @@ __global__ __launch_bounds__(kBlock, BANET_GATHER_WAVES) void ba_gather_kernel(c
         valid = (py < H) && (px < W);
         return valid ? py * W + px : 0;
       }
-      const int pt = t * kTilePix + n;
-      valid = pt < N;
+      const int pt = t * a.tile_pts + n;        // sparse points: a.tile_pts (64, or 16 on latency-bound launches) per wave item
+      valid = n < a.tile_pts && pt < N;
       return valid ? pt : 0;
     };
+    // slots of this item that hold a point (wave-uniform); the others contribute exact zeros and are skipped
+    const int npts = dense ? 64 : min(a.tile_pts, N - t * a.tile_pts);
     bool valid;
     const int pt = point_of(lane, valid);
     BANET_TICK(tb0);
@@ -304,8 +306,9 @@ __global__ __launch_bounds__(kBlock, BANET_GATHER_WAVES) void ba_gather_kernel(c
       for (int tt = 0; tt < ((dbg & 8) ? 0 : 64); tt += 2) {
         const int j0 = brev6(tt);          // leaf tt+1 is pixel j0 + 32
         BANET_TICK(t0);
-        const Q5 qa = pixel_q5(j0);
-        const Q5 qb = pixel_q5(j0 + 32);
+        const Q5 zero5{0.f, 0.f, 0.f, 0.f, 0.f};
+        const Q5 qa = j0 < npts ? pixel_q5(j0) : zero5;
+        const Q5 qb = j0 + 32 < npts ? pixel_q5(j0 + 32) : zero5;
 #ifdef BANET_TIMING
         asm volatile("" ::"v"(qa.m11), "v"(qb.m11), "v"(qa.g2), "v"(qb.g2));
 #endif
@@ -370,12 +373,12 @@ __global__ __launch_bounds__(kBlock, BANET_GATHER_WAVES) void ba_gather_kernel(c
       for (int i = 0; i < 6; ++i)
 #pragma unroll
         for (int j = i; j < 6; ++j) {
-          atomicAdd(&sH[w][o][lane], jc[i] * mj[j] + jc[6 + i] * mj[6 + j]);
-          ++o;
+          sH[w][o][lane] += jc[i] * mj[j] + jc[6 + i] * mj[6 + j];      // one owner per address: plain read-modify-write
+          ++o;                                                           // (ds_add_f32 measured ~240 ns each, round 6)
         }
 #pragma unroll
-      for (int i = 0; i < 6; ++i) atomicAdd(&sH[w][21 + i][lane], jc[i] * q.g1 + jc[6 + i] * q.g2);
-      atomicAdd(&sH[w][27][lane], (float)(gflags & 1));
+      for (int i = 0; i < 6; ++i) sH[w][21 + i][lane] += jc[i] * q.g1 + jc[6 + i] * q.g2;
+      sH[w][27][lane] += (float)(gflags & 1);
       if (a.mask_out != nullptr && valid) a.mask_out[(size_t)vb * N + pt] = (unsigned char)(gflags & 1);
       if constexpr (KCH > 0) {
         if (valid) {
@@ -457,8 +460,13 @@ int plan_gather(const banet_level_t* lv, GatherPlan* pl) {
     pl->tiles = pl->tiles_x * pl->tiles_y;
   } else {
     pl->tiles_x = pl->tiles_y = 0;
-    pl->tiles = (lv->N + kTilePix - 1) / kTilePix;
+    // Sparse points: 64 per wave item -- or 16 (round 6) while four times as many items still fit one resident round: the item is
+    // a serial chain of its points (the reference's own tracker, N = 4096 at batch 1: 64 items = 64 waves on 16 CUs, 54 us per launch)
+    const long long items64 = (long long)((lv->N + kTilePix - 1) / kTilePix) * Bsel * npairs(lv);
+    pl->tile_pts = (4 * items64 <= (long long)kCUs * kGenericBlocksPerCU * kNumWaves && !(lv->flags & 2)) ? 16 : kTilePix;   // bit 1: 64 (A/B)
+    pl->tiles = (lv->N + pl->tile_pts - 1) / pl->tile_pts;
   }
+  if (lv->dense) pl->tile_pts = kTilePix;
   pl->groups = (pl->tiles + 3) / 4;
   pl->c128 = use_c128(lv) ? 1 : 0;
   // The strip gather (gather128s.hip: 16 x 32-pixel segments, rolling LDS window, target map fetched 1.44 x instead of 2.15 x)
@@ -692,6 +700,7 @@ int launch_gather(const banet_level_t* lv, const GatherPlan& pl, const float* R,
   a.partials = partials;
   a.G = pl.G;
   a.tiles = pl.tiles;
+  a.tile_pts = pl.tile_pts;
   a.tiles_x = pl.tiles_x;
   a.tiles_y = pl.tiles_y;
   a.groups = pl.groups;

@@ -23,6 +23,7 @@ struct GatherArgs {
   int seg_h;        // ba_gather128s_kernel: pixel rows per strip segment (32 or 16)
   unsigned char* mask_out;   // optional (parity diagnostics): [B * pairs][N] the in-image mask bit of every pixel, or nullptr
   int strip_fp;     // ba_gather128s_kernel: 1 = frame-parallel workgroups (`pairs` waves per segment, one per target frame)
+  int tile_pts;     // ba_gather_kernel, sparse points: points per wave item (64 or 16)
 };
 
 template <int VEC>

@@ -30,6 +30,7 @@ struct GatherPlan {
   int nbands;   // tile-queue bands (8 = one per XCD)
   int pairloop; // patch kernel: target frames looped over inside a tile (grid y = windows)
   int qshift;   // 2: quarter-tile work items (levels with fewer tiles than resident waves)
+  int tile_pts; // generic kernel, sparse points: points per wave item (64; 16 on latency-bound launches)
   size_t off_fold, off_queue;   // inside the partial region
   size_t partial_bytes, rec_bytes;
 };

@@ -236,3 +236,37 @@ def test_solve_differentiable_with_the_hip_small_step_equals_the_torch_small_ste
         for x, y in zip(res[True], res[False]):
             assert torch.isfinite(x).all()
             assert float((x - y).abs().max()) <= 2e-4 * max(float(y.abs().max()), 1e-30)
+
+
+@pytest.mark.parametrize("B,N,C,K", [(1, 4096, 128, 0), (2, 1000, 70, 33), (3, 777, 128, 128)])
+def test_sparse_gather_with_16_point_items_equals_the_64_point_items(B, N, C, K):
+    """ba_gather_kernel on sparse points (the reference's tracker / training layout): latency-bound launches cut the wave items to 16
+    points (round 6: 4x the waves, the reference's own N = 4096 batch-1 tracker 2.06 -> 1.35 ms per solve); flags bit 1 keeps 64.
+    Same sums to rounding (another grouping of the partial rows), the in-image counts exactly; ragged N (a last item with empty slots)."""
+    from banet_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    H, W = 48, 64
+    img = torch.randn(B, H, W, C, generator=g).to(DEV)
+    conv2 = ops.target_map(img)
+    pts = torch.stack([torch.rand(B, N, generator=g) * (W + 2) - 1.5, torch.rand(B, N, generator=g) * (H + 2) - 1.5], dim=-1).to(DEV)
+    conv1 = ops.resample(img, pts.clamp(min=0.0)) + 0.05 * torch.randn(B, N, C, generator=g).to(DEV)
+    fx = torch.full((B, N), 0.8 * W, device=DEV)
+    ox, oy = torch.full((B, N), W / 2.0, device=DEV), torch.full((B, N), H / 2.0, device=DEV)
+    ray = torch.stack([(pts[..., 0] - ox) / fx, (pts[..., 1] - oy) / fx, torch.ones(B, N, device=DEV)], dim=1)
+    p = (ray / ray.norm(dim=1, keepdim=True)).contiguous()
+    D = (2.5 + torch.rand(B, N, generator=g)).to(DEV)
+    Bs = (torch.randn(B, N, K, generator=g) / max(K, 1) ** 0.5).to(DEV) if K else None
+    R = torch.eye(3, device=DEV).repeat(B, 1, 1)
+    T = (0.02 * torch.randn(B, 3, 1, generator=g)).to(DEV)
+    Wc = (0.01 * torch.randn(B, K, 1, generator=g)).to(DEV) if K else None
+    outs = {}
+    for bits in (0, 2):
+        prob = ops.LevelProblem("bundle" if K else "bundle_camera", conv1, conv2, D, H, W, C, basis=Bs, rays=p, fx=fx, fy=fx.clone(), ox=ox, oy=oy,
+                                dense=False, tgt_has_grad=True)
+        prob.c.flags = bits
+        outs[bits] = [x.double().cpu() for x in ops.ba_assemble(prob, R, T, Wc)]
+    torch.cuda.synchronize()
+    assert 0 < float(outs[0][3].min()) and float(outs[0][3].max()) < N                 # some points are outside the image
+    assert torch.equal(outs[0][3], outs[2][3])                                          # in-image counts: exact
+    for a, b_ in zip(outs[0][:3], outs[2][:3]):
+        assert float((a - b_).abs().max()) <= 2e-5 * float(b_.abs().max())
