@@ -2230,7 +2230,10 @@ bool adj_supported(const banet_level_t* lv) {
 }
 
 // fold mode: the dense layout (the target map holds features, gradients are formed from it), any C the pixel kernels take
-bool adj_fold_supported(const banet_level_t* lv) { return adj_supported(lv) && lv->dense == 1 && lv->tgt_has_grad == 0; }
+bool adj_fold_supported(const banet_level_t* lv) {
+  // (the tile kernels address a window's target map with 32-bit float offsets)
+  return adj_supported(lv) && lv->dense == 1 && lv->tgt_has_grad == 0 && (size_t)lv->H * lv->W * lv->C < ((size_t)1 << 31);
+}
 
 void adj_plan(const banet_level_t* lv, int flags, AdjPlan* pl) {
   const size_t B = lv->B, N = lv->N, C = lv->C, K = lv->K, P = 6 + K, HW = (size_t)lv->H * lv->W;   // (dense: HW == N)

@@ -48,6 +48,14 @@ for it in range(count):
     errs["dT"] = float(np.abs(dpose[:, 9:12] - want["dT"].reshape(B, 3)).max() / max(np.abs(want["dT"]).max(), 1e-30))
     if not camera:
         errs["dW"] = float(np.abs(dpose[:, 12:] - want["dW"].reshape(B, K)).max() / max(np.abs(want["dW"]).max(), 1e-30))
+    # round 6: the target-tile path (BANET_ADJOINT_FOLD_TARGET) with a random tile kernel / shape: its target gradient against the
+    # float64 statement, every other output bit-equal to the row-gather path's
+    shape = int(rng0.choice([0, 1, 2, 3, 4, 5, 8, 9, 10, 11, 12, 13]))
+    gf = tb._run_adjoint(intr, lv, R, T, Wc, G, gb, gabs, variant="bundle_camera" if camera else "bundle", fold=True, tile=shape)
+    errs["dtgt_tile%d" % shape] = float(np.abs(tb.n(gf["dtgt"]).reshape(want["dtgt"].shape) - want["dtgt"]).max() / max(np.abs(want["dtgt"]).max(), 1e-30))
+    for k in ("dsrc", "ddepth", "dpose") + (() if camera else ("dbasis",)):
+        if not torch.equal(gf[k], got[k]):
+            errs["tile_vs_rows_" + k] = 1.0
     bad = {k: v for k, v in errs.items() if not (v < (5e-4 if k in ("dR", "dT", "dW") else 2e-4))}
     if bad:
         fails += 1
