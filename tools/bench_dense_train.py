@@ -60,4 +60,6 @@ print("  forward only (lm_level)                 %8.2f ms   (%.1f LM it/s)" % (f
 print("  forward + backward (solve_differentiable) %6.2f ms   (%.1f LM it/s, %.2fx the forward), peak extra memory %.2f GB"
       % (t_ms, nit / t_ms * 1e3, t_ms / f_ms, mem))
 from banet_amd import dense_train
-print("  small backward step (lambda MLP / damping / solve / update adjoint on [B,P,P]):", dense_train.small_step_modes())
+modes = dense_train.small_step_modes()       # empty when the HIP small step ran (smallstep.hip: four launches, no torch graph)
+print("  small backward step (lambda MLP / damping / solve / update adjoint on [B,P,P]):",
+      modes if modes else "HIP (banet_small_step_adjoint_f32)")
