@@ -24,6 +24,7 @@
 //   adj_fold_kernel     per-wave partials -> dpose [B, 12 + K] in fixed order
 // and, once per level after all iterations, target_map_adjoint_kernel: d tgt += dmap_f + grad_fixed^T (dmap_gx, dmap_gy)
 // (REFLECT rim: bundlenet.py:92-100).
+#include <type_traits>
 #include <algorithm>
 #include <cstdlib>
 
@@ -753,6 +754,10 @@ __global__ __launch_bounds__(kBlock, (KJ >= 3 ? 2 : 3)) void adj_pixel_kernel(co
 // per pair of pixels instead of once per pixel, and the eight reductions per pixel run over 32 lanes (DPP row sum + one
 // permlane swap).  C % 4 == 0, C <= 128 CJ4, K % 4 == 0, K <= 128.  Pixels outside the image take safe coordinates and skip
 // their stores (the two halves of a wave diverge, so there is no early exit).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
+__device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ float hsum(float v) {   // sum over the 32 lanes of each half wave, every lane gets its half's total
   v = row16_sum(v);
   return bfly_merge(v, v, 16);
@@ -767,14 +772,33 @@ __global__ __launch_bounds__(kBlock, 2) void adj_pixel2_kernel(const AdjArgs a) 
   const float* __restrict__ src_b = lv.src + (size_t)b * N * C;
   const float* __restrict__ tgt_b = lv.tgt + (size_t)b * N * C;
   const float* __restrict__ bas_b = lv.basis + (size_t)b * N * K;
+  // every row of the loop = a per-window base (wave-uniform: scalar registers) + an unsigned 32-bit BYTE offset (launch_dense_adjoint
+  // takes this kernel only while a window's largest array, N x 3C floats, stays below 4 GB): no 64-bit address arithmetic per access
+  const char* const src_c = reinterpret_cast<const char*>(src_b);
+  const char* const tgt_c = reinterpret_cast<const char*>(tgt_b);
+  const char* const bas_c = reinterpret_cast<const char*>(bas_b);
+  const char* const arec_c = reinterpret_cast<const char*>(a.arec + (size_t)b * N * 8);
+  const char* const dep_c = reinterpret_cast<const char*>(lv.depth + (size_t)b * N);
+  const char* const z2_c = reinterpret_cast<const char*>(a.z2 + (size_t)b * N * K);
+  char* const dsrc_c = reinterpret_cast<char*>(a.dsrc + (size_t)b * N * C);
+  char* const dbas_c = reinterpret_cast<char*>(a.dbasis + (size_t)b * N * K);
+  char* const ddep_c = reinterpret_cast<char*>(a.ddepth + (size_t)b * N);
+  char* const frac_c = reinterpret_cast<char*>(a.frac + (size_t)b * N * kFrac);
+  char* const cnt_c = reinterpret_cast<char*>(a.cnt + (size_t)b * H * W);
+  char* const arow_c = a.arow ? reinterpret_cast<char*>(a.arow + (size_t)b * N * 3 * C) : nullptr;
+  const unsigned rowC = (unsigned)C * 4u, rowK = (unsigned)K * 4u;
+  // (pixel index x row bytes with the full-rate 24-bit multiply: N < 2^24 and the product < 2^32 are launch conditions; the 32-bit
+  // v_mul_lo / v_mad_u64 the compiler takes otherwise run at a quarter of the rate, 26 of them per pixel pair)
+  auto offC = [&](unsigned pix, unsigned add) { return __umul24(pix, rowC) + add; };
+  auto offK = [&](unsigned pix, unsigned add) { return __umul24(pix, rowK) + add; };
   const float* __restrict__ S = a.S + (size_t)b * P * P;
   const float* __restrict__ gb = a.gb + (size_t)b * P;
-  float Scc[6][6], gbc[6], Rm[9], Tv[3];
+  float Scc[6][6], gbc[6], Rm[9], Tv[3];      // S is symmetric (adj_sym_kernel): 21 distinct uniform values, not 36 -- the scalar registers are short
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     gbc[i] = gb[i];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) Scc[i][j] = S[i * P + j];
+    for (int j = i; j < 6; ++j) Scc[i][j] = Scc[j][i] = S[i * P + j];
   }
 #pragma unroll
   for (int i = 0; i < 9; ++i) Rm[i] = a.R[b * 9 + i];
@@ -799,11 +823,13 @@ __global__ __launch_bounds__(kBlock, 2) void adj_pixel2_kernel(const AdjArgs a) 
       for (int e = 0; e < 4; ++e) scd[i][e] = S[i * P + 6 + k0 + e];
   }
   bool cok[CJ4];
+  unsigned chb[CJ4];      // this lane's channel quad of chunk j as a byte offset into a row (clamped: a lane without channels reads quad 0)
   f32x4 ga[CJ4];
 #pragma unroll
   for (int j = 0; j < CJ4; ++j) {
     const int c = 4 * hl + 128 * j;
     cok[j] = c < C;
+    chb[j] = cok[j] ? (unsigned)c * 4u : 0u;
     ga[j] = cok[j] ? *reinterpret_cast<const f32x4*>(a.gabs + (size_t)b * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   float accR[9], accT[3];
@@ -823,18 +849,24 @@ __global__ __launch_bounds__(kBlock, 2) void adj_pixel2_kernel(const AdjArgs a) 
                                     // copies that wait for it on the spot); what a lane without coefficients / channels reads is masked where it is used
   f32x4 bv_n, ar0_n, ar1_n;
   float dep_n;
+  const unsigned kcb = (unsigned)kc * 4u;
   {
-    const size_t q0 = (size_t)b * N + pix_of(n_lo < n_hi ? n_lo : 0);
-    bv_n = *reinterpret_cast<const f32x4*>(bas_b + (q0 - (size_t)b * N) * K + kc);
-    ar0_n = *reinterpret_cast<const f32x4*>(a.arec + q0 * 8);
-    ar1_n = *reinterpret_cast<const f32x4*>(a.arec + q0 * 8 + 4);
-    dep_n = lv.depth[q0];
+    const unsigned q0 = (unsigned)pix_of(n_lo < n_hi ? n_lo : 0);
+    bv_n = *reinterpret_cast<const f32x4*>(bas_c + offK(q0, kcb));
+    ar0_n = *reinterpret_cast<const f32x4*>(arec_c + q0 * 32u);
+    ar1_n = *reinterpret_cast<const f32x4*>(arec_c + (q0 * 32u + 16u));
+    dep_n = *reinterpret_cast<const float*>(dep_c + q0 * 4u);
   }
+  int by = n_lo / W, bx = n_lo - by * W;               // (column, row) of the pair's first pixel, stepped along with n2 (uniform)
   for (int n2 = n_lo; n2 < n_hi; n2 += 2) {
     const int n = n2 + hi;
     const bool live = n < n_hi;
-    const int nn = live ? n : n_hi - 1;                 // a dead upper half recomputes the lower pixel and stores nothing
-    const int qy = nn / W, qx = nn - qy * W;
+    const int nn = live ? n : n_hi - 1;                 // a dead upper half recomputes the lower pixel (n_hi - 1 = n2: chunks are even) and stores nothing
+    int qx = bx + (live ? hi : 0), qy = by;
+    if (qx >= W) {
+      qx = 0;
+      ++qy;
+    }
     float p0 = ((float)qx * lv.scale - ox0) / fx0, p1 = ((float)qy * lv.scale - oy0) / fy0, p2 = 1.f;
     if (lv.normalize_rays) {
       const float inv = 1.f / sqrtf(fmaxf(p0 * p0 + p1 * p1 + p2 * p2, 1e-12f));
@@ -842,7 +874,7 @@ __global__ __launch_bounds__(kBlock, 2) void adj_pixel2_kernel(const AdjArgs a) 
       p1 *= inv;
       p2 *= inv;
     }
-    const size_t q = (size_t)b * N + nn;
+    const unsigned qn0 = (unsigned)nn;
     const f32x4 bv = bv_n, ar0 = ar0_n, ar1 = ar1_n;
     const float qv[6] = {ar0[0], ar0[1], ar0[2], ar0[3], ar1[0], ar1[1]};
     const float zeta = ar1[2], ee = ar1[3];
@@ -872,73 +904,65 @@ __global__ __launch_bounds__(kBlock, 2) void adj_pixel2_kernel(const AdjArgs a) 
       for (int cc = 0; cc < 4; ++cc) {
         if ((r == 0 || r == 3) && (cc == 0 || cc == 3)) continue;
         const int yy = min(max(y0 - 1 + r, 0), H - 1), xx = min(max(x0 - 1 + cc, 0), W - 1);
-        const float* __restrict__ row = tgt_b + (size_t)(yy * W + xx) * C;
+        const unsigned row = offC((unsigned)(__mul24(yy, W) + xx), 0u);
 #pragma unroll
-        for (int j = 0; j < CJ4; ++j) tex[j][r][cc] = *reinterpret_cast<const f32x4*>(row + (cok[j] ? 4 * hl + 128 * j : 0));
+        for (int j = 0; j < CJ4; ++j) tex[j][r][cc] = *reinterpret_cast<const f32x4*>(tgt_c + (row + chb[j]));
       }
     // this pair's source row and z2 row (needed after the taps / at the very end), the next pair's geometry rows
-    const f32x4 z2v = *reinterpret_cast<const f32x4*>(a.z2 + q * K + kc);
+    const f32x4 z2v = *reinterpret_cast<const f32x4*>(z2_c + offK(qn0, kcb));
     f32x4 f1v[CJ4];
 #pragma unroll
-    for (int j = 0; j < CJ4; ++j) f1v[j] = *reinterpret_cast<const f32x4*>(src_b + (size_t)nn * C + (cok[j] ? 4 * hl + 128 * j : 0));
+    for (int j = 0; j < CJ4; ++j) f1v[j] = *reinterpret_cast<const f32x4*>(src_c + offC(qn0, chb[j]));
     f32x4 ds_old[CJ4], db_old;      // accumulate mode: the old contents travel with the texels
     float dd_old = 0.f;
     if constexpr (!OW) {
 #pragma unroll
-      for (int j = 0; j < CJ4; ++j) ds_old[j] = *reinterpret_cast<const f32x4*>(a.dsrc + q * C + (cok[j] ? 4 * hl + 128 * j : 0));
-      db_old = *reinterpret_cast<const f32x4*>(a.dbasis + q * K + kc);
-      dd_old = a.ddepth[q];
+      for (int j = 0; j < CJ4; ++j) ds_old[j] = *reinterpret_cast<const f32x4*>(dsrc_c + offC(qn0, chb[j]));
+      db_old = *reinterpret_cast<const f32x4*>(dbas_c + offK(qn0, kcb));
+      dd_old = *reinterpret_cast<const float*>(ddep_c + qn0 * 4u);
     }
     {
-      const int nx = pix_of(n2 + 2 < n_hi ? n2 + 2 : n2);      // (the last pair requests itself again: no branch around the loads)
-      const size_t qn = (size_t)b * N + nx;
-      bv_n = *reinterpret_cast<const f32x4*>(bas_b + (size_t)nx * K + kc);
-      ar0_n = *reinterpret_cast<const f32x4*>(a.arec + qn * 8);
-      ar1_n = *reinterpret_cast<const f32x4*>(a.arec + qn * 8 + 4);
-      dep_n = lv.depth[qn];
+      const unsigned nx = (unsigned)pix_of(n2 + 2 < n_hi ? n2 + 2 : n2);      // (the last pair requests itself again: no branch around the loads)
+      bv_n = *reinterpret_cast<const f32x4*>(bas_c + offK(nx, kcb));
+      ar0_n = *reinterpret_cast<const f32x4*>(arec_c + nx * 32u);
+      ar1_n = *reinterpret_cast<const f32x4*>(arec_c + (nx * 32u + 16u));
+      dep_n = *reinterpret_cast<const float*>(dep_c + nx * 4u);
     }
     // ---- per-pixel algebra, the part without M and g (as adj_pixel_kernel), under the texel loads
+    // (written on PAIRS (row 0, row 1) of the 2 x 6 Jacobian: one packed operation per pair, element by element the same chain of
+    // fused multiply-adds as adj_pixel_kernel -- left to itself the compiler packs across the column index instead and spends
+    // ~130 register copies per pixel pair on building its operands)
     const float iz = 1.f / Z;
-    float J0[6], J1[6];
-    J0[0] = fx * (-(x * y));
-    J0[1] = fx * (1.f + x * x);
-    J0[2] = fx * (-y);
-    J0[3] = fx * iz;
-    J0[4] = 0.f;
-    J0[5] = fx * (-(x * iz));
-    J1[0] = fy * (-1.f - y * y);
-    J1[1] = fy * (x * y);
-    J1[2] = fy * x;
-    J1[3] = 0.f;
-    J1[4] = fy * iz;
-    J1[5] = fy * (-(y * iz));
-    const float jd0 = fx * ((rx - rz * x) * iz), jd1 = fy * ((ry - rz * y) * iz);
-    float JS0[6], JS1[6];
+    const f32x2 fxy = {fx, fy};
+    f32x2 Jp[6];
+    Jp[0] = fxy * f32x2{-(x * y), -1.f - y * y};
+    Jp[1] = fxy * f32x2{1.f + x * x, x * y};
+    Jp[2] = fxy * f32x2{-y, x};
+    Jp[3] = f32x2{fx * iz, 0.f};
+    Jp[4] = f32x2{0.f, fy * iz};
+    Jp[5] = fxy * f32x2{-(x * iz), -(y * iz)};
+    const f32x2 jdp = fxy * f32x2{(rx - rz * x) * iz, (ry - rz * y) * iz};
+    const float jd0 = jdp[0], jd1 = jdp[1];
+    f32x2 JSp[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      float s0 = jd0 * qv[j], s1 = jd1 * qv[j];
+      f32x2 sp = jdp * qv[j];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        s0 = fmaf(J0[i], Scc[i][j], s0);
-        s1 = fmaf(J1[i], Scc[i][j], s1);
-      }
-      JS0[j] = s0;
-      JS1[j] = s1;
+      for (int i = 0; i < 6; ++i) sp = fma2(Jp[i], splat2(Scc[i][j]), sp);
+      JSp[j] = sp;
     }
-    float t0 = jd0 * zeta, t1 = jd1 * zeta, dM11 = 0.f, dM12 = 0.f, dM22 = 0.f, dg1 = jd0 * ee, dg2 = jd1 * ee;
+    f32x2 tp = jdp * zeta, dgp = jdp * ee, dMd = {0.f, 0.f};
+    float dM12 = 0.f;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      t0 = fmaf(J0[i], qv[i], t0);
-      t1 = fmaf(J1[i], qv[i], t1);
-      dM11 = fmaf(JS0[i], J0[i], dM11);
-      dM12 = fmaf(JS0[i], J1[i], dM12);
-      dM22 = fmaf(JS1[i], J1[i], dM22);
-      dg1 = fmaf(J0[i], gbc[i], dg1);
-      dg2 = fmaf(J1[i], gbc[i], dg2);
+      tp = fma2(Jp[i], splat2(qv[i]), tp);
+      dMd = fma2(JSp[i], Jp[i], dMd);
+      dM12 = fmaf(JSp[i][0], Jp[i][1], dM12);
+      dgp = fma2(Jp[i], splat2(gbc[i]), dgp);
     }
-    dM11 = fmaf(t0, jd0, dM11);
-    dM12 = fmaf(t0, jd1, dM12);
-    dM22 = fmaf(t1, jd1, dM22);
+    dMd = fma2(tp, jdp, dMd);
+    dM12 = fmaf(tp[0], jd1, dM12);
+    const float t0 = tp[0], t1 = tp[1], dg1 = dgp[0], dg2 = dgp[1], dM11 = dMd[0], dM22 = dMd[1];
     asm volatile("" ::: "memory");      // (keeps the block above ahead of the first use of a texel)
     f32x4 Sf[CJ4], Sgx[CJ4], Sgy[CJ4], Ax[CJ4][3], Ay[CJ4][3];
 #pragma unroll
@@ -947,30 +971,44 @@ __global__ __launch_bounds__(kBlock, 2) void adj_pixel2_kernel(const AdjArgs a) 
 #pragma unroll
       for (int e = 0; e < 3; ++e) Ax[j][e] = Ay[j][e] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // the four taps.  `inner` (every footprint of the wave off the image rim: nearly always) knows fin = 1, hx = hy = 0.5 at compile
+    // time -- ~75 instructions less per pair; same values, and explicit fused multiply-adds so that the two paths (and the two
+    // instantiations of this kernel) round alike
+    auto taps = [&](auto innerc) __attribute__((always_inline)) {
+      constexpr bool IN = decltype(innerc)::value;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int ix = t & 1, iy = t >> 1;
-      const int tx = x0 + ix, ty = y0 + iy;
-      const bool in = tx <= W - 1 && ty <= H - 1;
-      const float hx = (in && tx > 0 && tx < W - 1) ? 0.5f : 0.f, hy = (in && ty > 0 && ty < H - 1) ? 0.5f : 0.f;
-      const float fin = in ? 1.f : 0.f;
-      const float wx = ix ? ax : 1.f - ax, wy = iy ? ay : 1.f - ay;
-      const float wt = wx * wy, sx = (ix ? 1.f : -1.f) * wy, sy = (iy ? 1.f : -1.f) * wx;
+      for (int t = 0; t < 4; ++t) {
+        const int ix = t & 1, iy = t >> 1;
+        const int tx = x0 + ix, ty = y0 + iy;
+        const bool in = IN || (tx <= W - 1 && ty <= H - 1);
+        const float hx = (IN || (in && tx > 0 && tx < W - 1)) ? 0.5f : 0.f, hy = (IN || (in && ty > 0 && ty < H - 1)) ? 0.5f : 0.f;
+        const float wx = ix ? ax : 1.f - ax, wy = iy ? ay : 1.f - ay;
+        const float wt = wx * wy, sx = (ix ? 1.f : -1.f) * wy, sy = (iy ? 1.f : -1.f) * wx;
+        const f32x4 wt4 = {wt, wt, wt, wt}, sx4 = {sx, sx, sx, sx}, sy4 = {sy, sy, sy, sy};
 #pragma unroll
-      for (int j = 0; j < CJ4; ++j) {
-        const f32x4 F = fin * tex[j][1 + iy][1 + ix];
-        const f32x4 GX = hx * (tex[j][1 + iy][2 + ix] - tex[j][1 + iy][ix]);
-        const f32x4 GY = hy * (tex[j][2 + iy][1 + ix] - tex[j][iy][1 + ix]);
-        Sf[j] += wt * F;
-        Sgx[j] += wt * GX;
-        Sgy[j] += wt * GY;
-        Ax[j][0] += sx * F;
-        Ax[j][1] += sx * GX;
-        Ax[j][2] += sx * GY;
-        Ay[j][0] += sy * F;
-        Ay[j][1] += sy * GX;
-        Ay[j][2] += sy * GY;
+        for (int j = 0; j < CJ4; ++j) {
+          f32x4 F = tex[j][1 + iy][1 + ix];
+          if (!IN && !in) F = f32x4{0.f, 0.f, 0.f, 0.f};
+          const f32x4 GX = hx * (tex[j][1 + iy][2 + ix] - tex[j][1 + iy][ix]);
+          const f32x4 GY = hy * (tex[j][2 + iy][1 + ix] - tex[j][iy][1 + ix]);
+          Sf[j] = fma4(wt4, F, Sf[j]);
+          Sgx[j] = fma4(wt4, GX, Sgx[j]);
+          Sgy[j] = fma4(wt4, GY, Sgy[j]);
+          Ax[j][0] = fma4(sx4, F, Ax[j][0]);
+          Ax[j][1] = fma4(sx4, GX, Ax[j][1]);
+          Ax[j][2] = fma4(sx4, GY, Ax[j][2]);
+          Ay[j][0] = fma4(sy4, F, Ay[j][0]);
+          Ay[j][1] = fma4(sy4, GX, Ay[j][1]);
+          Ay[j][2] = fma4(sy4, GY, Ay[j][2]);
+        }
       }
+    };
+    if (__builtin_expect(__all(x0 >= 1 && y0 >= 1 && x0 + 2 <= W - 1 && y0 + 2 <= H - 1) != 0, 1)) {
+      taps(std::true_type{});
+    } else {
+      asm volatile("" ::: "memory");
+      taps(std::false_type{});
+      asm volatile("" ::: "memory");
     }
     f32x4 dif[CJ4];
     float M11 = 0.f, M12 = 0.f, M22 = 0.f, g1 = 0.f, g2 = 0.f;
@@ -993,20 +1031,27 @@ __global__ __launch_bounds__(kBlock, 2) void adj_pixel2_kernel(const AdjArgs a) 
     g1 = hsum(g1);
     g2 = hsum(g2);
     // ---- per-pixel algebra, the part with M and g
-    float dJ0[6], dJ1[6], u[6];
-    const float Mjd0 = M11 * jd0 + M12 * jd1, Mjd1 = M12 * jd0 + M22 * jd1;
+    f32x2 dJp[6];
+    float u[6];
+    const f32x2 Mr0 = {M11, M12}, Mr1 = {M12, M22}, gp = {g1, g2};
+    const float Mjd0 = fmaf(M11, jd0, M12 * jd1), Mjd1 = fmaf(M12, jd0, M22 * jd1);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      dJ0[i] = 2.f * (M11 * JS0[i] + M12 * JS1[i]) + g1 * gbc[i];
-      dJ1[i] = 2.f * (M12 * JS0[i] + M22 * JS1[i]) + g2 * gbc[i];
-      u[i] = J0[i] * Mjd0 + J1[i] * Mjd1;
+      dJp[i] = fma2(splat2(2.f), fma2(Mr0, splat2(JSp[i][0]), Mr1 * JSp[i][1]), gp * gbc[i]);
+      u[i] = fmaf(Jp[i][0], Mjd0, Jp[i][1] * Mjd1);
     }
-    const float djd0 = 2.f * (M11 * t0 + M12 * t1) + g1 * ee, djd1 = 2.f * (M12 * t0 + M22 * t1) + g2 * ee;
-    const float s_n = jd0 * Mjd0 + jd1 * Mjd1, r_n = jd0 * g1 + jd1 * g2;
+    const f32x2 djdp = fma2(splat2(2.f), fma2(Mr0, splat2(t0), Mr1 * t1), gp * ee);
+    const float djd0 = djdp[0], djd1 = djdp[1];
+    const float s_n = fmaf(jd0, Mjd0, jd1 * Mjd1), r_n = fmaf(jd0, g1, jd1 * g2);
+    float dJ0[6], dJ1[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      dJ0[i] = dJp[i][0];
+      dJ1[i] = dJp[i][1];
+    }
     // ---- channel adjoints
     float dpx = 0.f, dpy = 0.f;
-    float* __restrict__ dsrc_n = a.dsrc + q * C + 4 * hl;
-    float* __restrict__ arow_n = a.arow + q * 3 * C + 4 * hl;
+    const unsigned dsrc_o = offC(qn0, (unsigned)hl * 16u), arow_o = 3u * offC(qn0, 0u) + (unsigned)hl * 16u;     // (base + 32-bit offset at every store)
 #pragma unroll
     for (int j = 0; j < CJ4; ++j) {
       if (cok[j]) {
@@ -1023,17 +1068,17 @@ __global__ __launch_bounds__(kBlock, 2) void adj_pixel2_kernel(const AdjArgs a) 
           dpx += -dd[e] * Ax[j][0][e] + dgx[e] * Ax[j][1][e] + dgy[e] * Ax[j][2][e];
           dpy += -dd[e] * Ay[j][0][e] + dgx[e] * Ay[j][1][e] + dgy[e] * Ay[j][2][e];
         }
-        if (OW && live && !m) *reinterpret_cast<f32x4*>(dsrc_n + 128 * j) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (OW && live && !m) *reinterpret_cast<f32x4*>(dsrc_c + (dsrc_o + 512u * j)) = f32x4{0.f, 0.f, 0.f, 0.f};
         if (m) {
-          f32x4* ds = reinterpret_cast<f32x4*>(dsrc_n + 128 * j);
+          f32x4* ds = reinterpret_cast<f32x4*>(dsrc_c + (dsrc_o + 512u * j));
           if constexpr (OW)
             *ds = dd;
           else
             *ds = ds_old[j] + dd;
-          if (a.arow) {
-            *reinterpret_cast<f32x4*>(arow_n + 128 * j) = -dd;
-            *reinterpret_cast<f32x4*>(arow_n + C + 128 * j) = dgx;
-            *reinterpret_cast<f32x4*>(arow_n + 2 * C + 128 * j) = dgy;
+          if (arow_c) {
+            *reinterpret_cast<f32x4*>(arow_c + (arow_o + 512u * j)) = -dd;
+            *reinterpret_cast<f32x4*>(arow_c + (arow_o + rowC + 512u * j)) = dgx;
+            *reinterpret_cast<f32x4*>(arow_c + (arow_o + 2u * rowC + 512u * j)) = dgy;
           }
         }
       }
@@ -1077,26 +1122,31 @@ __global__ __launch_bounds__(kBlock, 2) void adj_pixel2_kernel(const AdjArgs a) 
         v[e] = fmaf(2.f, su, fmaf(dD, wc[e], fmaf(r_n, gbd[e], s_n * z2v[e])));
         dwc[e] = fmaf(dD, bv[e], dwc[e]);
       }
-      f32x4* db = reinterpret_cast<f32x4*>(a.dbasis + q * K + k0);
+      f32x4* db = reinterpret_cast<f32x4*>(dbas_c + offK(qn0, kcb));
       if constexpr (OW)
         *db = v;
       else
         *db = db_old + v;
     } else if (OW && live && kok) {
-      *reinterpret_cast<f32x4*>(a.dbasis + q * K + k0) = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(dbas_c + offK(qn0, kcb)) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (hl == 0 && live) {
-      float* __restrict__ fr = a.frac + q * kFrac;
-      if (OW && !m) a.ddepth[q] = 0.f;
+      const unsigned fro = qn0 * (unsigned)(kFrac * 4), ddo = qn0 * 4u;
+      if (OW && !m) *reinterpret_cast<float*>(ddep_c + ddo) = 0.f;
       if (m) {
-        a.ddepth[q] = OW ? dD : dd_old + dD;
+        *reinterpret_cast<float*>(ddep_c + ddo) = OW ? dD : dd_old + dD;
         const int key = y0 * W + x0;
-        *reinterpret_cast<f32x4*>(fr) = f32x4{__int_as_float(key), ax, ay, dg1};
-        *reinterpret_cast<f32x4*>(fr + 4) = f32x4{dg2, dM11, dM12, dM22};
-        atomicAdd(&a.cnt[(size_t)b * H * W + key], 1);
+        *reinterpret_cast<f32x4*>(frac_c + fro) = f32x4{__int_as_float(key), ax, ay, dg1};
+        *reinterpret_cast<f32x4*>(frac_c + (fro + 16u)) = f32x4{dg2, dM11, dM12, dM22};
+        atomicAdd(reinterpret_cast<int*>(cnt_c + (unsigned)key * 4u), 1);
       } else {
-        fr[0] = __int_as_float(-1);
+        *reinterpret_cast<float*>(frac_c + fro) = __int_as_float(-1);
       }
+    }
+    bx += 2;
+    while (bx >= W) {
+      bx -= W;
+      ++by;
     }
   }
   // the wave's partial row: lower half + upper half, fixed order
@@ -1696,24 +1746,31 @@ __global__ __launch_bounds__(64) void adj_tile2_kernel(const AdjArgs a, int tile
     f32x4 tex[4][4];           // the 4x4-minus-corners target texels of its cell
     int xy;                    // x0 | y0 << 16
   };
+  // every row address = a wave-uniform base + an unsigned 32-bit BYTE offset (adj_fold_supported: a window's maps stay below 4 GB):
+  // the loads take the base from scalar registers, no 64-bit address arithmetic per load
+  const char* const src_c = reinterpret_cast<const char*>(src_b);
+  const char* const tgt_c = reinterpret_cast<const char*>(tgt_b);
+  const char* const lrec_c = reinterpret_cast<const char*>(lrec);
+  const unsigned rowb = (unsigned)C * 4u, coffb = (unsigned)coff * 4u, pitchb = (unsigned)W * rowb;
   auto request = [&](int i, const int2 nx, Set& q) {
-    q.r0 = *reinterpret_cast<const f32x3*>(lrec + (size_t)i * kFrac + 1);
-    q.r1 = *reinterpret_cast<const f32x4*>(lrec + (size_t)i * kFrac + 4);
-    q.f1 = *reinterpret_cast<const f32x4*>(src_b + (size_t)nx.x * C + coff);
+    const unsigned ib = (unsigned)i * (unsigned)(kFrac * 4);
+    q.r0 = *reinterpret_cast<const f32x3*>(lrec_c + (ib + 4u));
+    q.r1 = *reinterpret_cast<const f32x4*>(lrec_c + (ib + 16u));
+    q.f1 = *reinterpret_cast<const f32x4*>(src_c + (__umul24((unsigned)nx.x, rowb) + coffb));      // (24-bit multiplies: full rate; N, W C 4 < 2^24: adj_fold_supported)
     q.xy = nx.y;
     const int cx = nx.y & 0xffff, cy = nx.y >> 16;
     unsigned xo[4], yo[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      xo[k] = (unsigned)min(max(cx - 1 + k, 0), W - 1) * (unsigned)C + (unsigned)coff;
-      yo[k] = (unsigned)min(max(cy - 1 + k, 0), H - 1) * ((unsigned)W * (unsigned)C);
+      xo[k] = __umul24((unsigned)min(max(cx - 1 + k, 0), W - 1), rowb) + coffb;
+      yo[k] = __umul24((unsigned)min(max(cy - 1 + k, 0), H - 1), pitchb);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
         if ((r == 0 || r == 3) && (cc == 0 || cc == 3)) continue;
-        q.tex[r][cc] = *reinterpret_cast<const f32x4*>(tgt_b + (yo[r] + xo[cc]));
+        q.tex[r][cc] = *reinterpret_cast<const f32x4*>(tgt_c + (yo[r] + xo[cc]));
       }
   };
   auto work_on = [&](int k, const Set& q) {
@@ -1823,29 +1880,35 @@ __global__ __launch_bounds__(64) void adj_tile2_kernel(const AdjArgs a, int tile
   if (nv > 0) {
     Set A, B;
     int2 nx1, nx2 = make_int2(0, 0);
+    int i1, i2;                           // the list indices of iterations k + 1 / k + 2 (each computed once: ~20 instructions)
     {
       const int i0 = list_index(0);
       const int2 nx0 = lidx[i0];
       request(i0, nx0, A);
-      nx1 = lidx[list_index(1)];          // (clamped: valid even when there is no second iteration)
+      i1 = list_index(1);                 // (clamped: valid even when there is no second iteration)
+      nx1 = lidx[i1];
     }
     wait_vm0();
     for (int k = 0; k < half; k += 2) {
       // iteration k on A: request k + 1 into B, the (pixel, cell) of k + 2.  Unconditionally (list_index clamps past the end: the
       // last iteration requests a valid pair it never uses) -- a conditional request makes the compiler merge the register set with
       // its old contents by copies that wait for the loads just issued
-      request(list_index(k + 1), nx1, B);
-      nx2 = lidx[list_index(k + 2)];
+      request(i1, nx1, B);
+      i2 = list_index(k + 2);
+      nx2 = lidx[i2];
       work_on(k, A);
       wait_vm0();
       nx1 = nx2;
+      i1 = i2;
       if (k + 1 >= half) break;
       // iteration k + 1 on B: request k + 2 into A
-      request(list_index(k + 2), nx1, A);
-      nx2 = lidx[list_index(k + 3)];
+      request(i1, nx1, A);
+      i2 = list_index(k + 3);
+      nx2 = lidx[i2];
       work_on(k + 1, B);
       wait_vm0();
       nx1 = nx2;
+      i1 = i2;
     }
   }
   // ---- the tile's texels: written once (overwrite_map) or added to the gradient of the earlier iterations; a half wave per texel
@@ -2231,8 +2294,9 @@ bool adj_supported(const banet_level_t* lv) {
 
 // fold mode: the dense layout (the target map holds features, gradients are formed from it), any C the pixel kernels take
 bool adj_fold_supported(const banet_level_t* lv) {
-  // (the tile kernels address a window's target map with 32-bit float offsets)
-  return adj_supported(lv) && lv->dense == 1 && lv->tgt_has_grad == 0 && (size_t)lv->H * lv->W * lv->C < ((size_t)1 << 31);
+  // (the tile kernels address a window's maps with 32-bit byte offsets built by 24-bit multiplies: pixel index, bytes per texel row)
+  return adj_supported(lv) && lv->dense == 1 && lv->tgt_has_grad == 0 && (size_t)lv->H * lv->W * lv->C < ((size_t)1 << 30) &&
+         lv->N < (1 << 24) && (size_t)lv->W * lv->C < ((size_t)1 << 22);
 }
 
 void adj_plan(const banet_level_t* lv, int flags, AdjPlan* pl) {
@@ -2443,7 +2507,8 @@ int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T
     BANET_ADJ_POINT(1, 4);
     BANET_ADJ_POINT(2, 4);
 #undef BANET_ADJ_POINT
-  } else if ((lv->C & 3) == 0 && (K & 3) == 0 && lv->C <= 128 && K <= 128 && !(lv->flags & (1 << 27))) {   // bit 27: one pixel per wave (A/B)
+  } else if ((lv->C & 3) == 0 && (K & 3) == 0 && lv->C <= 128 && K <= 128 && !(lv->flags & (1 << 27)) &&   // bit 27: one pixel per wave (A/B)
+             (size_t)N * 3 * lv->C < ((size_t)1 << 30) && N < (1 << 24)) {   // (32-bit byte offsets inside a window: its largest array is the N x 3C adjoint rows; 24-bit multiplies)
     if (a.overwrite)
       hipLaunchKernelGGL((adj_pixel2_kernel<1, true>), dim3(pl.G, B), dim3(kBlock), 0, s, a);   // (C = 256: 264 B of spills -> the one-pixel kernel)
     else

@@ -346,7 +346,8 @@ int banet_dense_adjoint_f32(const banet_level_t* lv, const float* R, const float
  *     tile, pixels in a fixed order (cells row-major, ascending pixel index): still no float atomics between waves, still
  *     bit-reproducible.  Neither the per-pixel 3C adjoint rows nor the [f|gx|gy] map adjoint exist, and banet_target_map_adjoint_f32
  *     is not called: 3C (N + HW) floats less memory per window, about a third of the backward's traffic.  The workspace layout
- *     differs: size it with banet_dense_adjoint_workspace_bytes_ex(lv, flags).  BANET_ADJOINT_TILE_SHAPE(k), k = 1 .. 13: development
+ *     differs: size it with banet_dense_adjoint_workspace_bytes_ex(lv, flags) (0 = unsupported: a window's H W C must stay below 2^30,
+ *     the tile kernels use 32-bit byte offsets inside a window).  BANET_ADJOINT_TILE_SHAPE(k), k = 1 .. 13: development
  *     switch (A/B) -- the tile kernel and its tile shape (csrc/adjoint.hip::launch_adj_tile); 0 = the default.                                              */
 enum { BANET_ADJOINT_OVERWRITE = 1, BANET_ADJOINT_OVERWRITE_MAP = 2, BANET_ADJOINT_FOLD_TARGET = 4 };
 #define BANET_ADJOINT_TILE_SHAPE(k) (((k) & 15) << 4)
