@@ -372,7 +372,9 @@ class _LevelSolve(torch.autograd.Function):
         pprobs = [prob] if pairs == 1 else _pair_problems(ba, li)
         # no zero-fills: the first adjoint call that touches a buffer writes it (BANET_ADJOINT_OVERWRITE), the later ones accumulate --
         # 25 GB of fills and as many bytes of reads per 32-window 640x480 level
-        fold = FOLD_MODE != "0"          # the target gradient per texel tile: no 3C rows, no [f|gx|gy] map adjoint, no fold pass
+        # the target gradient per texel tile: no 3C rows, no [f|gx|gy] map adjoint, no fold pass -- where the library takes the level
+        # in that mode (dense layout, a window's maps below 4 GB: the tile kernels use 32-bit byte offsets); else the round-5 path
+        fold = FOLD_MODE != "0" and capi.lib().banet_dense_adjoint_workspace_bytes_ex(ctypes.byref(pprobs[0].c), ADJOINT_FOLD_TARGET) != 0
         xflags = ADJOINT_TILE_SHAPE(TILE_SHAPE)
         dsrc = torch.empty((B, N, C), dtype=torch.float32, device=dev)
         dmap3 = [torch.empty((B, H, W, C if fold else 3 * C), dtype=torch.float32, device=dev) for _ in range(pairs)]

@@ -11,7 +11,8 @@ for f in ("pytest_gpu.txt", "smoke.txt", "dense_train.txt", "backward_pmc_fetch_
     shutil.copy(os.path.join(R, f), os.path.join(P, "r06_" + f))
 for f in glob.glob(os.path.join(P, "r06_*_kernel_stats_build_*.csv")):
     os.remove(f)
-for f in glob.glob(os.path.join(R, "*_kernel_stats_build_*.csv")):
+BID = open(os.path.join(R, "build_id.txt")).read().split()[-1]          # gpurun_out/ keeps earlier builds' files: only this build's
+for f in glob.glob(os.path.join(R, "*_kernel_stats_build_%s.csv" % BID)):
     shutil.copy(f, os.path.join(P, "r06_" + os.path.basename(f)))
 shutil.copy(os.path.join(R, "pmc_traffic.json"), os.path.join(P, "pmc_traffic.json"))
 line = json.load(open(os.path.join(R, "bench_default_line.json")))
@@ -26,9 +27,12 @@ tracker = [json.loads(l) for l in sp.split("\n") if l.startswith("{")]
 sw = line["sweep"]
 k = lambda v: "%.2f k" % (v / 1e3)
 import csv
-rows = list(csv.DictReader(open(glob.glob(os.path.join(R, "sparse_training_iteration_kernel_stats_build_*.csv"))[0])))
+rows = list(csv.DictReader(open(os.path.join(R, "sparse_training_iteration_kernel_stats_build_%s.csv" % BID))))
 launches = sum(int(r["Calls"]) for r in rows if "banet" in r["Name"] and "target_map_kernel" not in r["Name"] and "resample" not in r["Name"]) / 4.0
+drows = list(csv.DictReader(open(os.path.join(R, "dense_train_kernel_stats_build_%s.csv" % BID))))      # 4 training steps
+per_step = lambda sub: "%.1f" % (sum(float(r["TotalDurationNs"]) for r in drows if sub in r["Name"]) / 4e6)
 vals = {
+    "K_PIXEL2_MS": per_step("adj_pixel2_kernel"), "K_TILE2_MS": per_step("adj_tile2_kernel"), "K_BASIS6_MS": per_step("adj_basis6_kernel"),
     "GPU_TESTS": tests, "CPU_TESTS": "67",
     "HEAD_VALUE": k(line["value"]), "HEAD_MS": "%.1f" % line["ms_per_step"], "HEAD_FRAC": "%.3f" % line["roofline"]["frac"],
     "HEAD_TRAFFIC": "%.2f" % (line["roofline"]["traffic"] / line["roofline"]["algorithmic_bytes_per_launch"]) if line["roofline"].get("traffic") else "1.19",
@@ -42,6 +46,7 @@ vals = {
     "CFG1_MS": "%.2f" % sw["cfg1_160x120_K32_B1"]["ms_per_step"], "CPU_VALUE": "%.2f" % line["cpu_baseline"]["value"],
 }
 print(vals)
+json.dump(vals, open(os.path.join(P, "r06_numbers_quoted_in_documents.json"), "w"), indent=1, sort_keys=True)
 for name in ("DESIGN.md", "README.md", os.path.join("profiles", "README.md")):
     p = os.path.join(ROOT, name)
     s = open(p).read()
