@@ -72,6 +72,7 @@ struct AdjArgs {
   int* list2;         // [B][N]         scratch of the big-cell sort
   int2* lidx;         // [B][N]         (pixel index, x0 | y0 << 16) in cell-list order: what adj_tile2_kernel addresses with
   int* bigq;          // [1 + B*N/32]   queue of the cells with more than kSortSerial entries (bigq[0] = their number)
+  int reuse_z;        // BANET_ADJOINT_REUSE_DEPTH_SEED: z2 / zeta / e of the previous call on this workspace are valid (adj_basis6_kernel)
 };
 
 __global__ void adj_sym_kernel(const float* __restrict__ g, float* __restrict__ S, int P, size_t total) {
@@ -174,9 +175,12 @@ __global__ __launch_bounds__(kBlock, 2) void adj_basis_kernel(const AdjArgs a) {
 // m (32 contiguous bytes; the four kq lanes of a pixel read 128), splits them (registers) and accumulates.  512 threads: two
 // waves per SIMD.  Epilogue as adj_basis_kernel (same accumulator layout).  flags bit 26 keeps the fp32-MFMA kernel (A/B).
 constexpr int kAdjB6Threads = 512, kAdjB6Waves = kAdjB6Threads / 64;
-template <int NK>   // KP = 16 NK >= K, NK <= 8
+// REUSE (BANET_ADJOINT_REUSE_DEPTH_SEED; the later target frames of a multi-frame window): S_dd, gAtb_d and the basis are those of the
+// previous call on this workspace, so z2 = 2 S_dd b, zeta and e are already there -- only the frame's own q = S_cd b is computed:
+// one column block of MFMAs instead of NK + 1, no z2 traffic.
+template <int NK, bool REUSE>   // KP = 16 NK >= K, NK <= 8
 __global__ __launch_bounds__(kAdjB6Threads) void adj_basis6_kernel(const AdjArgs a) {
-  constexpr int KS = (NK + 1) / 2, NB = NK + 1, KP = 16 * NK;
+  constexpr int KS = (NK + 1) / 2, NB = NK + 1, KP = 16 * NK, JB0 = REUSE ? NK : 0;      // column blocks JB0 .. NK
   extern __shared__ __attribute__((aligned(16))) unsigned sB6[];   // [KS][NB][3][64] quads
   const int b = blockIdx.y, K = a.lv.K, N = a.lv.N, P = 6 + K;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -186,6 +190,7 @@ __global__ __launch_bounds__(kAdjB6Threads) void adj_basis6_kernel(const AdjArgs
     const float* __restrict__ gb = a.gb + (size_t)b * P;
     for (int task = w; task < KS * NB; task += kAdjB6Waves) {
       const int ks = task / NB, jb = task - ks * NB;
+      if (jb < JB0) continue;
       float vv[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(kAdjB6Threads) void adj_basis6_kernel(const AdjArgs
       constexpr int kTa[6] = {2, 0, 1, 1, 0, 0}, kTb[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
       u32x4_t pb[NB][3];
 #pragma unroll
-      for (int jb = 0; jb < NB; ++jb)
+      for (int jb = JB0; jb < NB; ++jb)
 #pragma unroll
         for (int t = 0; t < 3; ++t) pb[jb][t] = *reinterpret_cast<const u32x4_t*>(&sB6[(((ks * NB + jb) * 3 + t) * 64 + lane) * 4]);
       // round 6: the SEED block is the A operand and the basis rows the B operand -- S_dd is symmetric and the extra block is kept
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(kAdjB6Threads) void adj_basis6_kernel(const AdjArgs
 #pragma unroll
       for (int t = 0; t < 6; ++t)       // term-major: consecutive MFMAs write different accumulators
 #pragma unroll
-        for (int jb = 0; jb < NB; ++jb)
+        for (int jb = JB0; jb < NB; ++jb)
           acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8a, pb[jb][kTb[t]]), __builtin_bit_cast(bf16x8a, pa[kTa[t]]),
                                                             acc[jb], 0, 0, 0);
       if (ks + 1 < KS) {
@@ -270,6 +275,17 @@ __global__ __launch_bounds__(kAdjB6Threads) void adj_basis6_kernel(const AdjArgs
     const bool ok = nn < N;
     const size_t ro = (size_t)(ok ? nn : 0) * K;
     float zeta = 0.f;
+    if constexpr (REUSE) {
+      if (ok) {                            // the frame's q; (zeta, e) stay as the first frame's call left them
+        float* __restrict__ ar = arec + (size_t)nn * 8;
+        if (kq == 0) *reinterpret_cast<f32x4*>(ar) = acc[NK];
+        if (kq == 1) {
+          ar[4] = acc[NK][0];
+          ar[5] = acc[NK][1];
+        }
+      }
+      continue;
+    }
     if ((K & 3) == 0) {
 #pragma unroll
       for (int jb = 0; jb < NK; ++jb) {
@@ -2402,9 +2418,15 @@ template <int NK>
 void launch_adj_basis6(const AdjArgs& a, int Ga, hipStream_t s) {
   constexpr int KS = (NK + 1) / 2, NB = NK + 1;
   const size_t shm = (size_t)KS * NB * 3 * 64 * 16;
+  if (a.reuse_z) {
+    if (shm > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&adj_basis6_kernel<NK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipLaunchKernelGGL((adj_basis6_kernel<NK, true>), dim3(std::max(1, Ga / 2), a.lv.B), dim3(kAdjB6Threads), shm, s, a);
+    return;
+  }
   if (shm > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&adj_basis6_kernel<NK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-  hipLaunchKernelGGL((adj_basis6_kernel<NK>), dim3(std::max(1, Ga / 2), a.lv.B), dim3(kAdjB6Threads), shm, s, a);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&adj_basis6_kernel<NK, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+  hipLaunchKernelGGL((adj_basis6_kernel<NK, false>), dim3(std::max(1, Ga / 2), a.lv.B), dim3(kAdjB6Threads), shm, s, a);
 }
 
 template <int NK>
@@ -2470,6 +2492,7 @@ int launch_dense_adjoint(const banet_level_t* lv, const float* R, const float* T
   hipLaunchKernelGGL(adj_sym_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, gAtA, S, P, tot);
   if (hipMemsetAsync(a.cnt, 0, ((size_t)B * HW + (pl.fold ? 1 : 0)) * sizeof(int), s) != hipSuccess) return BANET_ERR_LAUNCH;
   const bool b6 = !(lv->flags & (1 << 26));   // the bf16x6 form of the GEMM-shaped piece (bit 26: fp32 MFMA, A/B)
+  a.reuse_z = ((flags & BANET_ADJOINT_REUSE_DEPTH_SEED) && b6 && K > 16 && K <= 128) ? 1 : 0;     // (the other forms recompute: same result)
   switch ((K + 15) / 16) {
     case 1: launch_adj_basis<1>(a, pl.Ga, s); break;
     case 2: b6 ? launch_adj_basis6<2>(a, pl.Ga, s) : launch_adj_basis<2>(a, pl.Ga, s); break;

@@ -387,7 +387,7 @@ size_t banet_dense_adjoint_workspace_bytes(const banet_level_t* lv) {
 
 size_t banet_dense_adjoint_workspace_bytes_ex(const banet_level_t* lv, int flags) {
   if (!lv || lv->B <= 0 || lv->N <= 0) return 0;
-  if (flags & ~(BANET_ADJOINT_OVERWRITE | BANET_ADJOINT_OVERWRITE_MAP | BANET_ADJOINT_FOLD_TARGET | BANET_ADJOINT_TILE_SHAPE(15))) return 0;
+  if (flags & ~(BANET_ADJOINT_OVERWRITE | BANET_ADJOINT_OVERWRITE_MAP | BANET_ADJOINT_FOLD_TARGET | BANET_ADJOINT_REUSE_DEPTH_SEED | BANET_ADJOINT_TILE_SHAPE(15))) return 0;
   return dense_adjoint_workspace_bytes(lv, flags);
 }
 
@@ -398,7 +398,7 @@ int banet_dense_adjoint_ex_f32(const banet_level_t* lv, const float* R, const fl
   if (lv->K > 0 && (!Wc || !dbasis || !lv->basis)) return BANET_ERR_INVALID_ARG;     // K = 0 (pose only): no coefficient / basis tensors
   if (lv->B <= 0 || lv->N <= 0 || !lv->src || !lv->tgt || !lv->depth) return BANET_ERR_INVALID_ARG;
   if (lv->dense ? !lv->intr : (!lv->rays || !lv->fx || !lv->fy || !lv->ox || !lv->oy)) return BANET_ERR_INVALID_ARG;
-  if (flags & ~(BANET_ADJOINT_OVERWRITE | BANET_ADJOINT_OVERWRITE_MAP | BANET_ADJOINT_FOLD_TARGET | BANET_ADJOINT_TILE_SHAPE(15))) return BANET_ERR_INVALID_ARG;
+  if (flags & ~(BANET_ADJOINT_OVERWRITE | BANET_ADJOINT_OVERWRITE_MAP | BANET_ADJOINT_FOLD_TARGET | BANET_ADJOINT_REUSE_DEPTH_SEED | BANET_ADJOINT_TILE_SHAPE(15))) return BANET_ERR_INVALID_ARG;
   const size_t need = dense_adjoint_workspace_bytes(lv, flags);
   if (need == 0) return BANET_ERR_UNSUPPORTED;
   if (ws_bytes < need || (reinterpret_cast<uintptr_t>(ws) & 255) != 0) return BANET_ERR_WORKSPACE;

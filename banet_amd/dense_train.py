@@ -281,6 +281,8 @@ class SmallStepHip:
 
 ADJOINT_OVERWRITE, ADJOINT_OVERWRITE_MAP = 1, 2      # banet_hip.h: BANET_ADJOINT_OVERWRITE, BANET_ADJOINT_OVERWRITE_MAP
 ADJOINT_FOLD_TARGET = 4                               # banet_hip.h: BANET_ADJOINT_FOLD_TARGET
+ADJOINT_REUSE_DEPTH_SEED = 8                          # banet_hip.h: BANET_ADJOINT_REUSE_DEPTH_SEED (target frames 2.. of a multi-frame window)
+REUSE_MODE = os.environ.get("BANET_ADJOINT_REUSE", "1")   # "0": every frame's call recomputes z2 / zeta / e (A/B; same bits)
 
 
 def ADJOINT_TILE_SHAPE(k):
@@ -415,7 +417,7 @@ class _LevelSolve(torch.autograd.Function):
                 # dmap3[i] is fresh for every frame of the first iteration; dsrc / ddepth / dbasis are shared by the frames
                 dpose, ws = dense_adjoint(pprobs[i], Rv[:, i].contiguous(), Tv[:, i].contiguous(), Wi, gA_i, gb_i, gabs, dsrc,
                                           dmap3[i], ddepth, dbasis, ws, overwrite=first and i == 0, overwrite_map=first, fold=fold,
-                                          extra_flags=xflags)
+                                          extra_flags=xflags | (ADJOINT_REUSE_DEPTH_SEED if (i > 0 and REUSE_MODE != "0") else 0))
                 gR[:, i] += dpose[:, 0:9].reshape(B, 3, 3)
                 gT[:, i] += dpose[:, 9:12].reshape(B, 3, 1)
                 gW += dpose[:, 12:].reshape(B, K, 1)

@@ -31,7 +31,7 @@ extern "C" {
 typedef void* banet_stream_t; /* a hipStream_t (NULL = default stream) */
 #endif
 
-#define BANET_VERSION 150 /* 0.1.5: BANET_ADJOINT_FOLD_TARGET, banet_small_step_adjoint_f32; 0.1.4: banet_dense_adjoint_f32 / banet_target_map_adjoint_f32; 0.1.3: banet_lm_params_t / banet_lm_level_ex_f32 (0.1.2: banet_sample_stats[_grad]_f32; 0.1.1: banet_level_t.pairs) */
+#define BANET_VERSION 150 /* 0.1.5: BANET_ADJOINT_FOLD_TARGET / _REUSE_DEPTH_SEED, banet_small_step_adjoint_f32; 0.1.4: banet_dense_adjoint_f32 / banet_target_map_adjoint_f32; 0.1.3: banet_lm_params_t / banet_lm_level_ex_f32 (0.1.2: banet_sample_stats[_grad]_f32; 0.1.1: banet_level_t.pairs) */
 
 enum {
   BANET_OK = 0,
@@ -349,7 +349,11 @@ int banet_dense_adjoint_f32(const banet_level_t* lv, const float* R, const float
  *     differs: size it with banet_dense_adjoint_workspace_bytes_ex(lv, flags) (0 = unsupported: a window's H W C must stay below 2^30,
  *     the tile kernels use 32-bit byte offsets inside a window).  BANET_ADJOINT_TILE_SHAPE(k), k = 1 .. 13: development
  *     switch (A/B) -- the tile kernel and its tile shape (csrc/adjoint.hip::launch_adj_tile); 0 = the default.                                              */
-enum { BANET_ADJOINT_OVERWRITE = 1, BANET_ADJOINT_OVERWRITE_MAP = 2, BANET_ADJOINT_FOLD_TARGET = 4 };
+/*   BANET_ADJOINT_REUSE_DEPTH_SEED (multi-frame windows: the calls for target frames 2 .. of one iteration): the caller states that
+ *     the depth block of gAtA, the depth part of gAtb, lv->basis and the workspace are those of the PREVIOUS call -- then z2 = 2 S_dd b,
+ *     zeta = b.S_dd b and e = gAtb_d.b of that call are still in the workspace and only the frame's q = S_cd b is computed (one
+ *     column block of the GEMM-shaped piece instead of K/16 + 1).  Same bits as without the flag; ignored where it does not apply.   */
+enum { BANET_ADJOINT_OVERWRITE = 1, BANET_ADJOINT_OVERWRITE_MAP = 2, BANET_ADJOINT_FOLD_TARGET = 4, BANET_ADJOINT_REUSE_DEPTH_SEED = 8 };
 #define BANET_ADJOINT_TILE_SHAPE(k) (((k) & 15) << 4)
 size_t banet_dense_adjoint_workspace_bytes_ex(const banet_level_t* lv, int flags);
 int banet_dense_adjoint_ex_f32(const banet_level_t* lv, const float* R, const float* T, const float* Wc, const float* gAtA,

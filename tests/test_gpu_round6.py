@@ -142,6 +142,35 @@ def test_solve_differentiable_fold_and_row_gather_backward_agree(monkeypatch):
             assert float((x - y).abs().max()) <= 2e-5 * max(float(y.abs().max()), 1e-30)
 
 
+def test_multi_frame_backward_reusing_the_depth_seed_products_is_bit_equal(monkeypatch):
+    """Multi-frame windows: the adjoint calls for target frames 2.. of an iteration carry BANET_ADJOINT_REUSE_DEPTH_SEED (z2 = 2 S_dd b,
+    zeta, e of the first frame's call are still in the workspace; only q = S_cd b is computed) -- every gradient bit-equal to the
+    calls that recompute everything (BANET_ADJOINT_REUSE=0), at K = 32 / 128 (the bf16 form) and K = 16 (flag ignored)."""
+    from banet_amd import dense as bdense, dense_train, synth as bsynth
+    from banet_amd.bundlenet import he_normal_lambda_weights
+    for frames, K in ((3, 32), (5, 128), (3, 16)):
+        B, H, W, C = 2, 48, 64, 32
+        scales = [2, 1]
+        intr, levels, gt = bsynth.make_dense_windows(B, H, W, C, K, scales, 11, torch.device(DEV), trans_mag=0.06, pairs=frames - 1)
+        mlps = [[(w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)) for w, b in he_normal_lambda_weights(C, 300 + i)]
+                for i in range(len(scales))]
+        for lv in levels:
+            for name in ("src", "tgt", "depth", "basis"):
+                setattr(lv, name, getattr(lv, name).requires_grad_(True))
+        ba = bdense.DenseBA(intr, levels, mlps, "bundle", 1.0)
+        T0 = (gt["T"] * 0.7).reshape(B * (frames - 1), 3, 1).to(DEV)
+        leaves = [getattr(lv, nm) for lv in levels for nm in ("src", "tgt", "depth", "basis")] + [x for lw in mlps for wb in lw for x in wb]
+        res = {}
+        for mode in ("1", "0"):
+            monkeypatch.setattr(dense_train, "REUSE_MODE", mode)
+            Rr, Tt, Ww = ba.solve_differentiable([2, 2], T=T0)
+            loss = (Rr * torch.arange(Rr.numel(), device=DEV).reshape(Rr.shape).float().cos()).sum() + Tt.sum() + (Ww * 0.5).sum()
+            res[mode] = torch.autograd.grad(loss, leaves)
+        for x, y in zip(res["1"], res["0"]):
+            assert torch.isfinite(x).all()
+            assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize("variant,B,C,K,pairs,l2", [("bundle", 3, 128, 128, 1, 1000.0), ("bundle", 2, 32, 40, 3, 1.0),
                                                     ("bundle_camera", 4, 16, 0, 1, 1.0), ("bundle", 2, 70, 33, 1, 10.0),
                                                     ("bundle", 1, 256, 64, 2, 1000.0)])

@@ -20,7 +20,7 @@ det = json.load(open(os.path.join(R, "bench_detail.json")))
 tests = re.search(r"(\d+) passed", open(os.path.join(R, "pytest_gpu.txt")).read()).group(1)
 dt = open(os.path.join(R, "dense_train.txt")).read()
 fb = re.findall(r"forward only \(lm_level\)\s+([\d.]+) ms.*?\n\s*forward \+ backward \(solve_differentiable\)\s+([\d.]+) ms.*?([\d.]+)x the forward\), peak extra memory ([\d.]+) GB", dt)
-# order: 32, 8, 2 windows, 8 five-frame; then FOLD=0, SMALL_STEP_HIP=0, TILE=1
+# order: 32, 8, 2 windows, 8 five-frame; 8 five-frame with REUSE=0; then FOLD=0, SMALL_STEP_HIP=0 (TILE=1 carries a prefix: not matched)
 sp = open(os.path.join(R, "sparse_training_and_tracker.txt")).read()
 sparse_ms = re.search(r"fused\s+B=4 N=4096.*?: ([\d.]+) ms", sp).group(1)
 tracker = [json.loads(l) for l in sp.split("\n") if l.startswith("{")]
@@ -38,7 +38,7 @@ vals = {
     "HEAD_TRAFFIC": "%.2f" % (line["roofline"]["traffic"] / line["roofline"]["algorithmic_bytes_per_launch"]) if line["roofline"].get("traffic") else "1.19",
     "EXACT_VALUE": k(line["value_exact_syrk"]),
     "FWD_MS": fb[0][0], "BWD_MS": fb[0][1], "BWD_X": fb[0][2], "BWD_GB": "%.1f" % float(fb[0][3]),
-    "BWD8_MS": fb[1][1], "BWD85_MS": fb[3][1], "BWD_OLDPATH_MS": fb[4][1], "BWD_TORCHSMALL_MS": fb[5][1],
+    "BWD8_MS": fb[1][1], "BWD85_MS": fb[3][1], "BWD85_NOREUSE_MS": fb[4][1], "BWD_OLDPATH_MS": fb[5][1], "BWD_TORCHSMALL_MS": fb[6][1],
     "SPARSE_MS": sparse_ms, "SPARSE_LAUNCHES": "%.0f" % launches,
     "TRACKER_MS": "%.2f" % tracker[0]["ms_per_solve"],
     "B1_VALUE": k(sw["B1_2frame"]["value"]), "B8_VALUE": k(sw["B8_2frame"]["value"]), "B256_VALUE": k(sw["B256_2frame"]["value"]),

@@ -45,6 +45,8 @@ tail -1 $OUT/bench_2rank.err
 # ---- the dense training step
 { for w in 32 8 2; do timeout 600 python tools/bench_dense_train.py $w 480 640 2 2>&1 | grep -v amdgpu | tail -3; done
   PFRAMES=5 timeout 600 python tools/bench_dense_train.py 8 480 640 2 2>&1 | grep -v amdgpu | tail -3
+  echo "--- 8 five-frame windows with BANET_ADJOINT_REUSE=0 (every target frame's call recomputes z2 / zeta / e)"
+  BANET_ADJOINT_REUSE=0 PFRAMES=5 timeout 600 python tools/bench_dense_train.py 8 480 640 2 2>&1 | grep -v amdgpu | tail -3 | head -2
   echo "--- A/B on this box: BANET_ADJOINT_FOLD=0 (round-5 rows + per-texel gather), BANET_SMALL_STEP_HIP=0 (torch small step)"
   BANET_ADJOINT_FOLD=0 timeout 600 python tools/bench_dense_train.py 32 480 640 2 2>&1 | grep -v amdgpu | tail -3 | head -2
   BANET_SMALL_STEP_HIP=0 timeout 600 python tools/bench_dense_train.py 32 480 640 2 2>&1 | grep -v amdgpu | tail -3 | head -2
