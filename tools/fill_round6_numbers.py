@@ -10,7 +10,8 @@ for f in ("pytest_gpu.txt", "smoke.txt", "dense_train.txt", "backward_pmc_fetch_
           "bench_2rank_gloo_one_gpu_line.json"):
     shutil.copy(os.path.join(R, f), os.path.join(P, "r06_" + f))
 for f in glob.glob(os.path.join(P, "r06_*_kernel_stats_build_*.csv")):
-    os.remove(f)
+    if "959cda8c4e94dfd4" not in f:          # (the dense-training statistics of the build before the instruction pass stay: its before-record)
+        os.remove(f)
 BID = open(os.path.join(R, "build_id.txt")).read().split()[-1]          # gpurun_out/ keeps earlier builds' files: only this build's
 for f in glob.glob(os.path.join(R, "*_kernel_stats_build_%s.csv" % BID)):
     shutil.copy(f, os.path.join(P, "r06_" + os.path.basename(f)))
@@ -46,13 +47,45 @@ vals = {
     "CFG1_MS": "%.2f" % sw["cfg1_160x120_K32_B1"]["ms_per_step"], "CPU_VALUE": "%.2f" % line["cpu_baseline"]["value"],
 }
 print(vals)
-json.dump(vals, open(os.path.join(P, "r06_numbers_quoted_in_documents.json"), "w"), indent=1, sort_keys=True)
+NUM = os.path.join(P, "r06_numbers_quoted_in_documents.json")
+prev = json.load(open(NUM)) if os.path.exists(NUM) else {}
+# Values that are distinctive strings are replaced wherever they stand; the short ones only inside these contexts ({} = the value)
+CONTEXT = {
+    "GPU_TESTS": ["Parity: {} GPU tests", "({} tests)", "again ({} passed)"],
+    "CPU_TESTS": ["+ {} CPU tests"],
+    "BWD_X": ["8.46 \u2192 {} \u00d7", "8.46 -> {} x", ": {} \u00d7), peak", "= {} \u00d7 the forward"],
+    "BWD_GB": ["47.6 \u2192\n{} GB", "47.6 \u2192 {} GB", "47.6 ->\n{} GB", "47.6 -> {} GB", "memory **{} GB**", "forward (target 5 \u00d7), {} GB"],
+    "HEAD_FRAC": ["gather {} of the 8 TB/s"],
+    "HEAD_MS": ["{} ms per 32-window"],
+    "HEAD_TRAFFIC": ["roofline on {} \u00d7 its", "roofline on {} x its"],
+    "TRACKER_MS": ["2.06 \u2192 **{} ms**", "2.06 \u2192 {} ms", "2.06 -> {} ms"],
+    "SPARSE_MS": ["**{} ms** per forward + backward at 4 pairs", "2.0 \u2192 {} ms", "2.0 -> {} ms", "2.0 \u2192\n**{} ms**"],
+    "SPARSE_LAUNCHES": ["4096 points, {} library launches"],
+    "CFG1_MS": ["cfg-1 ({} ms", "cfg-1 {} ms", "cfg-1\n{} ms"],
+    "CPU_VALUE": ["CPU baseline {} it/s"],
+    "CFG5_VALUE": ["cfg-5 share {}) have", "K = 256) {}, cfg-1"],
+    "K_BASIS6_MS": ["**{} ms** (13.6)"], "K_PIXEL2_MS": ["**{} ms** (42;"], "K_TILE2_MS": ["**{} ms** (adj_map2"],
+}
 for name in ("DESIGN.md", "README.md", os.path.join("profiles", "README.md")):
     p = os.path.join(ROOT, name)
     s = open(p).read()
-    for key, v in vals.items():
+    for key, v in vals.items():                       # first use: the @PLACEHOLDER@ form
         s = s.replace("@%s@" % key, str(v))
+    for key, v in vals.items():                       # later runs: the previous run's figures -> this run's
+        o = prev.get(key)
+        if o is None or o == v:
+            continue
+        if key in CONTEXT:
+            n = 0
+            for c in CONTEXT[key]:
+                n += s.count(c.format(o))
+                s = s.replace(c.format(o), c.format(v))
+        else:
+            n = s.count(o)
+            s = s.replace(o, str(v))
+        print("%-22s %-18s %s -> %s: %d places" % (name, key, o, v, n))
     left = set(re.findall(r"@[A-Z0-9_]+@", s))
     if left:
         print(name, "unfilled:", left)
     open(p, "w").write(s)
+json.dump(vals, open(NUM, "w"), indent=1, sort_keys=True)
