@@ -31,7 +31,7 @@ extern "C" {
 typedef void* banet_stream_t; /* a hipStream_t (NULL = default stream) */
 #endif
 
-#define BANET_VERSION 150 /* 0.1.5: BANET_ADJOINT_FOLD_TARGET / _REUSE_DEPTH_SEED, banet_small_step_adjoint_f32; 0.1.4: banet_dense_adjoint_f32 / banet_target_map_adjoint_f32; 0.1.3: banet_lm_params_t / banet_lm_level_ex_f32 (0.1.2: banet_sample_stats[_grad]_f32; 0.1.1: banet_level_t.pairs) */
+#define BANET_VERSION 150 /* 0.1.5: BANET_ADJOINT_FOLD_TARGET, banet_small_step_adjoint_f32; 0.1.4: banet_dense_adjoint_f32 / banet_target_map_adjoint_f32; 0.1.3: banet_lm_params_t / banet_lm_level_ex_f32 (0.1.2: banet_sample_stats[_grad]_f32; 0.1.1: banet_level_t.pairs) */
 
 enum {
   BANET_OK = 0,

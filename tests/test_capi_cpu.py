@@ -514,3 +514,22 @@ def test_round6_backward_entry_points_on_the_host(capi):
     assert ws(capi.BUNDLE, 8, 1228800, 128, 256, 7) == 0                                      # P = 298: beyond the SPD kernel's LDS
     assert ws(capi.BUNDLE, 8, 1000, 300, 16, 1) == 0 and ws(capi.BUNDLE, 8, 1000, 64, 0, 1) == 0 and ws(capi.LEGACY_LM, 1, 100, 16, 0, 1) == 0
     assert L.banet_small_step_adjoint_f32(capi.BUNDLE, 2, 100, 16, 8, 1, 1000.0, None, *([None] * 14), None, None, 0, None) == -1
+
+
+def test_committed_traffic_file_belongs_to_the_committed_sources():
+    """profiles/pmc_traffic.json (what bench.py quotes as roofline.traffic) names the build it was measured on; the digest build.sh
+    bakes into the library -- every csrc/*.hip, *.hpp, include/banet_hip.h and the compile flags -- must be that build for the tree
+    as committed: a source edit after the evidence run (even in a comment) would otherwise make bench.py report traffic = null."""
+    import hashlib
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "banet_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".hpp"))):
+        h.update(open(os.path.join(csrc, name), "rb").read())
+    h.update(open(os.path.join(root, "include", "banet_hip.h"), "rb").read())
+    flags = re.search(r'^FLAGS="([^"]*)"', open(os.path.join(csrc, "build.sh")).read(), re.M).group(1)
+    h.update((flags + " \n").encode())           # build.sh: echo "$FLAGS ${EXTRA_HIPCC_FLAGS:-}" with no extra flags
+    digest = h.hexdigest()[:16]
+    traffic = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
+    assert traffic["build_id"] == digest, (traffic["build_id"], digest)

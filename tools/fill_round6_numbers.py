@@ -34,7 +34,7 @@ drows = list(csv.DictReader(open(os.path.join(R, "dense_train_kernel_stats_build
 per_step = lambda sub: "%.1f" % (sum(float(r["TotalDurationNs"]) for r in drows if sub in r["Name"]) / 4e6)
 vals = {
     "K_PIXEL2_MS": per_step("adj_pixel2_kernel"), "K_TILE2_MS": per_step("adj_tile2_kernel"), "K_BASIS6_MS": per_step("adj_basis6_kernel"),
-    "GPU_TESTS": tests, "CPU_TESTS": "67",
+    "GPU_TESTS": tests, "CPU_TESTS": "68",
     "HEAD_VALUE": k(line["value"]), "HEAD_MS": "%.1f" % line["ms_per_step"], "HEAD_FRAC": "%.3f" % line["roofline"]["frac"],
     "HEAD_TRAFFIC": "%.2f" % (line["roofline"]["traffic"] / line["roofline"]["algorithmic_bytes_per_launch"]) if line["roofline"].get("traffic") else "1.19",
     "EXACT_VALUE": k(line["value_exact_syrk"]),
